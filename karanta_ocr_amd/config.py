@@ -1,0 +1,213 @@
+"""Model geometry for the Qwen2-VL family served on the karanta OCR hot path.
+
+The reference never states these numbers: it hands a model *name* to ``vllm serve``
+(/root/reference/karanta/pipeline.py:707-742) or to ``from_pretrained``
+(/root/reference/karanta/training/test_trained_model.py:15-22).  The dimensions
+below are the public Qwen2-VL model-card values collected in SURVEY.md §8; a real
+checkpoint's ``config.json`` overrides them through :func:`from_hf_config_dict`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Dict, List, Tuple
+
+
+@dataclass(frozen=True)
+class VisionConfig:
+    depth: int = 32
+    embed_dim: int = 1280
+    num_heads: int = 16
+    mlp_ratio: int = 4
+    patch_size: int = 14
+    spatial_merge_size: int = 2
+    temporal_patch_size: int = 2
+    in_channels: int = 3
+    hidden_size: int = 1536  # merger output = decoder width
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+    @property
+    def mlp_dim(self) -> int:
+        return self.embed_dim * self.mlp_ratio
+
+    @property
+    def patch_dim(self) -> int:
+        return self.in_channels * self.temporal_patch_size * self.patch_size * self.patch_size
+
+    @property
+    def patch_dim_padded(self) -> int:
+        """K of the patch-embed GEMM rounded up to the GEMM's BK=64."""
+        return (self.patch_dim + 63) // 64 * 64
+
+    @property
+    def merge_dim(self) -> int:
+        return self.embed_dim * self.spatial_merge_size**2
+
+
+@dataclass(frozen=True)
+class TextConfig:
+    hidden_size: int = 1536
+    intermediate_size: int = 8960
+    num_layers: int = 28
+    num_heads: int = 12
+    num_kv_heads: int = 2
+    head_dim: int = 128
+    vocab_size: int = 151936
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: Tuple[int, int, int] = (16, 24, 24)
+    tie_word_embeddings: bool = True
+
+    @property
+    def q_dim(self) -> int:
+        return self.num_heads * self.head_dim
+
+    @property
+    def kv_dim(self) -> int:
+        return self.num_kv_heads * self.head_dim
+
+    @property
+    def qkv_dim(self) -> int:
+        return self.q_dim + 2 * self.kv_dim
+
+    @property
+    def kv_bytes_per_token(self) -> int:
+        """bf16 K+V bytes cached per token over all layers."""
+        return 2 * self.num_layers * self.num_kv_heads * self.head_dim * 2
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    name: str
+    vision: VisionConfig
+    text: TextConfig
+    image_token_id: int = 151655
+    video_token_id: int = 151656
+    vision_start_token_id: int = 151652
+    vision_end_token_id: int = 151653
+    eos_token_ids: Tuple[int, ...] = (151645, 151643)
+    pad_token_id: int = 151643
+
+    def decoder_weight_bytes(self) -> int:
+        """Bytes of decoder weights read once per decode step in bf16
+        (all layer Linears + biases + norms + final norm + lm_head): the ``W_dec``
+        of SURVEY.md §8(d) / BASELINE.md §3."""
+        t = self.text
+        per_layer = (
+            t.hidden_size * t.qkv_dim + t.qkv_dim  # qkv weight + bias
+            + t.q_dim * t.hidden_size  # o_proj
+            + 3 * t.hidden_size * t.intermediate_size  # gate, up, down
+            + 2 * t.hidden_size  # two RMSNorm weights
+        )
+        total = t.num_layers * per_layer + t.hidden_size + t.vocab_size * t.hidden_size
+        return 2 * total
+
+
+QWEN2_VL_2B = ModelConfig(
+    name="Qwen2-VL-2B",
+    vision=VisionConfig(hidden_size=1536),
+    text=TextConfig(),
+)
+
+QWEN2_VL_7B = ModelConfig(
+    name="Qwen2-VL-7B",
+    vision=VisionConfig(hidden_size=3584),
+    text=TextConfig(
+        hidden_size=3584,
+        intermediate_size=18944,
+        num_layers=28,
+        num_heads=28,
+        num_kv_heads=4,
+        vocab_size=152064,
+        tie_word_embeddings=False,
+    ),
+)
+
+# Test-sized model with the *production* head dims (ViT 80, decoder 128) so the same
+# HIP kernels run; every GEMM K is a multiple of 64.  Used by tests/golden.
+TINY = ModelConfig(
+    name="tiny",
+    vision=VisionConfig(depth=2, embed_dim=320, num_heads=4, hidden_size=256),
+    text=TextConfig(
+        hidden_size=256,
+        intermediate_size=512,
+        num_layers=2,
+        num_heads=2,
+        num_kv_heads=1,
+        vocab_size=512,
+        tie_word_embeddings=False,
+    ),
+    image_token_id=500,
+    video_token_id=501,
+    vision_start_token_id=498,
+    vision_end_token_id=499,
+    eos_token_ids=(497, 496),
+    pad_token_id=496,
+)
+
+# TINY with a GQA group of 3 and tied embeddings (second golden model).
+TINY_GQA = replace(
+    TINY,
+    name="tiny-gqa",
+    vision=replace(TINY.vision, hidden_size=384),
+    text=replace(
+        TINY.text,
+        hidden_size=384,
+        intermediate_size=768,
+        num_heads=3,
+        num_kv_heads=1,
+        num_layers=3,
+        tie_word_embeddings=True,
+    ),
+)
+
+CONFIGS: Dict[str, ModelConfig] = {
+    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, TINY, TINY_GQA)
+}
+
+
+def from_hf_config_dict(d: dict, name: str = "hf") -> ModelConfig:
+    """Build a :class:`ModelConfig` from a Qwen2-VL ``config.json`` dict (either the
+    transformers-4 flat layout or the transformers-5 ``text_config`` layout)."""
+    t = d.get("text_config", d)
+    v = d["vision_config"]
+    rope = t.get("rope_parameters") or t.get("rope_scaling") or {}
+    heads = t["num_attention_heads"]
+    text = TextConfig(
+        hidden_size=t["hidden_size"],
+        intermediate_size=t["intermediate_size"],
+        num_layers=t["num_hidden_layers"],
+        num_heads=heads,
+        num_kv_heads=t.get("num_key_value_heads", heads),
+        head_dim=t.get("head_dim") or t["hidden_size"] // heads,
+        vocab_size=t["vocab_size"],
+        rms_norm_eps=t.get("rms_norm_eps", 1e-6),
+        rope_theta=float(rope.get("rope_theta", t.get("rope_theta", 1e6))),
+        mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))),
+        tie_word_embeddings=bool(d.get("tie_word_embeddings", t.get("tie_word_embeddings", False))),
+    )
+    vision = VisionConfig(
+        depth=v["depth"],
+        embed_dim=v["embed_dim"],
+        num_heads=v["num_heads"],
+        mlp_ratio=int(v.get("mlp_ratio", 4)),
+        patch_size=v.get("patch_size", 14),
+        spatial_merge_size=v.get("spatial_merge_size", 2),
+        temporal_patch_size=v.get("temporal_patch_size", 2),
+        in_channels=v.get("in_channels", v.get("in_chans", 3)),
+        hidden_size=v["hidden_size"],
+    )
+    eos = d.get("eos_token_id", 151645)
+    eos = tuple(eos) if isinstance(eos, (list, tuple)) else (eos, 151643)
+    return ModelConfig(
+        name=name,
+        vision=vision,
+        text=text,
+        image_token_id=d.get("image_token_id", 151655),
+        video_token_id=d.get("video_token_id", 151656),
+        vision_start_token_id=d.get("vision_start_token_id", 151652),
+        vision_end_token_id=d.get("vision_end_token_id", 151653),
+        eos_token_ids=eos,
+    )

@@ -1,0 +1,173 @@
+"""Host-side weight store for the Qwen2-VL hot path.
+
+Names follow the Hugging Face state-dict (transformers-5 layout,
+``model.visual.*`` / ``model.language_model.*`` / ``lm_head.weight``) so a real
+checkpoint — the thing the reference points ``vllm serve`` at,
+/root/reference/karanta/pipeline.py:707-742 — loads without a mapping table; the
+transformers-4 hub layout (``visual.*`` / ``model.layers.*``) is renamed on load.
+
+Everything here is numpy on the host.  Packing for the device lives in engine.py.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+
+from .config import ModelConfig, from_hf_config_dict
+
+# ----------------------------------------------------------------------------- bf16
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round fp32 → nearest-even bf16, returned as fp32 (NaN preserved)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    out = ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+    return np.where(np.isnan(x), x, out)
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 → bf16 bit pattern (uint16), round-to-nearest-even."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    return ((u + r) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+# ----------------------------------------------------------------------------- names
+
+
+def weight_shapes(cfg: ModelConfig) -> Dict[str, tuple]:
+    """Every parameter of the model, HF name → shape."""
+    v, t = cfg.vision, cfg.text
+    s: Dict[str, tuple] = {}
+    s["model.visual.patch_embed.proj.weight"] = (
+        v.embed_dim, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size)
+    for i in range(v.depth):
+        p = f"model.visual.blocks.{i}."
+        s[p + "norm1.weight"] = (v.embed_dim,)
+        s[p + "norm1.bias"] = (v.embed_dim,)
+        s[p + "norm2.weight"] = (v.embed_dim,)
+        s[p + "norm2.bias"] = (v.embed_dim,)
+        s[p + "attn.qkv.weight"] = (3 * v.embed_dim, v.embed_dim)
+        s[p + "attn.qkv.bias"] = (3 * v.embed_dim,)
+        s[p + "attn.proj.weight"] = (v.embed_dim, v.embed_dim)
+        s[p + "attn.proj.bias"] = (v.embed_dim,)
+        s[p + "mlp.fc1.weight"] = (v.mlp_dim, v.embed_dim)
+        s[p + "mlp.fc1.bias"] = (v.mlp_dim,)
+        s[p + "mlp.fc2.weight"] = (v.embed_dim, v.mlp_dim)
+        s[p + "mlp.fc2.bias"] = (v.embed_dim,)
+    s["model.visual.merger.ln_q.weight"] = (v.embed_dim,)
+    s["model.visual.merger.ln_q.bias"] = (v.embed_dim,)
+    s["model.visual.merger.mlp.0.weight"] = (v.merge_dim, v.merge_dim)
+    s["model.visual.merger.mlp.0.bias"] = (v.merge_dim,)
+    s["model.visual.merger.mlp.2.weight"] = (v.hidden_size, v.merge_dim)
+    s["model.visual.merger.mlp.2.bias"] = (v.hidden_size,)
+    s["model.language_model.embed_tokens.weight"] = (t.vocab_size, t.hidden_size)
+    for i in range(t.num_layers):
+        p = f"model.language_model.layers.{i}."
+        s[p + "self_attn.q_proj.weight"] = (t.q_dim, t.hidden_size)
+        s[p + "self_attn.q_proj.bias"] = (t.q_dim,)
+        s[p + "self_attn.k_proj.weight"] = (t.kv_dim, t.hidden_size)
+        s[p + "self_attn.k_proj.bias"] = (t.kv_dim,)
+        s[p + "self_attn.v_proj.weight"] = (t.kv_dim, t.hidden_size)
+        s[p + "self_attn.v_proj.bias"] = (t.kv_dim,)
+        s[p + "self_attn.o_proj.weight"] = (t.hidden_size, t.q_dim)
+        s[p + "mlp.gate_proj.weight"] = (t.intermediate_size, t.hidden_size)
+        s[p + "mlp.up_proj.weight"] = (t.intermediate_size, t.hidden_size)
+        s[p + "mlp.down_proj.weight"] = (t.hidden_size, t.intermediate_size)
+        s[p + "input_layernorm.weight"] = (t.hidden_size,)
+        s[p + "post_attention_layernorm.weight"] = (t.hidden_size,)
+    s["model.language_model.norm.weight"] = (t.hidden_size,)
+    if not t.tie_word_embeddings:
+        s["lm_head.weight"] = (t.vocab_size, t.hidden_size)
+    return s
+
+
+def random_weights(cfg: ModelConfig, seed: int = 0, as_bits: bool = False) -> Dict[str, np.ndarray]:
+    """Seeded random-init weights, every value exactly representable in bf16.
+
+    One ``np.random.default_rng([seed, index])`` stream per tensor (PCG64: stable across
+    machines and numpy versions), so the golden script, the oracle, the tests and the GPU
+    engine all see bit-identical parameters without shipping them.
+
+    Matrices ~ N(0, 1/sqrt(fan_in)); norm weights 1 + N(0, 0.1); biases N(0, 0.02).
+    With ``as_bits`` the tensors are returned as bf16 bit patterns (uint16) — half
+    the host memory for the full-size bench models.
+    """
+    out: Dict[str, np.ndarray] = {}
+    for idx, (name, shape) in enumerate(weight_shapes(cfg).items()):
+        rng = np.random.default_rng([seed, idx])
+        n = int(np.prod(shape))
+        if name.endswith("bias"):
+            w = rng.standard_normal(n, dtype=np.float32) * np.float32(0.02)
+        elif len(shape) == 1:
+            w = np.float32(1.0) + rng.standard_normal(n, dtype=np.float32) * np.float32(0.1)
+        elif "embed_tokens" in name:
+            w = rng.standard_normal(n, dtype=np.float32) * np.float32(0.5)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            w = rng.standard_normal(n, dtype=np.float32) * np.float32(1.0 / np.sqrt(fan_in))
+        w = w.reshape(shape)
+        out[name] = to_bf16_bits(w) if as_bits else bf16_round(w)
+    return out
+
+
+# ----------------------------------------------------------------------------- checkpoints
+
+_V4_RENAMES = (
+    ("visual.", "model.visual."),
+    ("model.embed_tokens.", "model.language_model.embed_tokens."),
+    ("model.layers.", "model.language_model.layers."),
+    ("model.norm.", "model.language_model.norm."),
+)
+
+
+def canonical_name(name: str) -> str:
+    """Map a transformers-4 hub name to the transformers-5 name used internally."""
+    if name.startswith("model.visual.") or name.startswith("model.language_model.") or name == "lm_head.weight":
+        return name
+    for old, new in _V4_RENAMES:
+        if name.startswith(old):
+            return new + name[len(old):]
+    return name
+
+
+def load_checkpoint(model_dir: str) -> tuple:
+    """Load ``config.json`` + ``*.safetensors`` from a local directory.
+
+    Returns ``(ModelConfig, {name: np.ndarray})``.  bf16 tensors come back as uint16
+    bit patterns (safetensors has no numpy bf16); callers use :func:`from_bf16_bits`.
+    """
+    from safetensors import safe_open  # local import: only needed with real weights
+
+    with open(os.path.join(model_dir, "config.json")) as f:
+        cfg = from_hf_config_dict(json.load(f), name=os.path.basename(model_dir.rstrip("/")))
+    import torch
+
+    tensors: Dict[str, np.ndarray] = {}
+    files = sorted(f for f in os.listdir(model_dir) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {model_dir}")
+    for fn in files:
+        with safe_open(os.path.join(model_dir, fn), framework="pt") as sf:
+            for k in sf.keys():
+                t = sf.get_tensor(k)
+                if t.dtype == torch.bfloat16:
+                    arr = t.view(torch.int16).numpy().view(np.uint16)
+                else:
+                    arr = t.float().numpy()
+                tensors[canonical_name(k)] = arr
+    return cfg, tensors
+
+
+def as_f32(w: np.ndarray) -> np.ndarray:
+    return from_bf16_bits(w) if w.dtype == np.uint16 else np.asarray(w, dtype=np.float32)

@@ -1,0 +1,496 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product package.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; ``karanta_ocr_amd`` must not (tests/test_layout.py enforces it).
+
+What it restates
+----------------
+The reference (karanta-ocr) holds *no* model arithmetic: the Qwen2-VL image-encoder +
+text-decoder forward runs inside an external ``vllm serve`` process
+(/root/reference/karanta/pipeline.py:707-742 spawn, :317-319 POST;
+/root/reference/bulk_processing/workers/vllm_client.py:209 POST) or inside Hugging Face
+``model.generate`` (/root/reference/karanta/training/test_trained_model.py:76-99).
+``vllm`` is unpinned and absent; ``transformers`` is pinned 4.53.3 in the reference's
+uv.lock (4.51.3 in requirements.txt:65) and present in the build container as 5.15.0.
+This file restates the *published* Qwen2-VL algorithm in numpy, function by function;
+each docstring names the reference call site it serves and the transformers symbol whose
+semantics it follows ("TF:" = transformers/models/qwen2_vl/).
+
+Pinning
+-------
+The reference has no golden vectors for this path.  The oracle is
+pinned against outputs of the Hugging Face implementation run in the build container:
+``tests/golden/make_golden.py`` generated ``tests/golden/*.npz`` from transformers
+5.15.0 (seeded tiny configs, fp32, eager attention) and ``tests/test_oracle_golden.py``
+checks every function here against them.
+
+dtype policy
+------------
+``policy="fp32"`` is plain fp32 (what the HF CPU path computes).
+``policy="bf16"`` rounds activations to bf16 at the points where the HIP engine stores
+bf16 to HBM (kernel boundaries), keeping fp32 accumulation inside each op — the
+"same dtype policy" oracle that SURVEY.md §7 asks greedy-token equality to be stated
+against.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+
+# =============================================================================
+# small helpers
+# =============================================================================
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 → nearest-even bf16 → fp32."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    out = ((u + r) & np.uint32(0xFFFF0000)).view(F32)
+    return np.where(np.isnan(x), x, out)
+
+
+class _Policy:
+    def __init__(self, name: str):
+        if name not in ("fp32", "bf16"):
+            raise ValueError(name)
+        self.name = name
+
+    def __call__(self, x: np.ndarray) -> np.ndarray:
+        return bf16_round(x) if self.name == "bf16" else np.asarray(x, dtype=F32)
+
+
+def _w(weights: Dict[str, np.ndarray], name: str) -> np.ndarray:
+    w = weights[name]
+    if w.dtype == np.uint16:  # bf16 bit pattern
+        return (w.astype(np.uint32) << 16).view(F32)
+    return np.asarray(w, dtype=F32)
+
+
+def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+    """``torch.nn.Linear``: x @ w.T + b, fp32 accumulate."""
+    y = x.astype(F32) @ w.T.astype(F32)
+    if b is not None:
+        y = y + b.astype(F32)
+    return y.astype(F32)
+
+
+def softmax_lastdim(x: np.ndarray) -> np.ndarray:
+    m = x.max(axis=-1, keepdims=True)
+    e = np.exp((x - m).astype(F32))
+    return (e / e.sum(axis=-1, keepdims=True)).astype(F32)
+
+
+def rotate_half(x: np.ndarray) -> np.ndarray:
+    """TF:modeling_qwen2_vl.py:173-177."""
+    h = x.shape[-1] // 2
+    return np.concatenate([-x[..., h:], x[..., :h]], axis=-1)
+
+
+def quick_gelu(x: np.ndarray) -> np.ndarray:
+    """ViT MLP activation, ``x * sigmoid(1.702 x)`` (TF:modeling_qwen2_vl.py:293-301)."""
+    x = x.astype(F32)
+    return (x / (1.0 + np.exp(-1.702 * x))).astype(F32)
+
+
+def gelu_erf(x: np.ndarray) -> np.ndarray:
+    """Exact GELU of the PatchMerger MLP (``nn.GELU()``, TF:modeling_qwen2_vl.py:277-290)."""
+    x = x.astype(np.float64)
+    erf = np.vectorize(math.erf, otypes=[np.float64])
+    return (0.5 * x * (1.0 + erf(x / math.sqrt(2.0)))).astype(F32)
+
+
+def silu(x: np.ndarray) -> np.ndarray:
+    x = x.astype(F32)
+    return (x / (1.0 + np.exp(-x))).astype(F32)
+
+
+def layer_norm(x: np.ndarray, w: np.ndarray, b: np.ndarray, eps: float = 1e-6) -> np.ndarray:
+    """``nn.LayerNorm`` with bias, eps 1e-6 (ViT blocks and merger)."""
+    x = x.astype(F32)
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    return ((x - mu) / np.sqrt(var + eps) * w + b).astype(F32)
+
+
+def rms_norm(x: np.ndarray, w: np.ndarray, eps: float = 1e-6, pol: Optional[_Policy] = None) -> np.ndarray:
+    """``Qwen2VLRMSNorm`` (TF:modeling_qwen2_vl.py:96-110):
+    ``w * (x * rsqrt(mean(x^2) + eps)).to(input_dtype)`` — the cast to the input dtype
+    happens *before* the multiply by ``w``."""
+    x = x.astype(F32)
+    var = (x * x).mean(axis=-1, keepdims=True)
+    y = x * (1.0 / np.sqrt(var + F32(eps)))
+    if pol is not None:
+        y = pol(y)
+    return (w * y).astype(F32)
+
+
+# =============================================================================
+# image front end (host side of the reference: the PNG/JPEG data-URL inside
+# create_vision_message, /root/reference/karanta/data/utils.py:269-297, becomes
+# pixel_values + image_grid_thw inside the server)
+# =============================================================================
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def smart_resize(height: int, width: int, factor: int = 28,
+                 min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280) -> Tuple[int, int]:
+    """TF:image_processing_pil_qwen2_vl.py:57-83.  Python ``round`` (banker's) and
+    float64 sqrt, exactly as there."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError("absolute aspect ratio must be smaller than 200")
+    h_bar = round(height / factor) * factor
+    w_bar = round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def patchify(image_chw: np.ndarray, patch: int = 14, merge: int = 2, temporal: int = 2) -> Tuple[np.ndarray, int, int]:
+    """TF:image_processing_pil_qwen2_vl.py:152-187 — ``[C,H,W]`` fp32 → ``[gh*gw, C*T*p*p]``
+    in (gh/m, gw/m, m, m, C, T, p, p) order with the single frame duplicated T times."""
+    c, h, w = image_chw.shape
+    gh, gw = h // patch, w // patch
+    x = image_chw.astype(F32).reshape(c, gh // merge, merge, patch, gw // merge, merge, patch)
+    x = x.transpose(1, 4, 2, 5, 0, 3, 6)  # gh/m, gw/m, m, m, C, p, p
+    x = np.broadcast_to(x[:, :, :, :, :, None, :, :], (*x.shape[:5], temporal, patch, patch))
+    return np.ascontiguousarray(x).reshape(gh * gw, c * temporal * patch * patch), gh, gw
+
+
+def preprocess_image(img_rgb_u8: np.ndarray, min_pixels: int = 56 * 56, max_pixels: int = 28 * 28 * 1280,
+                     patch: int = 14, merge: int = 2, temporal: int = 2) -> Tuple[np.ndarray, Tuple[int, int, int]]:
+    """resize(bicubic, PIL) → ×1/255 → (x-mean)/std → patchify
+    (TF:image_processing_pil_qwen2_vl.py:126-150, :226-229, :152-187).
+    ``img_rgb_u8`` is HWC uint8.  Returns (pixel_values [N,1176] fp32, (1,gh,gw))."""
+    from PIL import Image
+
+    h, w = img_rgb_u8.shape[:2]
+    rh, rw = smart_resize(h, w, patch * merge, min_pixels, max_pixels)
+    pil = Image.fromarray(img_rgb_u8, mode="RGB")
+    if (rh, rw) != (h, w):
+        pil = pil.resize((rw, rh), resample=Image.BICUBIC)
+    x = np.asarray(pil, dtype=np.uint8).astype(F32).transpose(2, 0, 1)  # CHW
+    x = x * F32(1.0 / 255.0)
+    mean = np.asarray(CLIP_MEAN, dtype=F32)[:, None, None]
+    std = np.asarray(CLIP_STD, dtype=F32)[:, None, None]
+    x = (x - mean) / std
+    pv, gh, gw = patchify(x, patch, merge, temporal)
+    return pv, (1, gh, gw)
+
+
+# =============================================================================
+# positions
+# =============================================================================
+
+
+def vision_position_ids(grid_thw: Sequence[Sequence[int]], merge: int = 2) -> np.ndarray:
+    """(h, w) id of every patch in 2×2-block-major order (TF:vision_utils.py:81-127)."""
+    out = []
+    for t, h, w in grid_thw:
+        hp, wp = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        shp = (h // merge, merge, w // merge, merge)
+        hp = hp.reshape(shp).transpose(0, 2, 1, 3).reshape(-1)
+        wp = wp.reshape(shp).transpose(0, 2, 1, 3).reshape(-1)
+        out.append(np.tile(np.stack([hp, wp], axis=-1), (t, 1)))
+    return np.concatenate(out, axis=0).astype(np.int64)
+
+
+def vision_rotary_cos_sin(pos_hw: np.ndarray, head_dim: int, theta: float = 10000.0) -> Tuple[np.ndarray, np.ndarray]:
+    """``VisionRotaryEmbedding(head_dim // 2)`` then ``cat(freqs, freqs)`` →
+    cos/sin ``[N, head_dim]`` (TF:modeling_qwen2_vl.py:239-248, :711-713)."""
+    dim = head_dim // 2
+    inv = (1.0 / (float(theta) ** (np.arange(0, dim, 2, dtype=np.float64) / dim))).astype(F32)
+    fr = (pos_hw[:, :, None].astype(F32) * inv[None, None, :]).reshape(pos_hw.shape[0], -1)  # [N, dim]
+    emb = np.concatenate([fr, fr], axis=-1)
+    return np.cos(emb).astype(F32), np.sin(emb).astype(F32)
+
+
+def get_rope_index(input_ids: np.ndarray, image_grid_thw: Sequence[Sequence[int]], image_token_id: int,
+                   merge: int = 2) -> Tuple[np.ndarray, np.ndarray]:
+    """3-D M-RoPE position ids ``[3,B,P]`` and ``rope_delta [B]`` for unpadded prompts
+    (TF:modeling_qwen2_vl.py:914-1016 with :862-912).  Text runs count up 1-D on all three
+    axes; an image run gets t=start, h=start+row, w=start+col over (gh/m, gw/m) and the
+    next text position is start + max(gh,gw)/m."""
+    input_ids = np.asarray(input_ids)
+    b, p = input_ids.shape
+    pos = np.zeros((3, b, p), dtype=np.int64)
+    deltas = np.zeros((b,), dtype=np.int64)
+    grids = iter(image_grid_thw)
+    for bi in range(b):
+        ids = input_ids[bi]
+        is_img = ids == image_token_id
+        cur = 0
+        i = 0
+        cols: List[np.ndarray] = []
+        while i < p:
+            j = i
+            while j < p and is_img[j] == is_img[i]:
+                j += 1
+            if not is_img[i]:
+                n = j - i
+                cols.append(np.tile(np.arange(n)[None, :] + cur, (3, 1)))
+                cur += n
+            else:
+                t, gh, gw = next(grids)
+                lh, lw = gh // merge, gw // merge
+                if t * lh * lw != j - i:
+                    raise ValueError("image token run does not match grid")
+                tt, hh, ww = np.meshgrid(np.arange(t), np.arange(lh) + cur, np.arange(lw) + cur, indexing="ij")
+                cols.append(np.stack([tt.reshape(-1) + cur, hh.reshape(-1), ww.reshape(-1)], axis=0))
+                cur += max(gh, gw) // merge
+            i = j
+        allp = np.concatenate(cols, axis=1)
+        pos[:, bi] = allp
+        deltas[bi] = allp.max() + 1 - p
+    return pos, deltas
+
+
+def mrope_cos_sin(position_ids: np.ndarray, head_dim: int, theta: float,
+                  mrope_section: Sequence[int]) -> Tuple[np.ndarray, np.ndarray]:
+    """cos/sin ``[B,P,head_dim]`` with the M-RoPE section interleave already applied:
+    ``Qwen2VLRotaryEmbedding`` (TF:modeling_qwen2_vl.py:117-169) followed by the
+    channel selection of ``apply_multimodal_rotary_pos_emb`` (:180-222): channel chunks of
+    sizes ``mrope_section*2`` take their angle from axis ``i % 3`` (t,h,w,t,h,w)."""
+    # inv_freq is evaluated in float64 and rounded once to fp32 (torch's fp32 powf differs
+    # from numpy's by <=1 ulp per element; at position p that is an angle error of p*6e-8,
+    # the same size as the fp32 rounding of the angle itself).
+    inv = (1.0 / (float(theta) ** (np.arange(0, head_dim, 2, dtype=np.float64) / head_dim))).astype(F32)
+    fr = position_ids[..., None].astype(F32) * inv  # [3,B,P,hd/2]
+    emb = np.concatenate([fr, fr], axis=-1)  # [3,B,P,hd]
+    cos3, sin3 = np.cos(emb).astype(F32), np.sin(emb).astype(F32)
+    sec = list(mrope_section) * 2
+    cos_parts, sin_parts, off = [], [], 0
+    for i, s in enumerate(sec):
+        cos_parts.append(cos3[i % 3, ..., off:off + s])
+        sin_parts.append(sin3[i % 3, ..., off:off + s])
+        off += s
+    return np.concatenate(cos_parts, -1), np.concatenate(sin_parts, -1)
+
+
+# =============================================================================
+# vision tower
+# =============================================================================
+
+
+def vit_forward(pixel_values: np.ndarray, grid_thw: Sequence[Sequence[int]], weights: Dict[str, np.ndarray],
+                vcfg, policy: str = "fp32", return_intermediates: bool = False):
+    """``Qwen2VisionTransformerPretrainedModel.forward`` (TF:modeling_qwen2_vl.py:700-731):
+    PatchEmbed (:251-274, Conv3d ≡ GEMM) → ``depth`` × Qwen2VLVisionBlock (:425-449) with
+    full non-causal attention per image (:342-422) → PatchMerger (:277-290).
+    ``vcfg`` is any object with the VisionConfig attributes.  Returns merged ``[T, d]``."""
+    pol = _Policy(policy)
+    pre = "model.visual."
+    D, H = vcfg.embed_dim, vcfg.num_heads
+    hd = D // H
+    inter = {}
+    x = pol(pixel_values)
+    wpe = _w(weights, pre + "patch_embed.proj.weight").reshape(D, -1)
+    x = pol(linear(x, wpe))
+    inter["patch_embed"] = x
+    pos = vision_position_ids(grid_thw, vcfg.spatial_merge_size)
+    cos, sin = vision_rotary_cos_sin(pos, hd)
+    inter["cos"], inter["sin"] = cos, sin
+    seg = np.cumsum([0] + [t * h * w for t, h, w in grid_thw])
+    scale = F32(hd ** -0.5)
+    for li in range(vcfg.depth):
+        p = f"{pre}blocks.{li}."
+        h1 = pol(layer_norm(x, _w(weights, p + "norm1.weight"), _w(weights, p + "norm1.bias")))
+        qkv = pol(linear(h1, _w(weights, p + "attn.qkv.weight"), _w(weights, p + "attn.qkv.bias")))
+        n = qkv.shape[0]
+        qkv = qkv.reshape(n, 3, H, hd)
+        q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]  # [N,H,hd]
+        # apply_rotary_pos_emb_vision: fp32 math, result cast back (:225-236)
+        q = pol(q * cos[:, None, :] + rotate_half(q) * sin[:, None, :])
+        k = pol(k * cos[:, None, :] + rotate_half(k) * sin[:, None, :])
+        o = np.zeros((n, H, hd), dtype=F32)
+        for s in range(len(seg) - 1):
+            a, b = seg[s], seg[s + 1]
+            sc = np.einsum("qhd,khd->hqk", q[a:b], k[a:b]).astype(F32) * scale
+            pr = pol(softmax_lastdim(sc))  # softmax fp32, cast to activation dtype (:334)
+            o[a:b] = np.einsum("hqk,khd->qhd", pr, v[a:b])
+        o = pol(o.reshape(n, D))
+        x = pol(x + linear(o, _w(weights, p + "attn.proj.weight"), _w(weights, p + "attn.proj.bias")))
+        h2 = pol(layer_norm(x, _w(weights, p + "norm2.weight"), _w(weights, p + "norm2.bias")))
+        f1 = pol(quick_gelu(linear(h2, _w(weights, p + "mlp.fc1.weight"), _w(weights, p + "mlp.fc1.bias"))))
+        x = pol(x + linear(f1, _w(weights, p + "mlp.fc2.weight"), _w(weights, p + "mlp.fc2.bias")))
+        inter[f"block{li}"] = x
+    m = pol(layer_norm(x, _w(weights, pre + "merger.ln_q.weight"), _w(weights, pre + "merger.ln_q.bias")))
+    m = m.reshape(-1, vcfg.embed_dim * vcfg.spatial_merge_size ** 2)
+    m = pol(gelu_erf(linear(m, _w(weights, pre + "merger.mlp.0.weight"), _w(weights, pre + "merger.mlp.0.bias"))))
+    m = pol(linear(m, _w(weights, pre + "merger.mlp.2.weight"), _w(weights, pre + "merger.mlp.2.bias")))
+    inter["merged"] = m
+    return (m, inter) if return_intermediates else m
+
+
+# =============================================================================
+# text decoder
+# =============================================================================
+
+
+@dataclass
+class KVCache:
+    """Per-layer lists of ``[B, KVH, S, hd]`` arrays (grown by concatenation)."""
+    k: List[Optional[np.ndarray]]
+    v: List[Optional[np.ndarray]]
+
+    @classmethod
+    def empty(cls, n_layers: int) -> "KVCache":
+        return cls([None] * n_layers, [None] * n_layers)
+
+    def length(self) -> int:
+        return 0 if self.k[0] is None else self.k[0].shape[2]
+
+
+def apply_mrope(x_bhsd: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
+    """``q*cos + rotate_half(q)*sin`` with cos/sin ``[B,S,hd]`` broadcast over heads
+    (TF:modeling_qwen2_vl.py:219-221)."""
+    return (x_bhsd * cos[:, None] + rotate_half(x_bhsd) * sin[:, None]).astype(F32)
+
+
+def decoder_layer(x: np.ndarray, li: int, weights, tcfg, cos, sin, cache: KVCache, pol: _Policy,
+                  attn_valid: Optional[np.ndarray] = None) -> np.ndarray:
+    """``Qwen2VLDecoderLayer`` (TF:modeling_qwen2_vl.py:559-624) with ``Qwen2VLAttention``
+    (:469-556; q/k/v bias, no o bias, GQA by repeat_kv :305-314, scale hd^-0.5, fp32 softmax)
+    and ``Qwen2MLP`` (:453-466).  ``x`` is ``[B,S,d]``; the cache is appended in place.
+    ``attn_valid`` ``[B, S_total]`` masks padded cache slots (ragged batches)."""
+    p = f"model.language_model.layers.{li}."
+    B, S, d = x.shape
+    H, KVH, hd = tcfg.num_heads, tcfg.num_kv_heads, tcfg.head_dim
+    h = rms_norm(x, _w(weights, p + "input_layernorm.weight"), tcfg.rms_norm_eps, pol)
+    h = pol(h)
+    q = pol(linear(h, _w(weights, p + "self_attn.q_proj.weight"), _w(weights, p + "self_attn.q_proj.bias")))
+    k = pol(linear(h, _w(weights, p + "self_attn.k_proj.weight"), _w(weights, p + "self_attn.k_proj.bias")))
+    v = pol(linear(h, _w(weights, p + "self_attn.v_proj.weight"), _w(weights, p + "self_attn.v_proj.bias")))
+    q = q.reshape(B, S, H, hd).transpose(0, 2, 1, 3)
+    k = k.reshape(B, S, KVH, hd).transpose(0, 2, 1, 3)
+    v = v.reshape(B, S, KVH, hd).transpose(0, 2, 1, 3)
+    q = pol(apply_mrope(q, cos, sin))
+    k = pol(apply_mrope(k, cos, sin))
+    past = cache.length() if cache.k[li] is not None else 0
+    if cache.k[li] is None:
+        cache.k[li], cache.v[li] = k, v
+    else:
+        cache.k[li] = np.concatenate([cache.k[li], k], axis=2)
+        cache.v[li] = np.concatenate([cache.v[li], v], axis=2)
+    kk, vv = cache.k[li], cache.v[li]
+    St = kk.shape[2]
+    g = H // KVH
+    kk_r = np.repeat(kk, g, axis=1)
+    vv_r = np.repeat(vv, g, axis=1)
+    sc = np.einsum("bhqd,bhkd->bhqk", q, kk_r).astype(F32) * F32(hd ** -0.5)
+    qi = np.arange(S)[:, None] + past
+    ki = np.arange(St)[None, :]
+    mask = ki <= qi  # causal
+    if attn_valid is not None:
+        mask = mask[None, None] & attn_valid[:, None, None, :]
+    sc = np.where(mask, sc, np.finfo(F32).min)  # HF masks with finfo.min, not -inf
+    pr = pol(softmax_lastdim(sc))
+    o = np.einsum("bhqk,bhkd->bhqd", pr, vv_r).astype(F32)
+    o = pol(o.transpose(0, 2, 1, 3).reshape(B, S, H * hd))
+    x = pol(x + linear(o, _w(weights, p + "self_attn.o_proj.weight")))
+    h2 = pol(rms_norm(x, _w(weights, p + "post_attention_layernorm.weight"), tcfg.rms_norm_eps, pol))
+    gate = linear(h2, _w(weights, p + "mlp.gate_proj.weight"))
+    up = linear(h2, _w(weights, p + "mlp.up_proj.weight"))
+    if pol.name == "bf16":
+        # HF bf16 rounds gate and up separately before silu*mul; the HIP engine fuses
+        # silu(g)*u on fp32 accumulators and rounds once.  The oracle follows the engine.
+        act = pol(silu(gate) * up)
+    else:
+        act = silu(gate) * up
+    x = pol(x + linear(act, _w(weights, p + "mlp.down_proj.weight")))
+    return x
+
+
+def lm_head_weight(weights, tcfg) -> np.ndarray:
+    if tcfg.tie_word_embeddings or "lm_head.weight" not in weights:
+        return _w(weights, "model.language_model.embed_tokens.weight")
+    return _w(weights, "lm_head.weight")
+
+
+def decoder_forward(inputs_embeds: np.ndarray, position_ids: np.ndarray, weights, tcfg, cache: KVCache,
+                    policy: str = "fp32", last_only: bool = True) -> np.ndarray:
+    """``Qwen2VLTextModel.forward`` (TF:modeling_qwen2_vl.py:762-845) + ``lm_head`` (:1320-1323).
+    ``inputs_embeds [B,S,d]``, ``position_ids [3,B,S]``.  Returns fp32 logits
+    (``[B,V]`` for the last position, or ``[B,S,V]``)."""
+    pol = _Policy(policy)
+    cos, sin = mrope_cos_sin(position_ids, tcfg.head_dim, tcfg.rope_theta, tcfg.mrope_section)
+    if policy == "bf16":
+        cos, sin = pol(cos), pol(sin)  # HF casts cos/sin to x.dtype (:169)
+    x = pol(inputs_embeds)
+    for li in range(tcfg.num_layers):
+        x = decoder_layer(x, li, weights, tcfg, cos, sin, cache, pol)
+    x = pol(rms_norm(x, _w(weights, "model.language_model.norm.weight"), tcfg.rms_norm_eps, pol))
+    if last_only:
+        x = x[:, -1]
+    return linear(x, lm_head_weight(weights, tcfg))
+
+
+def embed_and_scatter(input_ids: np.ndarray, image_embeds: Optional[np.ndarray], weights, cfg) -> np.ndarray:
+    """``embed_tokens[input_ids]`` then ``masked_scatter`` of the image embeds at
+    ``input_ids == image_token_id`` in row-major order (TF:modeling_qwen2_vl.py:1159-1168)."""
+    emb = _w(weights, "model.language_model.embed_tokens.weight")[np.asarray(input_ids)]
+    emb = np.array(emb, dtype=F32)
+    if image_embeds is not None:
+        mask = np.asarray(input_ids) == cfg.image_token_id
+        if int(mask.sum()) != image_embeds.shape[0]:
+            raise ValueError("Image features and image tokens do not match")
+        emb[mask] = image_embeds
+    return emb
+
+
+def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[np.ndarray],
+                    image_grid_thw: Optional[Sequence[Sequence[int]]], max_new_tokens: int,
+                    policy: str = "fp32", ignore_eos: bool = False,
+                    return_logits: bool = False):
+    """The call sequence of /root/reference/karanta/training/test_trained_model.py:76-99
+    (``model.generate(**inputs, max_new_tokens=N)`` with ``do_sample=False``), i.e. what a
+    ``temperature=0`` request to the reference's vLLM server computes
+    (/root/reference/karanta/pipeline.py:166-171): ViT → scatter → prefill → greedy decode,
+    stopping at EOS.  Single-sequence or equal-length batch (no padding)."""
+    input_ids = np.asarray(input_ids)
+    B, P = input_ids.shape
+    img = None
+    if pixel_values is not None:
+        img = vit_forward(pixel_values, image_grid_thw, weights, cfg.vision, policy)
+    emb = embed_and_scatter(input_ids, img, weights, cfg)
+    if image_grid_thw is not None:
+        pos, delta = get_rope_index(input_ids, image_grid_thw, cfg.image_token_id, cfg.vision.spatial_merge_size)
+    else:
+        pos = np.tile(np.arange(P)[None, None, :], (3, B, 1))
+        delta = np.zeros((B,), dtype=np.int64)
+    cache = KVCache.empty(cfg.text.num_layers)
+    logits = decoder_forward(emb, pos, weights, cfg.text, cache, policy)
+    all_logits = [logits]
+    out = np.zeros((B, 0), dtype=np.int64)
+    done = np.zeros((B,), dtype=bool)
+    for step in range(max_new_tokens):
+        nxt = logits.argmax(axis=-1)
+        nxt = np.where(done, cfg.pad_token_id, nxt)
+        out = np.concatenate([out, nxt[:, None]], axis=1)
+        if not ignore_eos:
+            done |= np.isin(nxt, cfg.eos_token_ids)
+            if done.all():
+                break
+        if step == max_new_tokens - 1:
+            break
+        e = embed_and_scatter(nxt[:, None], None, weights, cfg)
+        ppos = np.tile((P + step + delta)[None, :, None], (3, 1, 1))
+        logits = decoder_forward(e, ppos, weights, cfg.text, cache, policy)
+        all_logits.append(logits)
+    if return_logits:
+        return out, np.stack(all_logits, axis=1)
+    return out
