@@ -1,0 +1,224 @@
+/*
+ * karanta_hip.h — C-ABI of libkaranta_hip.so, the MI355X (gfx950) kernel library behind the
+ * karanta-ocr VLM inference hot path.
+ *
+ * What it replaces.  The reference has NO in-process kernel interface: the Qwen2-VL
+ * image-encoder + text-decoder forward runs in an external `vllm serve` process
+ * (reference karanta/pipeline.py:707-742 spawn, :317-319 HTTP POST;
+ * bulk_processing/workers/vllm_client.py:209 POST) or inside Hugging Face `model.generate`
+ * (karanta/training/test_trained_model.py:76-99).  The entry points below are therefore the
+ * operator set those third-party forwards execute, one C function per
+ * operator, each citing the Hugging Face symbol whose arithmetic it reproduces
+ * ("TF:" = transformers/models/qwen2_vl/modeling_qwen2_vl.py, line numbers as in SURVEY.md §8 a-ii).
+ * INTEGRATION.md shows the ctypes binding a reference maintainer adds.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Device pointers are raw HIP device addresses
+ *    (e.g. torch.Tensor.data_ptr()); the caller owns every buffer.
+ *  - Every launch takes `kr_stream` (a hipStream_t cast to void*; NULL = default stream) and is
+ *    asynchronous on it.  No function synchronises unless its name says so.
+ *  - Return value: 0 = ok, <0 = error; kr_last_error() gives a thread-local message.
+ *    No exceptions cross the ABI.  No global mutable state besides the error string.
+ *  - "bf16" buffers are raw uint16 bit patterns (round-to-nearest-even); fp32 accumulate inside
+ *    every kernel.  Row-major unless stated.
+ *  - Shapes that a kernel cannot serve are rejected on the host with an error (never launched).
+ */
+#ifndef KARANTA_HIP_H
+#define KARANTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* kr_stream; /* hipStream_t */
+typedef uint16_t kr_bf16;
+
+#define KR_OK 0
+#define KR_ERR_ARG (-1)    /* unsupported shape / null pointer */
+#define KR_ERR_HIP (-2)    /* HIP runtime error */
+#define KR_ERR_RCCL (-3)   /* RCCL error */
+#define KR_ERR_STATE (-4)  /* wrong call order (graph capture etc.) */
+
+/* GEMM / GEMV epilogues (applied to the fp32 accumulator, then one rounding to the output type) */
+#define KR_EPI_NONE 0
+#define KR_EPI_QUICK_GELU 1 /* x*sigmoid(1.702x): ViT fc1, TF:293-301 */
+#define KR_EPI_GELU_ERF 2   /* exact GELU: PatchMerger, TF:277-290 */
+#define KR_EPI_SILU_MUL 3   /* silu(gate)*up with gate/up rows interleaved in 16-row groups: Qwen2MLP, TF:453-466 */
+
+/* ------------------------------------------------------------------ library / device */
+int kr_version(void);
+const char* kr_last_error(void);
+/* fills name (<=63 chars), CU count, total memory bytes of `device`. */
+int kr_device_info(int device, char* name64, int* compute_units, size_t* total_mem);
+int kr_set_device(int device);
+int kr_stream_synchronize(kr_stream s);
+
+/* ------------------------------------------------------------------ profiling events
+ * HIP events on the caller's stream, used by bench.py to time kernels on the stream they are
+ * launched on (torch.cuda.Event only sees torch's current stream). */
+int kr_event_create(void** ev);
+int kr_event_destroy(void* ev);
+int kr_event_record(void* ev, kr_stream s);
+int kr_event_synchronize(void* ev);
+int kr_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* ------------------------------------------------------------------ HIP graphs (decode step replay) */
+int kr_graph_begin_capture(kr_stream s);
+int kr_graph_end_capture(kr_stream s, void** graph_exec);
+int kr_graph_launch(void* graph_exec, kr_stream s);
+int kr_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------------------ elementwise / norms */
+
+/* pixel_values fp32 [rows, k] -> bf16 [rows, k_pad], zero padded (k_pad % 8 == 0).
+ * Front of PatchEmbed (TF:251-274): `hidden_states.to(dtype=target_dtype)`. */
+int kr_cast_pad_f32_bf16(const float* src, kr_bf16* dst, int64_t rows, int k, int k_pad, kr_stream s);
+
+/* nn.LayerNorm with bias, fp32 statistics (ViT blocks TF:425-449, merger ln_q TF:277-290).
+ * x,y bf16 [rows, d]; w,b bf16 [d]; d % 8 == 0, d <= 8192. */
+int kr_layernorm(const kr_bf16* x, const kr_bf16* w, const kr_bf16* b, kr_bf16* y,
+                 int64_t rows, int d, float eps, kr_stream s);
+
+/* Qwen2VLRMSNorm (TF:96-110): y = w * bf16(x * rsqrt(mean(x^2)+eps)).
+ * x has row stride ldx (elements); y is dense [rows, d]. */
+int kr_rmsnorm(const kr_bf16* x, int64_t ldx, const kr_bf16* w, kr_bf16* y,
+               int64_t rows, int d, float eps, kr_stream s);
+
+/* ------------------------------------------------------------------ dense linears */
+
+/* C[M,N] = epi(A[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N]); nn.Linear with the weight in its
+ * native [out,in] layout.  bf16 in, fp32 MFMA accumulate, bf16 out.  K % 64 == 0.
+ * bias / residual may be NULL.  With KR_EPI_SILU_MUL, W holds gate/up rows interleaved in groups
+ * of 16 (g0..g15,u0..u15,g16..), N counts both, C is [M, N/2] and N % 32 == 0.
+ * lda / ldc / ldr are row strides in elements.  Used for every ViT Linear, the merger, and every
+ * decoder Linear at prefill. */
+int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
+                 const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc,
+                 int64_t M, int N, int K, int epilogue, kr_stream s);
+
+/* Decode-time Linear for M <= 16 rows (one row per live sequence): the weight matrix is streamed
+ * exactly once from HBM (this is the HBM-roofline kernel of the decode loop).
+ * Same semantics and epilogues as kr_gemm_bf16.  If out_f32 != NULL the result is written there
+ * as fp32 [M, ldc] instead of bf16 (lm_head logits, TF:1320-1323).
+ * If norm_w != NULL, x is first RMS-normalised (Qwen2VLRMSNorm, eps=norm_eps) on the fly. */
+int kr_gemv_bf16(const kr_bf16* x, int64_t ldx, const kr_bf16* W, const kr_bf16* bias,
+                 const kr_bf16* residual, int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc,
+                 int M, int N, int K, int epilogue,
+                 const kr_bf16* norm_w, float norm_eps, kr_stream s);
+
+/* ------------------------------------------------------------------ ViT attention path */
+
+/* Rotary + re-layout in 64-token blocks, shared by the ViT (apply_rotary_pos_emb_vision,
+ * TF:225-236, rotate_half TF:173-177) and the decoder prefill (apply_multimodal_rotary_pos_emb,
+ * TF:180-222, with section-interleaved cos/sin precomputed on the host).
+ * `qkv` is the fused projection output, row stride ld_qkv, with q / k / v starting at column
+ * q_off / k_off / v_off (elements), heads contiguous.  cos,sin fp32 [n, hd] by token row.
+ * Block i covers tokens blk_tok0[i] .. +blk_ntok[i] (<= 64) of one segment, starting at a
+ * multiple of 64 inside that segment:
+ *   q_out  [q_heads][token row][hd]                    (head stride q_head_stride elements)
+ *   k_out  [kv_heads][rows][hd]: token j -> row blk_k_row0[i] + j   (head stride k_head_stride)
+ *   vt_out [kv_heads][blocks][hd][64]: V transposed, block blk_vt_blk[i], zero padded
+ * For the decoder, k_out / vt_out are the KV cache of one layer. hd in {80, 128}. */
+int kr_qkv_prep(const kr_bf16* qkv, int64_t ld_qkv, int q_off, int k_off, int v_off,
+                const float* cos, const float* sin,
+                const int32_t* blk_tok0, const int32_t* blk_ntok,
+                const int64_t* blk_k_row0, const int64_t* blk_vt_blk, int n_blk,
+                kr_bf16* q_out, int64_t q_head_stride, kr_bf16* k_out, int64_t k_head_stride,
+                kr_bf16* vt_out, int64_t vt_head_stride, int q_heads, int kv_heads, int hd,
+                kr_stream s);
+
+/* Plain in-place rotary on a [n, heads, hd] tensor (kept for API parity with SURVEY §8 b2
+ * `kr_rope2d_vision`; the engine uses the fused kr_vit_qkv_prep). */
+int kr_rope2d_vision(kr_bf16* x, const float* cos, const float* sin, int64_t n, int heads, int hd,
+                     int64_t row_stride, kr_stream s);
+
+/* Flash-style attention over variable-length segments, fp32 online softmax, bf16 P (as
+ * eager_attention_forward TF:317-339 computes it: softmax in fp32, cast, P*V).
+ *   q : [q_heads, nq_total, hd]   k : [kv_heads, *, hd] rows   vt : [kv_heads, *, hd, 64] blocks
+ *   out : [nq_total, q_heads*hd]
+ * Work list: qblk[4*i+0..3] = {q_row0 (global row of first query), n_q_rows (<=128),
+ *   k_row0 (global k row of the segment's key 0), vt_block0}; qblk_len[2*i+0..1] =
+ *   {kv_len visible to the LAST query of the block when causal / segment length otherwise,
+ *    position of the block's first query inside its segment}.
+ * kv head = q head / (q_heads / kv_heads).  k_head_stride / vt_head_stride in elements.
+ * hd in {80, 128}.  causal=0: ViT full attention per image (VisionAttention TF:342-422, segments
+ * from cu_seqlens TF:399-418); causal=1: decoder prefill (Qwen2VLAttention TF:469-556). */
+int kr_attn_varlen(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out,
+                   const int32_t* qblk, const int32_t* qblk_len, int n_qblk,
+                   int64_t nq_total, int q_heads, int kv_heads, int hd,
+                   int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal,
+                   kr_stream s);
+
+/* ------------------------------------------------------------------ decoder: embedding, M-RoPE, KV cache */
+
+/* inputs_embeds (TF:1159-1168): row i of out = table[src[i]] if src[i] >= 0, else
+ * image_embeds[-src[i]-1] (masked_scatter order precomputed on the host). bf16, d % 8 == 0. */
+int kr_embed_scatter(const int32_t* src, const kr_bf16* table, const kr_bf16* image_embeds,
+                     kr_bf16* out, int64_t rows, int d, kr_stream s);
+
+/* KV cache of one model:
+ *   kcache  : [layers, batch, kv_heads, s_max, hd]
+ *   vtcache : [layers, batch, kv_heads, s_max/64, hd, 64]   (V transposed in 64-token blocks)
+ * zero-initialised by the caller (masked keys are multiplied by P = 0, so they must be finite). */
+
+/* SURVEY §8 b2 names kept as thin standalone operators (tests call them directly). */
+int kr_mrope(kr_bf16* x, const float* cos, const float* sin, int64_t n, int heads, int hd,
+             int64_t row_stride, kr_stream s);
+int kr_kv_append(const kr_bf16* k, const kr_bf16* v, int64_t row_stride,
+                 const int32_t* tok_seq, const int32_t* tok_pos,
+                 kr_bf16* kcache, kr_bf16* vtcache,
+                 int64_t n, int kv_heads, int hd, int layer, int batch, int s_max, kr_stream s);
+
+/* Decode step front: for each live sequence b (one new token): M-RoPE at position
+ * ctx_len[b] + rope_delta[b] (all three axes equal for text tokens, TF:1124-1136), computed from
+ * inv_freq fp32 [hd/2]; writes q_out [batch, heads, hd] and appends K / V^T at cache position
+ * ctx_len[b].  ctx_len is NOT modified (kr_argmax_embed advances it once per step). */
+int kr_decode_qkv_prep(const kr_bf16* qkv, const float* inv_freq, const int32_t* ctx_len,
+                       const int32_t* rope_delta, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache,
+                       int batch, int heads, int kv_heads, int hd, int layer, int s_max, kr_stream s);
+
+/* Decode attention, q_len = 1, GQA, context = ctx_len[b] + 1 tokens (the new token included),
+ * split over `n_split` key ranges; partials go to `workspace` (fp32,
+ * batch*heads*n_split*(hd+2) floats) and are merged by the same call's second kernel.
+ * out : [batch, heads*hd] bf16.  (Qwen2VLAttention with cache, TF:469-556.) */
+int kr_attn_decode_gqa(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache,
+                       const int32_t* ctx_len, kr_bf16* out, float* workspace,
+                       int batch, int heads, int kv_heads, int hd, int layer, int s_max,
+                       int n_split, float scale, kr_stream s);
+
+/* Greedy sampling (`generate(do_sample=False)`, reference test_trained_model.py:91): argmax of
+ * fp32 logits [batch, vocab] (lowest index wins ties), token written to tokens_out[b] and to
+ * history[step_ptr[0]*batch + b]; the token's embedding row is gathered into x_next [batch, d];
+ * ctx_len[b] += 1; step_ptr[0] += 1 (by a trailing 1-thread kernel).  Sequences with finished[b] != 0 emit pad_id; a
+ * sequence becomes finished when it emits one of eos[0..n_eos).  */
+int kr_argmax_embed(const float* logits, int64_t ld_logits, int vocab,
+                    const kr_bf16* embed_table, int d,
+                    int32_t* tokens_out, int32_t* history, int32_t* step_ptr, int32_t* ctx_len,
+                    int32_t* finished, const int32_t* eos, int n_eos, int pad_id, int ignore_eos,
+                    kr_bf16* x_next, int batch, kr_stream s);
+
+/* Plain argmax (SURVEY §8 b2 `kr_argmax`). */
+int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, int batch, kr_stream s);
+
+/* ------------------------------------------------------------------ multi-GPU: one-time weight broadcast (RCCL)
+ * One process per GPU.  Rank 0 calls kr_comm_unique_id and shares the 128 bytes through any host
+ * channel (the Python host uses torch.distributed's store); every rank then calls kr_comm_init.
+ * kr_bcast_weights is ncclBroadcast of the packed weight arena from `root`; it is
+ * the only collective on the path — steady state has none. */
+#define KR_UNIQUE_ID_BYTES 128
+int kr_comm_unique_id(uint8_t* id128);
+int kr_comm_init(void** comm, int n_ranks, int rank, const uint8_t* id128);
+int kr_comm_destroy(void* comm);
+int kr_bcast_weights(void* comm, void* buf, size_t bytes, int root, kr_stream s);
+
+/* ------------------------------------------------------------------ device self-tests (used by tests/ -m gpu) */
+/* Runs an MFMA lane-layout check (A=I, asymmetric B) on the device; returns 0 if exact. */
+int kr_selftest_mfma(kr_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KARANTA_HIP_H */

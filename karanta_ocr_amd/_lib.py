@@ -1,0 +1,118 @@
+"""ctypes binding of libkaranta_hip.so (include/karanta_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or fails to load,
+:func:`lib` raises :class:`KarantaHipError`.  `import torch` happens first on purpose — torch
+ships its own libamdhip64.so.7 / librccl.so.1 and the extension must bind to the same runtime
+instance so that torch's streams and device pointers are valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkaranta_hip.so")
+
+c_p = C.c_void_p
+i32, i64, f32 = C.c_int, C.c_int64, C.c_float
+
+
+class KarantaHipError(RuntimeError):
+    pass
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "kr_version": [],
+    "kr_last_error": [],
+    "kr_device_info": [i32, C.c_char_p, C.POINTER(i32), C.POINTER(C.c_size_t)],
+    "kr_set_device": [i32],
+    "kr_stream_synchronize": [c_p],
+    "kr_event_create": [C.POINTER(c_p)],
+    "kr_event_destroy": [c_p],
+    "kr_event_record": [c_p, c_p],
+    "kr_event_synchronize": [c_p],
+    "kr_event_elapsed_ms": [c_p, c_p, C.POINTER(f32)],
+    "kr_graph_begin_capture": [c_p],
+    "kr_graph_end_capture": [c_p, C.POINTER(c_p)],
+    "kr_graph_launch": [c_p, c_p],
+    "kr_graph_destroy": [c_p],
+    "kr_cast_pad_f32_bf16": [c_p, c_p, i64, i32, i32, c_p],
+    "kr_layernorm": [c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
+    "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
+    "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
+    "kr_gemv_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, c_p, f32, c_p],
+    "kr_qkv_prep": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p, i64, c_p, i64, c_p, i64,
+                    i32, i32, i32, c_p],
+    "kr_rope2d_vision": [c_p, c_p, c_p, i64, i32, i32, i64, c_p],
+    "kr_attn_varlen": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i64, i32, i32, i32, i64, i64, f32, i32, c_p],
+    "kr_embed_scatter": [c_p, c_p, c_p, c_p, i64, i32, c_p],
+    "kr_mrope": [c_p, c_p, c_p, i64, i32, i32, i64, c_p],
+    "kr_kv_append": [c_p, c_p, i64, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p],
+    "kr_decode_qkv_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p],
+    "kr_attn_decode_gqa": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
+    "kr_argmax_embed": [c_p, i64, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
+    "kr_argmax": [c_p, i64, i32, c_p, i32, c_p],
+    "kr_comm_unique_id": [c_p],
+    "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],
+    "kr_comm_destroy": [c_p],
+    "kr_bcast_weights": [c_p, c_p, C.c_size_t, i32, c_p],
+    "kr_selftest_mfma": [c_p],
+}
+_RESTYPES = {"kr_last_error": C.c_char_p}
+
+EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SILU_MUL = 0, 1, 2, 3
+
+
+class _Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise KarantaHipError(
+                f"{path} not found: build it with `python -m karanta_ocr_amd.build` "
+                "(the MI355X engine has no CPU fallback)")
+        import torch  # noqa: F401  (loads torch's libamdhip64 / librccl first; see module docstring)
+
+        try:
+            self._dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # pragma: no cover
+            raise KarantaHipError(f"cannot load {path}: {e}") from e
+        self.path = path
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise KarantaHipError(f"{path} does not export {name}") from e
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+            if name in ("kr_version", "kr_last_error"):
+                setattr(self, name, fn)
+            else:
+                setattr(self, name, self._checked(name, fn))
+
+    def _checked(self, name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                msg = self._dll.kr_last_error()
+                raise KarantaHipError(f"{name} -> {rc}: {msg.decode() if msg else ''}")
+            return rc
+
+        call.__name__ = name
+        call.raw = fn
+        return call
+
+
+_LIB: Optional[_Lib] = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib(os.environ.get("KARANTA_HIP_LIB", LIB_PATH))
+    return _LIB
+
+
+def ptr(t) -> int:
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,96 @@
+// Library plumbing: error string, device info, events, graph capture.
+#include <stdarg.h>
+#include <string.h>
+
+#include "kr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void kr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int kr_version(void) { return 100; }
+
+const char* kr_last_error(void) { return g_err; }
+
+int kr_device_info(int device, char* name64, int* compute_units, size_t* total_mem) {
+    hipDeviceProp_t p;
+    KR_CHECK_HIP(hipGetDeviceProperties(&p, device));
+    if (name64) {
+        strncpy(name64, p.gcnArchName, 63);
+        name64[63] = 0;
+    }
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (total_mem) *total_mem = p.totalGlobalMem;
+    return KR_OK;
+}
+
+int kr_set_device(int device) {
+    KR_CHECK_HIP(hipSetDevice(device));
+    return KR_OK;
+}
+
+int kr_stream_synchronize(kr_stream s) {
+    KR_CHECK_HIP(hipStreamSynchronize(kr_hs(s)));
+    return KR_OK;
+}
+
+int kr_event_create(void** ev) {
+    KR_CHECK_ARG(ev, "kr_event_create: null");
+    hipEvent_t e;
+    KR_CHECK_HIP(hipEventCreate(&e));
+    *ev = e;
+    return KR_OK;
+}
+int kr_event_destroy(void* ev) {
+    KR_CHECK_HIP(hipEventDestroy((hipEvent_t)ev));
+    return KR_OK;
+}
+int kr_event_record(void* ev, kr_stream s) {
+    KR_CHECK_HIP(hipEventRecord((hipEvent_t)ev, kr_hs(s)));
+    return KR_OK;
+}
+int kr_event_synchronize(void* ev) {
+    KR_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return KR_OK;
+}
+int kr_event_elapsed_ms(void* start, void* stop, float* ms) {
+    KR_CHECK_ARG(ms, "kr_event_elapsed_ms: null");
+    KR_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return KR_OK;
+}
+
+int kr_graph_begin_capture(kr_stream s) {
+    KR_CHECK_HIP(hipStreamBeginCapture(kr_hs(s), hipStreamCaptureModeThreadLocal));
+    return KR_OK;
+}
+int kr_graph_end_capture(kr_stream s, void** graph_exec) {
+    KR_CHECK_ARG(graph_exec, "kr_graph_end_capture: null");
+    hipGraph_t g = nullptr;
+    KR_CHECK_HIP(hipStreamEndCapture(kr_hs(s), &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        kr_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return KR_ERR_HIP;
+    }
+    *graph_exec = ge;
+    return KR_OK;
+}
+int kr_graph_launch(void* graph_exec, kr_stream s) {
+    KR_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, kr_hs(s)));
+    return KR_OK;
+}
+int kr_graph_destroy(void* graph_exec) {
+    KR_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return KR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,633 @@
+// Attention path: rotary + layout prep, flash-style varlen attention (ViT full / decoder causal
+// prefill), decode attention (q_len = 1, GQA, split-KV) — all on v_mfma bf16 with fp32 softmax.
+//
+// Data layout in HBM (chosen for the matrix cores, not inherited from any framework):
+//   Q   : [heads, n, hd]                     rotated, bf16
+//   K   : [kv_heads, rows, hd]               rotated, bf16 (decoder: the KV cache itself)
+//   V^T : [kv_heads, blocks, hd, 64]         V transposed inside 64-token blocks, so that the
+//                                            P*V MFMA operand (8 consecutive keys for one d)
+//                                            is one contiguous 16-byte read per lane.
+#include "kr_common.h"
+
+namespace {
+
+// =====================================================================================
+// rotary helpers
+// =====================================================================================
+
+// x*cos + rotate_half(x)*sin on one head vector, 8 elements [c0, c0+8) per call.
+// `other` holds x[(c + hd/2) mod hd]; sign = -1 for the first half, +1 for the second.
+__device__ __forceinline__ bf16x8 rope8(bf16x8 x, bf16x8 other, const float* cs, const float* sn, float sign) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(x[j]) * cs[j] + sign * bf2f(other[j]) * sn[j]);
+    return o;
+}
+
+// In-place rotary on [n, heads, hd] (row stride given): standalone operator.
+__global__ void __launch_bounds__(256) rope_inplace_kernel(kr_bf16* __restrict__ x, const float* __restrict__ cos,
+                                                           const float* __restrict__ sin, int64_t n, int heads, int hd,
+                                                           int64_t row_stride) {
+    const int half_chunks = hd >> 4;  // chunks of 8 in half a head
+    const int64_t total = n * heads * half_chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % half_chunks);
+        const int64_t t = i / half_chunks;
+        const int h = (int)(t % heads);
+        const int64_t tok = t / heads;
+        kr_bf16* p = x + tok * row_stride + (int64_t)h * hd;
+        const int d0 = c * 8, d1 = d0 + (hd >> 1);
+        const bf16x8 a = ld8(p + d0), b = ld8(p + d1);
+        float c0[8], s0[8], c1[8], s1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c0[j] = cos[tok * hd + d0 + j];
+            s0[j] = sin[tok * hd + d0 + j];
+            c1[j] = cos[tok * hd + d1 + j];
+            s1[j] = sin[tok * hd + d1 + j];
+        }
+        st8(p + d0, rope8(a, b, c0, s0, -1.f));
+        st8(p + d1, rope8(b, a, c1, s1, 1.f));
+    }
+}
+
+// =====================================================================================
+// prep: rotary + re-layout (+ V transpose through LDS) for 64-token blocks
+// =====================================================================================
+// grid = (n_blocks, q_heads + kv_heads).  Block i covers tokens blk_tok0[i] .. +blk_ntok[i] (<= 64)
+// of the flattened activation `qkv` (row stride ld_qkv); they belong to one segment/sequence and
+// start at a multiple of 64 inside it, so the block owns one whole V^T block.
+//   y <  q_heads : rotate q head y            -> q_out[y][tok][hd]
+//   y >= q_heads : rotate k head, copy V^T    -> k rows (k_row0[i] + j), V^T block vt_blk[i]
+// Column offsets of q / k / v inside a qkv row are given in elements.
+template <int HD>
+__global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict__ qkv, int64_t ld_qkv, int q_off,
+                                                       int k_off, int v_off, const float* __restrict__ cos,
+                                                       const float* __restrict__ sin,
+                                                       const int32_t* __restrict__ blk_tok0,
+                                                       const int32_t* __restrict__ blk_ntok,
+                                                       const int64_t* __restrict__ blk_k_row0,
+                                                       const int64_t* __restrict__ blk_vt_blk, kr_bf16* __restrict__ q_out,
+                                                       int64_t q_head_stride, kr_bf16* __restrict__ k_out,
+                                                       int64_t k_head_stride, kr_bf16* __restrict__ vt_out,
+                                                       int64_t vt_head_stride, int q_heads) {
+    constexpr int HC = HD / 16;  // 8-element chunks in half a head
+    __shared__ __attribute__((aligned(16))) kr_bf16 vt_s[HD][64 + 8];
+    const int i = blockIdx.x;
+    const int y = blockIdx.y;
+    const int tok0 = blk_tok0[i], ntok = blk_ntok[i];
+    const bool is_q = y < q_heads;
+    const int head = is_q ? y : y - q_heads;
+    const int col = (is_q ? q_off : k_off) + head * HD;
+    kr_bf16* dst = is_q ? q_out + (int64_t)head * q_head_stride + (int64_t)tok0 * HD
+                        : k_out + (int64_t)head * k_head_stride + blk_k_row0[i] * HD;
+    // ---- rotary on 64 tokens x HD
+    for (int e = threadIdx.x; e < 64 * HC; e += 256) {
+        const int j = e / HC, c = e - j * HC;
+        if (j >= ntok) continue;
+        const int64_t tok = tok0 + j;
+        const kr_bf16* p = qkv + tok * ld_qkv + col;
+        const int d0 = c * 8, d1 = d0 + HD / 2;
+        const bf16x8 a = ld8(p + d0), b = ld8(p + d1);
+        float c0[8], s0[8], c1[8], s1[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            c0[jj] = cos[tok * HD + d0 + jj];
+            s0[jj] = sin[tok * HD + d0 + jj];
+            c1[jj] = cos[tok * HD + d1 + jj];
+            s1[jj] = sin[tok * HD + d1 + jj];
+        }
+        st8(dst + (int64_t)j * HD + d0, rope8(a, b, c0, s0, -1.f));
+        st8(dst + (int64_t)j * HD + d1, rope8(b, a, c1, s1, 1.f));
+    }
+    if (is_q) return;
+    // ---- V: [64 tok][HD] -> LDS transposed -> V^T block [HD][64], zero padded past ntok
+    for (int e = threadIdx.x; e < 64 * (HD / 8); e += 256) {
+        const int j = e / (HD / 8), c = e - j * (HD / 8);
+        bf16x8 v;
+        if (j < ntok) {
+            v = ld8(qkv + (int64_t)(tok0 + j) * ld_qkv + v_off + head * HD + c * 8);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) v[jj] = f2bf(0.f);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) vt_s[c * 8 + jj][j] = __builtin_bit_cast(kr_bf16, v[jj]);
+    }
+    __syncthreads();
+    kr_bf16* vt = vt_out + (int64_t)head * vt_head_stride + blk_vt_blk[i] * (int64_t)(HD * 64);
+    for (int e = threadIdx.x; e < HD * 8; e += 256) {
+        const int d = e >> 3, c = e & 7;
+        *reinterpret_cast<u32x4*>(vt + d * 64 + c * 8) = *reinterpret_cast<const u32x4*>(&vt_s[d][c * 8]);
+    }
+}
+
+// =====================================================================================
+// flash-style varlen attention, v_mfma_f32_32x32x16_bf16
+// =====================================================================================
+// Block = 4 waves = 128 queries of one head; each wave owns 32 queries.  Per 64-key tile:
+//   S^T[key][q]  = K (A operand, LDS) x Q^T (B operand, registers)        2 x HD/16 MFMA
+//   online softmax in registers: the query is on the lane, its 32 keys in 2x16 accumulator
+//   registers; one cross-lane max with lane^32
+//   O^T[d][q]   += V^T (A operand, LDS) x P^T (B operand = the S^T accumulators, converted in
+//   place to bf16: no LDS round trip, the MFMA k-order permutation is absorbed by reading V^T
+//   keys in the same order)                                               HD/32 x 4 MFMA
+template <int HD>
+struct AttnCfg {
+    static constexpr int KS = HD / 16;               // QK^T k-steps
+    static constexpr int DT = (HD + 31) / 32;        // 32-row tiles of O^T
+    static constexpr int KCH = HD / 8;               // 16-byte chunks per K row
+    static constexpr int KROW = (HD == 128) ? 256 : (KCH + 1) * 16;  // LDS K row bytes (hd=80: 176, conflict-free)
+    static constexpr int VROW = 136;                 // LDS V^T row bytes (64 keys + 8 B pad: conflict-free b64 reads)
+    static constexpr int K_PASSES = (64 * KCH + 255) / 256;
+    static constexpr int V_PASSES = (HD * 8 + 255) / 256;
+};
+
+template <int HD>
+__device__ __forceinline__ int k_lds_off(int key, int c) {
+    if (HD == 128) return key * 256 + ((c ^ (key & 15)) << 4);
+    return key * AttnCfg<HD>::KROW + (c << 4);
+}
+
+template <int HD, bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_varlen_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k,
+                                                          const kr_bf16* __restrict__ vt, kr_bf16* __restrict__ out,
+                                                          const int32_t* __restrict__ qblk,
+                                                          const int32_t* __restrict__ qblk_len, int64_t nq_total,
+                                                          int q_heads, int group, int64_t k_head_stride,
+                                                          int64_t vt_head_stride, float scale_log2e) {
+    using C = AttnCfg<HD>;
+    __shared__ __attribute__((aligned(16))) char k_s[64 * C::KROW];
+    __shared__ __attribute__((aligned(16))) char v_s[C::DT * 32 * C::VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int bi = blockIdx.x, head = blockIdx.y, kvh = head / group;
+    const int64_t q_row0 = qblk[4 * bi + 0];
+    const int n_q = qblk[4 * bi + 1];
+    const int64_t k_row0 = (int64_t)qblk[4 * bi + 2];
+    const int64_t vt_blk0 = (int64_t)qblk[4 * bi + 3];
+    const int kv_len_seg = qblk_len[2 * bi + 0];
+    const int q_pos0 = qblk_len[2 * bi + 1];
+    int kv_len = kv_len_seg;
+    if (CAUSAL) kv_len = min(kv_len, q_pos0 + n_q);
+    const int n_tiles = (kv_len + 63) >> 6;
+
+    // zero the padded V^T rows once (hd=80: rows 80..95 are never staged)
+    if (C::DT * 32 > HD) {
+        for (int e = tid; e < (C::DT * 32 - HD) * C::VROW / 8; e += 256)
+            reinterpret_cast<u32x2*>(v_s + HD * C::VROW)[e] = (u32x2){0u, 0u};
+    }
+
+    // ---- Q fragments (B operand): lane = query, 8 d per k-step half
+    int ql = wave * 32 + lq;
+    const bool q_valid = ql < n_q;
+    if (!q_valid) ql = n_q - 1;
+    const kr_bf16* qp = q + ((int64_t)head * nq_total + q_row0 + ql) * HD + lh * 8;
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) qf[s] = ld8(qp + s * 16);
+    const int qpos = q_pos0 + wave * 32 + lq;
+
+    const kr_bf16* kbase = k + (int64_t)kvh * k_head_stride + k_row0 * HD;
+    const kr_bf16* vbase = vt + (int64_t)kvh * vt_head_stride + vt_blk0 * (int64_t)(HD * 64);
+
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    bf16x8 kreg[C::K_PASSES], vreg[C::V_PASSES];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < C::K_PASSES; ++p) {
+            const int idx = p * 256 + tid;
+            if (idx < 64 * C::KCH) {
+                const int key = idx / C::KCH, c = idx - key * C::KCH;
+                int kg = t * 64 + key;
+                kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
+                kreg[p] = ld8(kbase + (int64_t)kg * HD + c * 8);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < C::V_PASSES; ++p) {
+            const int idx = p * 256 + tid;
+            if (idx < HD * 8) vreg[p] = ld8(vbase + (int64_t)t * (HD * 64) + idx * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < C::K_PASSES; ++p) {
+            const int idx = p * 256 + tid;
+            if (idx < 64 * C::KCH) {
+                const int key = idx / C::KCH, c = idx - key * C::KCH;
+                *reinterpret_cast<bf16x8*>(k_s + k_lds_off<HD>(key, c)) = kreg[p];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < C::V_PASSES; ++p) {
+            const int idx = p * 256 + tid;
+            if (idx < HD * 8) {
+                const int d = idx >> 3, c = idx & 7;
+                const u32x4 w = __builtin_bit_cast(u32x4, vreg[p]);
+                u32x2* dstp = reinterpret_cast<u32x2*>(v_s + d * C::VROW + c * 16);
+                dstp[0] = (u32x2){w[0], w[1]};
+                dstp[1] = (u32x2){w[2], w[3]};
+            }
+        }
+    };
+
+    if (n_tiles > 0) load_tile(0);
+    for (int t = 0; t < n_tiles; ++t) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (t + 1 < n_tiles) load_tile(t + 1);
+
+        // ---- S^T = K Q^T
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_s + k_lds_off<HD>(sub * 32 + lq, 2 * ks + lh));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+            }
+        }
+        // ---- mask, online softmax (lane = query; rows = keys)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = key < kv_len_seg && (!CAUSAL || key <= qpos);
+                const float v = ok ? s[sub][r] * scale_log2e : -INFINITY;
+                s[sub][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
+                const __bf16 pb = f2bf(p);
+                psum += bf2f(pb);  // normaliser of the bf16 P actually multiplied into V
+                pf[sub][r >> 3][r & 7] = pb;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int kb = sub * 32 + ss * 16 + 4 * lh;  // keys kb..kb+3 and kb+8..kb+11
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][ss], o[dt], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- normalise and store: lane = query, 4 consecutive d per register quad
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (!q_valid) return;
+    kr_bf16* op = out + (q_row0 + ql) * ((int64_t)q_heads * HD) + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = dt * 32 + 8 * i + 4 * lh;
+            if (d < HD) {
+                bf16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = f2bf(o[dt][4 * i + j] * inv);
+                *reinterpret_cast<bf16x4*>(op + d) = ov;
+            }
+        }
+}
+
+// =====================================================================================
+// decode: rotary + KV append for one new token per sequence
+// =====================================================================================
+__global__ void __launch_bounds__(256) decode_qkv_prep_kernel(const kr_bf16* __restrict__ qkv,
+                                                              const float* __restrict__ inv_freq,
+                                                              const int32_t* __restrict__ ctx_len,
+                                                              const int32_t* __restrict__ rope_delta,
+                                                              kr_bf16* __restrict__ q_out, kr_bf16* __restrict__ kcache,
+                                                              kr_bf16* __restrict__ vtcache, int heads, int kv_heads,
+                                                              int hd, int layer, int batch, int s_max) {
+    const int b = blockIdx.x;
+    const int pos = ctx_len[b];
+    const float rp = (float)(pos + rope_delta[b]);
+    const int half = hd >> 1;
+    const int qkv_dim = (heads + 2 * kv_heads) * hd;
+    const kr_bf16* row = qkv + (int64_t)b * qkv_dim;
+    const int64_t kv_base = ((int64_t)layer * batch + b) * kv_heads;
+    // rotary on q heads and k heads: one thread per (head, i < hd/2)
+    for (int e = threadIdx.x; e < (heads + kv_heads) * half; e += blockDim.x) {
+        const int h = e / half, i = e - h * half;
+        const float ang = rp * inv_freq[i];
+        // HF casts cos/sin to the activation dtype (TF:modeling_qwen2_vl.py:169)
+        const float c = bfround(cosf(ang)), s = bfround(sinf(ang));
+        const float x0 = bfbits2f(row[h * hd + i]), x1 = bfbits2f(row[h * hd + i + half]);
+        const __bf16 y0 = f2bf(x0 * c - x1 * s), y1 = f2bf(x1 * c + x0 * s);
+        kr_bf16* dst;
+        if (h < heads) {
+            dst = q_out + ((int64_t)b * heads + h) * hd;
+        } else {
+            dst = kcache + ((kv_base + (h - heads)) * s_max + pos) * hd;
+        }
+        dst[i] = __builtin_bit_cast(kr_bf16, y0);
+        dst[i + half] = __builtin_bit_cast(kr_bf16, y1);
+    }
+    // V -> transposed cache column
+    const kr_bf16* vrow = row + (heads + kv_heads) * hd;
+    for (int e = threadIdx.x; e < kv_heads * hd; e += blockDim.x) {
+        const int h = e / hd, d = e - h * hd;
+        vtcache[(((kv_base + h) * (s_max >> 6) + (pos >> 6)) * hd + d) * 64 + (pos & 63)] = vrow[e];
+    }
+}
+
+// =====================================================================================
+// decode attention, v_mfma_f32_16x16x32_bf16, K and V^T straight from HBM to registers
+// =====================================================================================
+// grid = (n_split, kv_heads, batch), 4 waves per block; wave `part` = split*4 + wave walks the
+// 64-key blocks part, part + n_part, ...  Heads of the GQA group sit on the 16 MFMA columns.
+//   S[key][g]   : A = K rows (keys permuted so that lane group fg ends up with keys 8fg..8fg+7)
+//                 B = Q^T
+//   O^T[d][g]  += A = V^T (16 B = 8 consecutive keys per lane), B = P^T (the S accumulators)
+// Partials (m, l, O) go to the fp32 workspace; attn_decode_combine_kernel merges them.
+template <int HD>
+__global__ void __launch_bounds__(256) attn_decode_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
+                                                          const kr_bf16* __restrict__ vtcache,
+                                                          const int32_t* __restrict__ ctx_len, float* __restrict__ ws,
+                                                          int heads, int kv_heads, int layer, int batch, int s_max,
+                                                          float scale_log2e) {
+    constexpr int DT = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int group = heads / kv_heads;
+    const int n_part = gridDim.x * 4;
+    const int part = blockIdx.x * 4 + wave;
+    const int ctx = ctx_len[b] + 1;
+    const int nb = (ctx + 63) >> 6;
+
+    const int g = fr < group ? fr : 0;
+    const kr_bf16* qp = q + ((int64_t)b * heads + kvh * group + g) * HD + fg * 32;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qf[i] = ld8(qp + i * 8);
+
+    const int64_t kv_base = ((int64_t)layer * batch + b) * kv_heads + kvh;
+    const kr_bf16* kc = kcache + kv_base * s_max * HD;
+    const kr_bf16* vc = vtcache + kv_base * (int64_t)(s_max >> 6) * (HD * 64);
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+
+    for (int blk = part; blk < nb; blk += n_part) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int key0 = blk * 64 + hf * 32;
+            if (key0 >= ctx) break;  // wave-uniform
+            // K fragments: tile kt, row r holds key 8(r>>2) + 4kt + (r&3)
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kf[kt][i] = ld8_nt(kp + i * 8);
+            }
+            // V^T fragments: row d = dt*16 + fr, keys key0 + 8fg .. +7
+            bf16x8 vf[DT];
+            const kr_bf16* vp = vc + (int64_t)blk * (HD * 64) + hf * 32 + fg * 8;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = ld8_nt(vp + (dt * 16 + fr) * 64);
+
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][i], qf[i], s[kt], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + 8 * fg + 4 * kt + r;
+                    const float v = key < ctx ? s[kt][r] * scale_log2e : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            bf16x8 pf;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const __bf16 pb = f2bf(__builtin_amdgcn_exp2f(s[kt][r] - m_new));
+                    psum += bf2f(pb);
+                    pf[kt * 4 + r] = pb;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    // l: sum the four key groups of each head column
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (fr < group) {
+        float* w = ws + (((int64_t)b * heads + kvh * group + fr) * n_part + part) * (HD + 2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(w + dt * 16 + fg * 4) = o[dt];
+        if (fg == 0) {
+            w[HD] = m_run;
+            w[HD + 1] = l_run;
+        }
+    }
+}
+
+// grid = batch*heads blocks of HD threads
+__global__ void attn_decode_combine_kernel(const float* __restrict__ ws, kr_bf16* __restrict__ out, int n_part, int hd) {
+    const int bh = blockIdx.x, d = threadIdx.x;
+    const float* w = ws + (int64_t)bh * n_part * (hd + 2);
+    float mx = -1e30f;
+    for (int p = 0; p < n_part; ++p) mx = fmaxf(mx, w[p * (hd + 2) + hd]);
+    float acc = 0.f, l = 0.f;
+    for (int p = 0; p < n_part; ++p) {
+        const float sc = __builtin_amdgcn_exp2f(w[p * (hd + 2) + hd] - mx);
+        l += w[p * (hd + 2) + hd + 1] * sc;
+        acc += w[p * (hd + 2) + d] * sc;
+    }
+    out[(int64_t)bh * hd + d] = __builtin_bit_cast(kr_bf16, f2bf(l > 0.f ? acc / l : 0.f));
+}
+
+// scattered K / V^T append (standalone operator; the engine uses the blocked prep kernels)
+__global__ void __launch_bounds__(256) kv_append_kernel(const kr_bf16* __restrict__ k, const kr_bf16* __restrict__ v,
+                                                        int64_t row_stride, const int32_t* __restrict__ tok_seq,
+                                                        const int32_t* __restrict__ tok_pos, kr_bf16* __restrict__ kcache,
+                                                        kr_bf16* __restrict__ vtcache, int64_t n, int kv_heads, int hd,
+                                                        int layer, int batch, int s_max) {
+    const int64_t total = n * kv_heads * hd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % hd);
+        const int64_t t = i / hd;
+        const int h = (int)(t % kv_heads);
+        const int64_t tok = t / kv_heads;
+        const int sq = tok_seq[tok], pos = tok_pos[tok];
+        const int64_t base = ((int64_t)layer * batch + sq) * kv_heads + h;
+        kcache[(base * s_max + pos) * hd + d] = k[tok * row_stride + h * hd + d];
+        vtcache[((base * (s_max >> 6) + (pos >> 6)) * hd + d) * 64 + (pos & 63)] = v[tok * row_stride + h * hd + d];
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+static int launch_rope_inplace(kr_bf16* x, const float* cos, const float* sin, int64_t n, int heads, int hd,
+                               int64_t row_stride, kr_stream s, const char* who) {
+    KR_CHECK_ARG(x && cos && sin && n >= 0 && heads > 0 && hd > 0 && hd % 16 == 0 && (row_stride & 7) == 0 &&
+                     row_stride >= (int64_t)heads * hd,
+                 "%s: bad args", who);
+    if (n == 0) return KR_OK;
+    const int64_t total = n * heads * (hd >> 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    rope_inplace_kernel<<<grid, 256, 0, kr_hs(s)>>>(x, cos, sin, n, heads, hd, row_stride);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_rope2d_vision(kr_bf16* x, const float* cos, const float* sin, int64_t n, int heads, int hd,
+                                int64_t row_stride, kr_stream s) {
+    return launch_rope_inplace(x, cos, sin, n, heads, hd, row_stride, s, "kr_rope2d_vision");
+}
+
+extern "C" int kr_mrope(kr_bf16* x, const float* cos, const float* sin, int64_t n, int heads, int hd,
+                        int64_t row_stride, kr_stream s) {
+    return launch_rope_inplace(x, cos, sin, n, heads, hd, row_stride, s, "kr_mrope");
+}
+
+extern "C" int kr_qkv_prep(const kr_bf16* qkv, int64_t ld_qkv, int q_off, int k_off, int v_off, const float* cos,
+                           const float* sin, const int32_t* blk_tok0, const int32_t* blk_ntok,
+                           const int64_t* blk_k_row0, const int64_t* blk_vt_blk, int n_blk, kr_bf16* q_out,
+                           int64_t q_head_stride, kr_bf16* k_out, int64_t k_head_stride, kr_bf16* vt_out,
+                           int64_t vt_head_stride, int q_heads, int kv_heads, int hd, kr_stream s) {
+    KR_CHECK_ARG(qkv && cos && sin && blk_tok0 && blk_ntok && blk_k_row0 && blk_vt_blk && q_out && k_out && vt_out,
+                 "kr_qkv_prep: null pointer");
+    KR_CHECK_ARG(hd == 80 || hd == 128, "kr_qkv_prep: hd=%d (only 80, 128)", hd);
+    KR_CHECK_ARG((ld_qkv & 7) == 0 && (q_off & 7) == 0 && (k_off & 7) == 0 && (v_off & 7) == 0, "kr_qkv_prep: alignment");
+    if (n_blk == 0) return KR_OK;
+    dim3 grid(n_blk, q_heads + kv_heads);
+    if (hd == 80)
+        qkv_prep_kernel<80><<<grid, 256, 0, kr_hs(s)>>>(qkv, ld_qkv, q_off, k_off, v_off, cos, sin, blk_tok0, blk_ntok,
+                                                        blk_k_row0, blk_vt_blk, q_out, q_head_stride, k_out,
+                                                        k_head_stride, vt_out, vt_head_stride, q_heads);
+    else
+        qkv_prep_kernel<128><<<grid, 256, 0, kr_hs(s)>>>(qkv, ld_qkv, q_off, k_off, v_off, cos, sin, blk_tok0, blk_ntok,
+                                                         blk_k_row0, blk_vt_blk, q_out, q_head_stride, k_out,
+                                                         k_head_stride, vt_out, vt_head_stride, q_heads);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_attn_varlen(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out, const int32_t* qblk,
+                              const int32_t* qblk_len, int n_qblk, int64_t nq_total, int q_heads, int kv_heads, int hd,
+                              int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal, kr_stream s) {
+    KR_CHECK_ARG(q && k && vt && out && qblk && qblk_len, "kr_attn_varlen: null pointer");
+    KR_CHECK_ARG(hd == 80 || hd == 128, "kr_attn_varlen: hd=%d (only 80, 128)", hd);
+    KR_CHECK_ARG(q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "kr_attn_varlen: heads");
+    if (n_qblk == 0) return KR_OK;
+    dim3 grid(n_qblk, q_heads);
+    const float sl = scale * 1.4426950408889634f;
+    const int group = q_heads / kv_heads;
+#define KR_LAUNCH_ATTN(HD_, C_)                                                                                     \
+    attn_varlen_kernel<HD_, C_><<<grid, 256, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total, q_heads, group, \
+                                                            k_head_stride, vt_head_stride, sl)
+    if (hd == 80) {
+        if (causal) KR_LAUNCH_ATTN(80, true); else KR_LAUNCH_ATTN(80, false);
+    } else {
+        if (causal) KR_LAUNCH_ATTN(128, true); else KR_LAUNCH_ATTN(128, false);
+    }
+#undef KR_LAUNCH_ATTN
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_kv_append(const kr_bf16* k, const kr_bf16* v, int64_t row_stride, const int32_t* tok_seq,
+                            const int32_t* tok_pos, kr_bf16* kcache, kr_bf16* vtcache, int64_t n, int kv_heads, int hd,
+                            int layer, int batch, int s_max, kr_stream s) {
+    KR_CHECK_ARG(k && v && tok_seq && tok_pos && kcache && vtcache && s_max % 64 == 0, "kr_kv_append: bad args");
+    if (n == 0) return KR_OK;
+    const int64_t total = n * kv_heads * hd;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    kv_append_kernel<<<grid, 256, 0, kr_hs(s)>>>(k, v, row_stride, tok_seq, tok_pos, kcache, vtcache, n, kv_heads, hd,
+                                                 layer, batch, s_max);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_decode_qkv_prep(const kr_bf16* qkv, const float* inv_freq, const int32_t* ctx_len,
+                                  const int32_t* rope_delta, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int batch,
+                                  int heads, int kv_heads, int hd, int layer, int s_max, kr_stream s) {
+    KR_CHECK_ARG(qkv && inv_freq && ctx_len && rope_delta && q_out && kcache && vtcache, "kr_decode_qkv_prep: null");
+    KR_CHECK_ARG(batch > 0 && s_max % 64 == 0 && hd % 2 == 0, "kr_decode_qkv_prep: bad sizes");
+    decode_qkv_prep_kernel<<<batch, 256, 0, kr_hs(s)>>>(qkv, inv_freq, ctx_len, rope_delta, q_out, kcache, vtcache, heads,
+                                                        kv_heads, hd, layer, batch, s_max);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_attn_decode_gqa(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
+                                  kr_bf16* out, float* workspace, int batch, int heads, int kv_heads, int hd, int layer,
+                                  int s_max, int n_split, float scale, kr_stream s) {
+    KR_CHECK_ARG(q && kcache && vtcache && ctx_len && out && workspace, "kr_attn_decode_gqa: null pointer");
+    KR_CHECK_ARG(hd == 128, "kr_attn_decode_gqa: hd=%d (only 128)", hd);
+    KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_gqa: GQA group must be <= 16");
+    KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_gqa: bad sizes");
+    dim3 grid(n_split, kv_heads, batch);
+    attn_decode_kernel<128><<<grid, 256, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, workspace, heads, kv_heads, layer,
+                                                        batch, s_max, scale * 1.4426950408889634f);
+    KR_CHECK_LAUNCH();
+    attn_decode_combine_kernel<<<batch * heads, hd, 0, kr_hs(s)>>>(workspace, out, n_split * 4, hd);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}

@@ -1,0 +1,86 @@
+// Shared device/host helpers for libkaranta_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/karanta_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define KR_WAVE 64
+
+// ---------------------------------------------------------------- error plumbing (host)
+void kr_set_error(const char* fmt, ...);
+
+#define KR_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            kr_set_error(__VA_ARGS__);          \
+            return KR_ERR_ARG;                  \
+        }                                       \
+    } while (0)
+
+#define KR_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            kr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return KR_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define KR_CHECK_LAUNCH()                                                               \
+    do {                                                                                \
+        hipError_t _e = hipGetLastError();                                              \
+        if (_e != hipSuccess) {                                                         \
+            kr_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return KR_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+static inline hipStream_t kr_hs(kr_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------- bf16 <-> f32 (device)
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN kept
+__device__ __forceinline__ float bfbits2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+__device__ __forceinline__ float bfround(float v) { return (float)((__bf16)v); }
+
+// 16-byte vector load/store of 8 bf16
+__device__ __forceinline__ bf16x8 ld8(const kr_bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st8(kr_bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+__device__ __forceinline__ bf16x8 ld8_nt(const kr_bf16* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (bid % 8) get a
+// contiguous chunk of the work list, so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

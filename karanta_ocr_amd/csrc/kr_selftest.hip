@@ -1,0 +1,71 @@
+// Device self-test: pins the MFMA lane layouts the kernels rely on with exact integer data
+// (A = asymmetric integers, B = asymmetric integers, compared against an integer matmul), so
+// that a transposed C/D map cannot pass (cdna_hip_programming.md §3).
+#include "kr_common.h"
+
+namespace {
+
+__global__ void selftest_mfma_kernel(int* fail) {
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    // ---- 16x16x32: A[i][k] = (i*3 + k) % 7 - 3, B[k][j] = (k*5 + j*2) % 9 - 4
+    {
+        const int r = lane & 15, g = lane >> 4;
+        bf16x8 a, b;
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            a[j] = f2bf((float)((r * 3 + k) % 7 - 3));
+            b[j] = f2bf((float)((k * 5 + r * 2) % 9 - 4));
+        }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 4 * g + reg, col = r;
+            int ref = 0;
+            for (int k = 0; k < 32; ++k) ref += ((row * 3 + k) % 7 - 3) * ((k * 5 + col * 2) % 9 - 4);
+            if (c[reg] != (float)ref) bad |= 1;
+        }
+    }
+    // ---- 32x32x16
+    {
+        const int r = lane & 31, h = lane >> 5;
+        bf16x8 a, b;
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * h + j;
+            a[j] = f2bf((float)((r * 3 + k) % 7 - 3));
+            b[j] = f2bf((float)((k * 5 + r * 2) % 9 - 4));
+        }
+        f32x16 c;
+        for (int i = 0; i < 16; ++i) c[i] = 0.f;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h, col = r;
+            int ref = 0;
+            for (int k = 0; k < 16; ++k) ref += ((row * 3 + k) % 7 - 3) * ((k * 5 + col * 2) % 9 - 4);
+            if (c[reg] != (float)ref) bad |= 2;
+        }
+    }
+    if (bad) atomicOr(fail, bad);
+}
+
+}  // namespace
+
+extern "C" int kr_selftest_mfma(kr_stream s) {
+    int* d = nullptr;
+    KR_CHECK_HIP(hipMalloc(&d, sizeof(int)));
+    KR_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(int), kr_hs(s)));
+    selftest_mfma_kernel<<<1, 64, 0, kr_hs(s)>>>(d);
+    int h = -1;
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, kr_hs(s));
+    if (e == hipSuccess) e = hipStreamSynchronize(kr_hs(s));
+    hipFree(d);
+    if (e != hipSuccess) {
+        kr_set_error("kr_selftest_mfma: %s", hipGetErrorString(e));
+        return KR_ERR_HIP;
+    }
+    if (h != 0) {
+        kr_set_error("kr_selftest_mfma: layout mismatch mask=%d (1: 16x16x32, 2: 32x32x16)", h);
+        return KR_ERR_STATE;
+    }
+    return KR_OK;
+}
