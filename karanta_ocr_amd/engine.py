@@ -1,0 +1,513 @@
+"""MI355X inference engine for the karanta OCR hot path: Qwen2-VL ViT -> scatter -> prefill ->
+greedy decode, every arithmetic step a hand-written HIP kernel behind include/karanta_hip.h.
+
+This is the thing the reference reaches over HTTP (``vllm serve``,
+/root/reference/karanta/pipeline.py:707-742, :317-319) or through Hugging Face ``generate``
+(/root/reference/karanta/training/test_trained_model.py:76-99).  PyTorch is used for device
+memory and streams only; there is no torch arithmetic and no CPU fallback on this path.
+
+Batching model: one `generate` call = one static batch of <= max_batch pages (one image +
+prompt each, any mix of sizes); pages of different requests never interact.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import positions as POS
+from ._lib import EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL, KarantaHipError, lib, ptr
+from .config import ModelConfig
+from .weights import to_bf16_bits
+
+BF16 = torch.bfloat16
+
+
+def _bits(w: np.ndarray) -> np.ndarray:
+    return w if w.dtype == np.uint16 else to_bf16_bits(np.asarray(w, dtype=np.float32))
+
+
+def _align(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
+# =============================================================================
+# weights on the device: one packed arena (this is what kr_bcast_weights sends)
+# =============================================================================
+class DeviceWeights:
+    """All parameters in one contiguous HBM arena, laid out for the kernels:
+
+    * every Linear keeps its [out, in] row-major layout (K contiguous = MFMA fragment order);
+    * decoder q/k/v are fused into one [q+2kv, d] matrix, gate/up into one [2*ff, d] matrix with
+      rows interleaved in groups of 16 (KR_EPI_SILU_MUL);
+    * the patch-embed kernel matrix is zero-padded from K=1176 to 1216 (GEMM BK=64).
+    """
+
+    def __init__(self, cfg: ModelConfig, device: torch.device):
+        self.cfg = cfg
+        self.device = device
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.nbytes = 0
+        self.arena: Optional[torch.Tensor] = None
+        self._plan()
+
+    def _add(self, name: str, shape: Tuple[int, ...]):
+        self.layout[name] = (self.nbytes, tuple(shape))
+        self.nbytes = _align(self.nbytes + 2 * int(np.prod(shape)))
+
+    def _plan(self):
+        v, t = self.cfg.vision, self.cfg.text
+        self._add("vit.patch", (v.embed_dim, v.patch_dim_padded))
+        for i in range(v.depth):
+            p = f"vit.{i}."
+            self._add(p + "ln1.w", (v.embed_dim,)); self._add(p + "ln1.b", (v.embed_dim,))
+            self._add(p + "qkv.w", (3 * v.embed_dim, v.embed_dim)); self._add(p + "qkv.b", (3 * v.embed_dim,))
+            self._add(p + "proj.w", (v.embed_dim, v.embed_dim)); self._add(p + "proj.b", (v.embed_dim,))
+            self._add(p + "ln2.w", (v.embed_dim,)); self._add(p + "ln2.b", (v.embed_dim,))
+            self._add(p + "fc1.w", (v.mlp_dim, v.embed_dim)); self._add(p + "fc1.b", (v.mlp_dim,))
+            self._add(p + "fc2.w", (v.embed_dim, v.mlp_dim)); self._add(p + "fc2.b", (v.embed_dim,))
+        self._add("vit.merger.ln.w", (v.embed_dim,)); self._add("vit.merger.ln.b", (v.embed_dim,))
+        self._add("vit.merger.fc1.w", (v.merge_dim, v.merge_dim)); self._add("vit.merger.fc1.b", (v.merge_dim,))
+        self._add("vit.merger.fc2.w", (v.hidden_size, v.merge_dim)); self._add("vit.merger.fc2.b", (v.hidden_size,))
+        self._add("llm.embed", (t.vocab_size, t.hidden_size))
+        for i in range(t.num_layers):
+            p = f"llm.{i}."
+            self._add(p + "ln1.w", (t.hidden_size,))
+            self._add(p + "qkv.w", (t.qkv_dim, t.hidden_size)); self._add(p + "qkv.b", (t.qkv_dim,))
+            self._add(p + "o.w", (t.hidden_size, t.q_dim))
+            self._add(p + "ln2.w", (t.hidden_size,))
+            self._add(p + "gate_up.w", (2 * t.intermediate_size, t.hidden_size))
+            self._add(p + "down.w", (t.hidden_size, t.intermediate_size))
+        self._add("llm.norm.w", (t.hidden_size,))
+        if not t.tie_word_embeddings:
+            self._add("llm.lm_head", (t.vocab_size, t.hidden_size))
+
+    def allocate(self):
+        self.arena = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+
+    def view(self, name: str) -> torch.Tensor:
+        if name == "llm.lm_head" and self.cfg.text.tie_word_embeddings:
+            name = "llm.embed"
+        off, shape = self.layout[name]
+        n = int(np.prod(shape))
+        return self.arena[off:off + 2 * n].view(BF16).view(*shape)
+
+    def _put(self, name: str, bits: np.ndarray):
+        off, shape = self.layout[name]
+        assert tuple(bits.shape) == shape, (name, bits.shape, shape)
+        src = torch.from_numpy(np.ascontiguousarray(bits).view(np.uint8).reshape(-1))
+        self.arena[off:off + src.numel()].copy_(src, non_blocking=False)
+
+    def load(self, w: Dict[str, np.ndarray]):
+        """Fill the arena from a HF-named state dict (fp32 arrays or bf16 bit patterns)."""
+        if self.arena is None:
+            self.allocate()
+        v, t = self.cfg.vision, self.cfg.text
+        V, Lm = "model.visual.", "model.language_model."
+        pe = _bits(w[V + "patch_embed.proj.weight"]).reshape(v.embed_dim, -1)
+        pad = np.zeros((v.embed_dim, v.patch_dim_padded), np.uint16)
+        pad[:, :pe.shape[1]] = pe
+        self._put("vit.patch", pad)
+        for i in range(v.depth):
+            s, d = f"{V}blocks.{i}.", f"vit.{i}."
+            for a, b in (("norm1.weight", "ln1.w"), ("norm1.bias", "ln1.b"), ("attn.qkv.weight", "qkv.w"),
+                         ("attn.qkv.bias", "qkv.b"), ("attn.proj.weight", "proj.w"), ("attn.proj.bias", "proj.b"),
+                         ("norm2.weight", "ln2.w"), ("norm2.bias", "ln2.b"), ("mlp.fc1.weight", "fc1.w"),
+                         ("mlp.fc1.bias", "fc1.b"), ("mlp.fc2.weight", "fc2.w"), ("mlp.fc2.bias", "fc2.b")):
+                self._put(d + b, _bits(w[s + a]))
+        for a, b in (("merger.ln_q.weight", "ln.w"), ("merger.ln_q.bias", "ln.b"), ("merger.mlp.0.weight", "fc1.w"),
+                     ("merger.mlp.0.bias", "fc1.b"), ("merger.mlp.2.weight", "fc2.w"), ("merger.mlp.2.bias", "fc2.b")):
+            self._put("vit.merger." + b, _bits(w[V + a]))
+        self._put("llm.embed", _bits(w[Lm + "embed_tokens.weight"]))
+        ff = t.intermediate_size
+        if ff % 16:
+            raise KarantaHipError(f"intermediate_size {ff} must be a multiple of 16")
+        for i in range(t.num_layers):
+            s, d = f"{Lm}layers.{i}.", f"llm.{i}."
+            self._put(d + "ln1.w", _bits(w[s + "input_layernorm.weight"]))
+            self._put(d + "ln2.w", _bits(w[s + "post_attention_layernorm.weight"]))
+            self._put(d + "qkv.w", np.concatenate([_bits(w[s + f"self_attn.{n}_proj.weight"]) for n in "qkv"], 0))
+            self._put(d + "qkv.b", np.concatenate([_bits(w[s + f"self_attn.{n}_proj.bias"]) for n in "qkv"], 0))
+            self._put(d + "o.w", _bits(w[s + "self_attn.o_proj.weight"]))
+            g = _bits(w[s + "mlp.gate_proj.weight"]).reshape(ff // 16, 16, -1)
+            u = _bits(w[s + "mlp.up_proj.weight"]).reshape(ff // 16, 16, -1)
+            self._put(d + "gate_up.w", np.stack([g, u], 1).reshape(2 * ff, -1))
+            self._put(d + "down.w", _bits(w[s + "mlp.down_proj.weight"]))
+        self._put("llm.norm.w", _bits(w[Lm + "norm.weight"]))
+        if not t.tie_word_embeddings:
+            self._put("llm.lm_head", _bits(w["lm_head.weight"]))
+        torch.cuda.synchronize(self.device)
+
+
+# =============================================================================
+# request / result types
+# =============================================================================
+@dataclass
+class PageRequest:
+    """One page = one sequence: prompt token ids (image placeholders included) + its images."""
+    input_ids: np.ndarray                      # int64 [P]
+    pixel_values: Optional[np.ndarray] = None  # fp32 [n_patches, 1176] (all images concatenated)
+    grids: List[Tuple[int, int, int]] = field(default_factory=list)
+
+
+@dataclass
+class GenerateResult:
+    tokens: List[np.ndarray]          # per page: generated ids (EOS included, nothing after it)
+    finish_reasons: List[str]         # "stop" | "length"
+    prompt_tokens: List[int]
+    timings: Dict[str, float]
+    logits: Optional[np.ndarray] = None  # [B, steps, V] when return_logits
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
+                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 8):
+        if not torch.cuda.is_available():
+            raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
+        self.L = lib()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.s = self.stream.cuda_stream
+        self.B = max_batch
+        if max_batch > 16:
+            raise KarantaHipError("max_batch > 16 needs the batched-GEMM decode path (not built yet)")
+        self.s_max = _align(s_max, 64)
+        self.max_patches = max_patches
+        self.max_tokens = max_prompt_tokens
+        self.n_split = decode_splits
+        v, t = cfg.vision, cfg.text
+        if v.head_dim not in (80, 128) or t.head_dim != 128:
+            raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
+        self.w = DeviceWeights(cfg, self.device)
+        self._graphs: Dict[Tuple[int, bool], int] = {}
+        self._alloc()
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        v, t, dev = self.cfg.vision, self.cfg.text, self.device
+        N, M, B = self.max_patches, self.max_tokens, self.B
+        z = lambda *shape, dtype=BF16: torch.zeros(*shape, dtype=dtype, device=dev)
+        nvb = N // 64 + 64  # V^T blocks: every image may add one partial block
+        # ViT
+        self.v_pix = z(N, v.patch_dim, dtype=torch.float32)
+        self.v_in = z(N, v.patch_dim_padded)
+        self.v_x = z(N, v.embed_dim)
+        self.v_h = z(N, v.embed_dim)
+        self.v_qkv = z(N, 3 * v.embed_dim)
+        self.v_q = z(v.num_heads, N, v.head_dim)
+        self.v_k = z(v.num_heads, N, v.head_dim)
+        self.v_vt = z(v.num_heads, nvb, v.head_dim, 64)
+        self.v_o = z(N, v.embed_dim)
+        self.v_f = z(N, v.mlp_dim)
+        self.v_m1 = z(N // 4 + 1, v.merge_dim)
+        self.v_cos = z(N, v.head_dim, dtype=torch.float32)
+        self.v_sin = z(N, v.head_dim, dtype=torch.float32)
+        self.img_embeds = z(N // 4 + 1, t.hidden_size)
+        # decoder prefill
+        self.p_x = z(M, t.hidden_size)
+        self.p_h = z(M, t.hidden_size)
+        self.p_qkv = z(M, t.qkv_dim)
+        self.p_q = z(t.num_heads, M, t.head_dim)
+        self.p_o = z(M, t.q_dim)
+        self.p_act = z(M, t.intermediate_size)
+        self.p_cos = z(M, t.head_dim, dtype=torch.float32)
+        self.p_sin = z(M, t.head_dim, dtype=torch.float32)
+        self.p_src = z(M, dtype=torch.int32)
+        # KV cache (zero-initialised: masked keys must be finite)
+        self.kcache = z(t.num_layers, B, t.num_kv_heads, self.s_max, t.head_dim)
+        self.vtcache = z(t.num_layers, B, t.num_kv_heads, self.s_max // 64, t.head_dim, 64)
+        # decode state
+        self.d_x = z(B, t.hidden_size)
+        self.d_qkv = z(B, t.qkv_dim)
+        self.d_q = z(B, t.num_heads, t.head_dim)
+        self.d_o = z(B, t.q_dim)
+        self.d_act = z(B, t.intermediate_size)
+        self.d_logits = z(B, t.vocab_size, dtype=torch.float32)
+        self.d_ws = z(B * t.num_heads * self.n_split * 4 * (t.head_dim + 2), dtype=torch.float32)
+        self.d_ctx = z(B, dtype=torch.int32)
+        self.d_delta = z(B, dtype=torch.int32)
+        self.d_tok = z(B, dtype=torch.int32)
+        self.d_fin = z(B, dtype=torch.int32)
+        self.d_step = z(1, dtype=torch.int32)
+        self.max_new = 0
+        self.d_hist = None
+        self.d_eos = torch.tensor(list(self.cfg.eos_token_ids), dtype=torch.int32, device=dev)
+        self.d_invfreq = torch.from_numpy(POS.rope_inv_freq(t.head_dim, t.rope_theta)).to(dev)
+        self.d_last = z(B, dtype=torch.int32)
+        torch.cuda.synchronize(dev)
+
+    def load_weights(self, weights: Dict[str, np.ndarray]):
+        self.w.load(weights)
+
+    # ------------------------------------------------------------------ small launch helpers
+    def _gemm(self, A, W, C_, M, bias=None, res=None, epi=EPI_NONE):
+        N, K = W.shape
+        self.L.kr_gemm_bf16(ptr(A), A.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
+                            ptr(C_), C_.stride(0), M, N, K, epi, self.s)
+
+    def _gemv(self, x, W, out, M, bias=None, res=None, epi=EPI_NONE, norm_w=None, out_f32=None):
+        N, K = W.shape
+        o = out if out is not None else out_f32
+        self.L.kr_gemv_bf16(ptr(x), x.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
+                            ptr(out), ptr(out_f32), o.stride(0), M, N, K, epi, ptr(norm_w),
+                            self.cfg.text.rms_norm_eps, self.s)
+
+    def _h2d(self, dst: torch.Tensor, arr: np.ndarray):
+        src = torch.from_numpy(np.ascontiguousarray(arr))
+        dst.view(-1)[:src.numel()].copy_(src.view(-1), non_blocking=False)
+
+    # ------------------------------------------------------------------ vision tower
+    def vit_forward(self, pixel_values: np.ndarray, grids: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Qwen2VisionTransformerPretrainedModel.forward (TF:700-731).  Returns a view of the merged
+        image embeddings ``[T, d]`` (bf16, device)."""
+        v, L, s, w = self.cfg.vision, self.L, self.s, self.w
+        n = int(pixel_values.shape[0])
+        if n == 0:
+            return self.img_embeds[:0]
+        if n > self.max_patches:
+            raise KarantaHipError(f"{n} patches > max_patches {self.max_patches}")
+        plan = POS.vit_attn_plan(grids)
+        assert plan.n_tokens == n, (plan.n_tokens, n)
+        cos, sin = POS.vision_rotary_tables(grids, v.head_dim, v.spatial_merge_size)
+        dev = self.device
+        with torch.cuda.stream(self.stream):
+            self._h2d(self.v_pix, pixel_values.astype(np.float32, copy=False))
+            self._h2d(self.v_cos, cos)
+            self._h2d(self.v_sin, sin)
+            t_ = lambda a: torch.from_numpy(a).to(dev)
+            blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
+            qblk, qlen = t_(plan.qblk), t_(plan.qblk_len)
+            D, H, hd = v.embed_dim, v.num_heads, v.head_dim
+            L.kr_cast_pad_f32_bf16(ptr(self.v_pix), ptr(self.v_in), n, v.patch_dim, v.patch_dim_padded, s)
+            self._gemm(self.v_in, w.view("vit.patch"), self.v_x, n)
+            nvb_total = self.v_vt.shape[1]
+            if plan.n_vt_blocks > nvb_total:
+                raise KarantaHipError("too many image segments for the V^T buffer")
+            for i in range(v.depth):
+                p = f"vit.{i}."
+                L.kr_layernorm(ptr(self.v_x), ptr(w.view(p + "ln1.w")), ptr(w.view(p + "ln1.b")), ptr(self.v_h), n, D, 1e-6, s)
+                self._gemm(self.v_h, w.view(p + "qkv.w"), self.v_qkv, n, bias=w.view(p + "qkv.b"))
+                L.kr_qkv_prep(ptr(self.v_qkv), 3 * D, 0, D, 2 * D, ptr(self.v_cos), ptr(self.v_sin),
+                              ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
+                              ptr(self.v_q), self.v_q.stride(0), ptr(self.v_k), self.v_k.stride(0),
+                              ptr(self.v_vt), self.v_vt.stride(0), H, H, hd, s)
+                L.kr_attn_varlen(ptr(self.v_q), ptr(self.v_k), ptr(self.v_vt), ptr(self.v_o), ptr(qblk), ptr(qlen),
+                                 plan.qblk.shape[0], self.v_q.shape[1], H, H, hd, self.v_k.stride(0),
+                                 self.v_vt.stride(0), hd ** -0.5, 0, s)
+                self._gemm(self.v_o, w.view(p + "proj.w"), self.v_x, n, bias=w.view(p + "proj.b"), res=self.v_x)
+                L.kr_layernorm(ptr(self.v_x), ptr(w.view(p + "ln2.w")), ptr(w.view(p + "ln2.b")), ptr(self.v_h), n, D, 1e-6, s)
+                self._gemm(self.v_h, w.view(p + "fc1.w"), self.v_f, n, bias=w.view(p + "fc1.b"), epi=EPI_QUICK_GELU)
+                self._gemm(self.v_f, w.view(p + "fc2.w"), self.v_x, n, bias=w.view(p + "fc2.b"), res=self.v_x)
+            # PatchMerger (TF:277-290): LN -> view [n/4, 4D] -> Linear+GELU -> Linear
+            L.kr_layernorm(ptr(self.v_x), ptr(w.view("vit.merger.ln.w")), ptr(w.view("vit.merger.ln.b")), ptr(self.v_h), n, D, 1e-6, s)
+            T = n // (v.spatial_merge_size ** 2)
+            merged_in = self.v_h.view(-1)[: T * v.merge_dim].view(T, v.merge_dim)
+            self._gemm(merged_in, w.view("vit.merger.fc1.w"), self.v_m1, T, bias=w.view("vit.merger.fc1.b"), epi=EPI_GELU_ERF)
+            self._gemm(self.v_m1, w.view("vit.merger.fc2.w"), self.img_embeds, T, bias=w.view("vit.merger.fc2.b"))
+        return self.img_embeds[:T]
+
+    # ------------------------------------------------------------------ prefill
+    def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int) -> List[int]:
+        """embed+scatter, M-RoPE, 28 x decoder layer over the flattened prompts (causal varlen
+        attention writing the KV cache), last-token logits -> first greedy token.
+        Leaves the decode state (d_x, d_ctx, d_delta, history row 0) ready.  Returns prompt lengths."""
+        cfg, t, L, s, w, dev = self.cfg, self.cfg.text, self.L, self.s, self.w, self.device
+        B = len(pages)
+        lens = [int(len(p.input_ids)) for p in pages]
+        M = sum(lens)
+        if M > self.max_tokens:
+            raise KarantaHipError(f"{M} prompt tokens > max_prompt_tokens {self.max_tokens}")
+        if max(lens) + self.max_new > self.s_max:
+            raise KarantaHipError(f"prompt {max(lens)} + max_new_tokens {self.max_new} exceeds s_max {self.s_max}")
+        src = np.empty(M, np.int32)
+        cos = np.empty((M, t.head_dim), np.float32)
+        sin = np.empty((M, t.head_dim), np.float32)
+        deltas = np.zeros(self.B, np.int32)
+        off, img_off = 0, 0
+        for b, pg in enumerate(pages):
+            ids = np.asarray(pg.input_ids).reshape(-1)
+            is_img = ids == cfg.image_token_id
+            k = int(is_img.sum())
+            row = ids.astype(np.int64).copy()
+            row[is_img] = -(np.arange(img_off, img_off + k) + 1)
+            if row.max(initial=0) >= t.vocab_size:
+                raise KarantaHipError("token id out of vocabulary")
+            src[off:off + len(ids)] = row
+            pos3, delta = POS.rope_index_one(ids, pg.grids, cfg.image_token_id, cfg.vision.spatial_merge_size)
+            c, sn = POS.mrope_tables(pos3, t.head_dim, t.rope_theta, t.mrope_section)
+            cos[off:off + len(ids)], sin[off:off + len(ids)] = c, sn
+            deltas[b] = delta
+            off += len(ids)
+            img_off += k
+        if img_off != n_image_tokens_total:
+            raise KarantaHipError(f"Image features and image tokens do not match, tokens: {img_off}, "
+                                  f"features: {n_image_tokens_total}")
+        plan = POS.prefill_attn_plan(lens, list(range(B)), t.num_kv_heads, self.s_max)
+        last_rows = (np.cumsum(lens) - 1).astype(np.int32)
+        ctx0 = np.zeros(self.B, np.int32)
+        ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_argmax_embed adds 1 -> number of cached tokens
+        with torch.cuda.stream(self.stream):
+            self._h2d(self.p_src, src)
+            self._h2d(self.p_cos, cos)
+            self._h2d(self.p_sin, sin)
+            self._h2d(self.d_delta, deltas)
+            self._h2d(self.d_ctx, ctx0)
+            self._h2d(self.d_last, last_rows)
+            self.d_fin.zero_()
+            self.d_step.zero_()
+            t_ = lambda a: torch.from_numpy(a).to(dev)
+            blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
+            qblk, qlen = t_(plan.qblk), t_(plan.qblk_len)
+            d, H, KVH, hd = t.hidden_size, t.num_heads, t.num_kv_heads, t.head_dim
+            L.kr_embed_scatter(ptr(self.p_src), ptr(w.view("llm.embed")), ptr(self.img_embeds), ptr(self.p_x), M, d, s)
+            k_head_stride = self.s_max * hd
+            vt_head_stride = (self.s_max // 64) * hd * 64
+            for i in range(t.num_layers):
+                p = f"llm.{i}."
+                L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln1.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
+                self._gemm(self.p_h, w.view(p + "qkv.w"), self.p_qkv, M, bias=w.view(p + "qkv.b"))
+                kc, vc = self.kcache[i], self.vtcache[i]
+                L.kr_qkv_prep(ptr(self.p_qkv), t.qkv_dim, 0, t.q_dim, t.q_dim + t.kv_dim, ptr(self.p_cos), ptr(self.p_sin),
+                              ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
+                              ptr(self.p_q), self.p_q.stride(0), ptr(kc), k_head_stride, ptr(vc), vt_head_stride,
+                              H, KVH, hd, s)
+                L.kr_attn_varlen(ptr(self.p_q), ptr(kc), ptr(vc), ptr(self.p_o), ptr(qblk), ptr(qlen),
+                                 plan.qblk.shape[0], self.p_q.shape[1], H, KVH, hd, k_head_stride, vt_head_stride,
+                                 hd ** -0.5, 1, s)
+                self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x)
+                L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln2.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
+                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL)
+                self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x)
+            # last position of every sequence -> final norm (fused) -> lm_head -> greedy token
+            L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)
+            self._lm_head_and_sample(B)
+        return lens
+
+    def _lm_head_and_sample(self, B: int):
+        t, L, w, s = self.cfg.text, self.L, self.w, self.s
+        self._gemv(self.d_x, w.view("llm.lm_head"), None, B, norm_w=w.view("llm.norm.w"), out_f32=self.d_logits)
+        L.kr_argmax_embed(ptr(self.d_logits), self.d_logits.stride(0), t.vocab_size, ptr(w.view("llm.embed")),
+                          t.hidden_size, ptr(self.d_tok), ptr(self.d_hist), ptr(self.d_step), ptr(self.d_ctx),
+                          ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
+                          1 if self._ignore_eos else 0, ptr(self.d_x), B, s)
+
+    # ------------------------------------------------------------------ decode
+    def _decode_step_launches(self, B: int):
+        """One decode step = 7 launches per layer + 3 (TF:559-624 per layer, TF:839, :1320-1323)."""
+        t, L, w, s = self.cfg.text, self.L, self.w, self.s
+        H, KVH, hd = t.num_heads, t.num_kv_heads, t.head_dim
+        for i in range(t.num_layers):
+            p = f"llm.{i}."
+            self._gemv(self.d_x, w.view(p + "qkv.w"), self.d_qkv, B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"))
+            # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base (layer=0)
+            kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])
+            L.kr_decode_qkv_prep(ptr(self.d_qkv), ptr(self.d_invfreq), ptr(self.d_ctx), ptr(self.d_delta), ptr(self.d_q),
+                                 kc, vc, B, H, KVH, hd, 0, self.s_max, s)
+            L.kr_attn_decode_gqa(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o),
+                                 ptr(self.d_ws), B, H, KVH, hd, 0, self.s_max, self.n_split, hd ** -0.5, s)
+            self._gemv(self.d_o, w.view(p + "o.w"), self.d_x, B, res=self.d_x)
+            self._gemv(self.d_x, w.view(p + "gate_up.w"), self.d_act, B, epi=EPI_SILU_MUL, norm_w=w.view(p + "ln2.w"))
+            self._gemv(self.d_act, w.view(p + "down.w"), self.d_x, B, res=self.d_x)
+        self._lm_head_and_sample(B)
+
+    def _graph_for(self, B: int) -> int:
+        key = (B, self._ignore_eos)
+        g = self._graphs.get(key)
+        if g is None:
+            L = self.L
+            L.kr_graph_begin_capture(self.s)
+            try:
+                self._decode_step_launches(B)
+            finally:
+                ge = C.c_void_p()
+                L.kr_graph_end_capture(self.s, C.byref(ge))
+            g = ge.value
+            self._graphs[key] = g
+        return g
+
+    # ------------------------------------------------------------------ public API
+    def generate(self, pages: Sequence[PageRequest], max_new_tokens: int, ignore_eos: bool = False,
+                 use_graph: bool = True, return_logits: bool = False, sync_every: int = 32) -> GenerateResult:
+        """Greedy generation for a static batch of pages (temperature 0 — the reference's
+        ``build_page_query`` default, /root/reference/karanta/pipeline.py:166-171)."""
+        B = len(pages)
+        if not 1 <= B <= self.B:
+            raise KarantaHipError(f"batch {B} not in 1..{self.B}")
+        if max_new_tokens < 1:
+            raise ValueError("max_new_tokens must be >= 1")
+        t0 = time.perf_counter()
+        self._ignore_eos = bool(ignore_eos)
+        if self.d_hist is None or self.max_new < max_new_tokens:
+            self.max_new = max_new_tokens
+            self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
+            # history pointer is baked into captured graphs
+            for g in self._graphs.values():
+                self.L.kr_graph_destroy(g)
+            self._graphs.clear()
+        pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
+        grids = [g for p in pages for g in p.grids]
+        n_img_tok = 0
+        if pvs:
+            emb = self.vit_forward(np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0], grids)
+            n_img_tok = emb.shape[0]
+        self.stream.synchronize()
+        t1 = time.perf_counter()
+        lens = self.prefill(pages, n_img_tok)
+        logits_steps = []
+        if return_logits:
+            self.stream.synchronize()
+            logits_steps.append(self.d_logits[:B].float().cpu().numpy().copy())
+        self.stream.synchronize()
+        t2 = time.perf_counter()
+        steps_done = 1
+        with torch.cuda.stream(self.stream):
+            want_graph = use_graph and not return_logits
+            graph = self._graphs.get((B, self._ignore_eos)) if want_graph else None
+            while steps_done < max_new_tokens:
+                if graph is not None:
+                    self.L.kr_graph_launch(graph, self.s)
+                else:
+                    # eager step; the first one also sets per-kernel attributes, so capture only
+                    # after it (no attribute calls inside a stream capture)
+                    self._decode_step_launches(B)
+                    if want_graph:
+                        graph = self._graph_for(B)
+                steps_done += 1
+                if return_logits:
+                    self.stream.synchronize()
+                    logits_steps.append(self.d_logits[:B].float().cpu().numpy().copy())
+                if not ignore_eos and steps_done % sync_every == 0:
+                    self.stream.synchronize()
+                    if bool(self.d_fin[:B].all().item()):
+                        break
+        self.stream.synchronize()
+        t3 = time.perf_counter()
+        hist = self.d_hist[:steps_done, :B].cpu().numpy().T  # [B, steps]
+        toks, reasons = [], []
+        eos = set(int(e) for e in self.cfg.eos_token_ids)
+        for b in range(B):
+            row = hist[b]
+            cut, reason = len(row), "length"
+            if not ignore_eos:
+                hit = np.flatnonzero(np.isin(row, list(eos)))
+                if hit.size:
+                    cut, reason = int(hit[0]) + 1, "stop"
+            toks.append(row[:cut].astype(np.int64))
+            reasons.append(reason)
+        return GenerateResult(
+            tokens=toks, finish_reasons=reasons, prompt_tokens=lens,
+            timings={"vit_s": t1 - t0, "prefill_s": t2 - t1, "decode_s": t3 - t2, "total_s": t3 - t0,
+                     "decode_steps": steps_done - 1},
+            logits=np.stack(logits_steps, 1) if return_logits else None)
+
+    def close(self):
+        for g in self._graphs.values():
+            self.L.kr_graph_destroy(g)
+        self._graphs.clear()

@@ -1,0 +1,567 @@
+"""Parity of every HIP kernel against numpy restatements, through the C-ABI (ctypes), on a real
+MI355X.  Integer-valued inputs make the MFMA paths bit-exact (any layout slip fails exactly);
+random inputs use a stated bf16 tolerance."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from karanta_ocr_amd import positions as POS  # noqa: E402
+from karanta_ocr_amd._lib import (EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL, KarantaHipError, lib,  # noqa: E402
+                                  ptr)
+from karanta_ocr_amd.weights import bf16_round  # noqa: E402
+from oracle import qwen2vl_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return lib()
+
+
+def dev_bf16(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(torch.bfloat16).contiguous()
+
+
+def host(t: torch.Tensor) -> np.ndarray:
+    torch.cuda.synchronize()
+    return t.float().cpu().numpy()
+
+
+def rnd(rng, *shape, scale=1.0):
+    return bf16_round(rng.standard_normal(shape).astype(np.float32) * np.float32(scale))
+
+
+def ints(rng, *shape, lo=-1, hi=2):
+    return rng.integers(lo, hi, size=shape).astype(np.float32)
+
+
+def assert_close_bf16(got, ref, rel=2 ** -7, abs_=1e-2, what=""):
+    """|got-ref| <= abs_ + rel*|ref| — one bf16 rounding of the result plus accumulation-order noise."""
+    err = np.abs(got - ref)
+    tol = abs_ + rel * np.abs(ref)
+    bad = err > tol
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} out of tolerance, max err {err.max():.4g} at " \
+                          f"{np.unravel_index(err.argmax(), err.shape)} (ref {ref.flat[err.argmax()]:.4g})"
+
+
+# ----------------------------------------------------------------------------- self test
+def test_mfma_layout_selftest(L):
+    L.kr_selftest_mfma(0)
+
+
+def test_device_info(L):
+    name = C.create_string_buffer(64)
+    cus, mem = C.c_int(), C.c_size_t()
+    L.kr_device_info(0, name, C.byref(cus), C.byref(mem))
+    assert b"gfx950" in name.value, name.value
+    assert cus.value == 256
+    assert mem.value > 200 * 2 ** 30
+
+
+# ----------------------------------------------------------------------------- elementwise
+def test_cast_pad(L):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((37, 1176)).astype(np.float32)
+    src = torch.from_numpy(x).to(DEV)
+    dst = torch.full((37, 1216), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.kr_cast_pad_f32_bf16(ptr(src), ptr(dst), 37, 1176, 1216, 0)
+    out = host(dst)
+    np.testing.assert_array_equal(out[:, :1176], bf16_round(x))
+    assert not out[:, 1176:].any()
+
+
+@pytest.mark.parametrize("d", [320, 1280, 1536, 3584])
+@pytest.mark.parametrize("rows", [1, 5, 130])
+def test_layernorm(L, d, rows):
+    rng = np.random.default_rng(d + rows)
+    x, w, b = rnd(rng, rows, d, scale=2.0) + 0.5, rnd(rng, d) + 1, rnd(rng, d, scale=0.1)
+    x = bf16_round(x)
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    L.kr_layernorm(ptr(dev_bf16(x)), ptr(dev_bf16(w)), ptr(dev_bf16(b)), ptr(y), rows, d, 1e-6, 0)
+    ref = O.layer_norm(x, bf16_round(w), bf16_round(b), 1e-6)
+    assert_close_bf16(host(y), ref, what="layernorm")
+
+
+@pytest.mark.parametrize("d", [256, 1536, 3584])
+def test_rmsnorm_matches_oracle_bit_exact_policy(L, d):
+    rng = np.random.default_rng(d)
+    rows = 9
+    x, w = rnd(rng, rows, d, scale=3.0), bf16_round(rnd(rng, d) * 0.1 + 1)
+    big = dev_bf16(np.concatenate([x, np.zeros((rows, 8), np.float32)], 1))  # row stride d+8
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    L.kr_rmsnorm(ptr(big), d + 8, ptr(dev_bf16(w)), ptr(y), rows, d, 1e-6, 0)
+    ref = bf16_round(O.rms_norm(x, w, 1e-6, O._Policy("bf16")))
+    got = host(y)
+    # identical rounding points; rsqrt / summation order may move a value by one bf16 ulp
+    assert_close_bf16(got, ref, rel=2 ** -7, abs_=1e-6, what="rmsnorm")
+    assert (got == ref).mean() > 0.98
+
+
+def test_embed_scatter(L):
+    rng = np.random.default_rng(1)
+    table, img = rnd(rng, 50, 64), rnd(rng, 6, 64)
+    src = np.asarray([3, -1, -2, 49, 0, -6, 7], np.int32)
+    out = torch.empty(len(src), 64, dtype=torch.bfloat16, device=DEV)
+    L.kr_embed_scatter(ptr(torch.from_numpy(src).to(DEV)), ptr(dev_bf16(table)), ptr(dev_bf16(img)), ptr(out), len(src), 64, 0)
+    ref = np.stack([table[i] if i >= 0 else img[-i - 1] for i in src])
+    np.testing.assert_array_equal(host(out), ref)
+
+
+def test_argmax_lowest_index_wins_ties(L):
+    rng = np.random.default_rng(2)
+    v = 151936
+    x = rng.standard_normal((5, v)).astype(np.float32)
+    x[0, [100, 90000, 151935]] = 50.0     # tie -> 100
+    x[1, 151935] = 60.0                   # last element
+    x[2, 0] = 60.0                        # first element
+    x[3] = -np.inf
+    x[3, 77777] = -1e30
+    out = torch.zeros(5, dtype=torch.int32, device=DEV)
+    L.kr_argmax(ptr(torch.from_numpy(x).to(DEV)), v, v, ptr(out), 5, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), x.argmax(1))
+
+
+def test_argmax_embed_state_machine(L):
+    rng = np.random.default_rng(3)
+    B, V, d = 3, 512, 64
+    table = rnd(rng, V, d)
+    dt = dev_bf16(table)
+    logits = np.full((B, V), -5.0, np.float32)
+    logits[0, 11] = 1; logits[1, 497] = 1; logits[2, 300] = 1     # seq 1 emits EOS 497
+    dl = torch.from_numpy(logits).to(DEV)
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV)
+    hist = torch.full((4, B), -1, dtype=torch.int32, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ctx = torch.tensor([10, 20, 30], dtype=torch.int32, device=DEV)
+    fin = torch.zeros(B, dtype=torch.int32, device=DEV)
+    eos = torch.tensor([497, 496], dtype=torch.int32, device=DEV)
+    xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):
+        L.kr_argmax_embed(ptr(dl), V, V, ptr(dt), d, ptr(tok), ptr(hist), ptr(step), ptr(ctx), ptr(fin), ptr(eos), 2,
+                          496, 0, ptr(xn), B, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hist.cpu().numpy()[:2], [[11, 497, 300], [11, 496, 300]])  # pad after EOS
+    np.testing.assert_array_equal(fin.cpu().numpy(), [0, 1, 0])
+    np.testing.assert_array_equal(ctx.cpu().numpy(), [12, 22, 32])
+    assert int(step.item()) == 2
+    np.testing.assert_array_equal(host(xn), table[[11, 496, 300]])
+
+
+# ----------------------------------------------------------------------------- GEMM
+def ref_linear(A, W, bias=None, res=None, epi=EPI_NONE):
+    acc = A.astype(np.float64) @ W.astype(np.float64).T
+    if epi == EPI_SILU_MUL:
+        n = W.shape[0]
+        g = acc.reshape(A.shape[0], n // 32, 2, 16)
+        gate, up = g[:, :, 0].reshape(A.shape[0], -1), g[:, :, 1].reshape(A.shape[0], -1)
+        return (gate / (1 + np.exp(-gate)) * up).astype(np.float32)
+    if bias is not None:
+        acc = acc + bias
+    if epi == EPI_QUICK_GELU:
+        acc = acc / (1 + np.exp(-1.702 * acc))
+    elif epi == EPI_GELU_ERF:
+        acc = 0.5 * acc * (1 + np.vectorize(math.erf)(acc / math.sqrt(2)))
+    if res is not None:
+        acc = acc + res
+    return acc.astype(np.float32)
+
+
+def run_gemm(L, A, W, bias=None, res=None, epi=EPI_NONE, lda_pad=0):
+    M, K = A.shape
+    N = W.shape[0]
+    Ad = dev_bf16(np.concatenate([A, np.zeros((M, lda_pad), np.float32)], 1)) if lda_pad else dev_bf16(A)
+    Wd = dev_bf16(W)
+    nc = N // 2 if epi == EPI_SILU_MUL else N
+    Cd = torch.full((M, nc), 9.0, dtype=torch.bfloat16, device=DEV)
+    bd = dev_bf16(bias) if bias is not None else None
+    rd = dev_bf16(res) if res is not None else None
+    L.kr_gemm_bf16(ptr(Ad), K + lda_pad, ptr(Wd), ptr(bd), ptr(rd), nc if res is not None else 0, ptr(Cd), nc, M, N, K,
+                   epi, 0)
+    return host(Cd)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (127, 128, 64), (128, 128, 128), (129, 144, 192), (300, 272, 64),
+                                   (257, 1280, 1216)])
+def test_gemm_exact_on_integers(L, M, N, K):
+    """Entries in {-1,0,1}: every product sum is a small integer, exact in fp32 and (|sum| <= 256) in bf16."""
+    rng = np.random.default_rng(M * 1000 + N + K)
+    A, W = ints(rng, M, K), ints(rng, N, K)
+    # keep |sum| small enough to be bf16-exact: zero out most of K for the big-K case
+    if K > 256:
+        W[:, 200:] = 0
+    got = run_gemm(L, A, W)
+    np.testing.assert_array_equal(got, ref_linear(A, W))
+
+
+def test_gemm_asymmetric_operands_catch_transposes(L):
+    M, N, K = 128, 128, 64
+    A = np.zeros((M, K), np.float32); A[np.arange(64), np.arange(64)] = 1  # rows 0..63 = identity on K
+    W = (np.arange(N)[:, None] % 7 + 2 * (np.arange(K)[None, :] % 5)).astype(np.float32)
+    got = run_gemm(L, A, W)
+    np.testing.assert_array_equal(got, ref_linear(A, W))
+
+
+@pytest.mark.parametrize("epi", [EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF])
+def test_gemm_bias_residual_epilogues(L, epi):
+    rng = np.random.default_rng(10 + epi)
+    M, N, K = 200, 320, 320
+    A, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    bias, res = rnd(rng, N, scale=0.1), rnd(rng, M, N)
+    got = run_gemm(L, A, W, bias=bias, res=res, epi=epi, lda_pad=64)
+    assert_close_bf16(got, ref_linear(A, W, bias, res, epi), what=f"gemm epi {epi}")
+
+
+def test_gemm_silu_mul_interleaved(L):
+    rng = np.random.default_rng(20)
+    M, ff, K = 150, 512, 256
+    A, Wp = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5)
+    got = run_gemm(L, A, Wp, epi=EPI_SILU_MUL)
+    assert got.shape == (M, ff)
+    assert_close_bf16(got, ref_linear(A, Wp, epi=EPI_SILU_MUL), what="gemm silu_mul")
+
+
+def test_gemm_in_place_residual(L):
+    rng = np.random.default_rng(21)
+    M, N, K = 130, 256, 128
+    A, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
+    Xd = dev_bf16(X)
+    L.kr_gemm_bf16(ptr(dev_bf16(A)), K, ptr(dev_bf16(W)), 0, ptr(Xd), N, ptr(Xd), N, M, N, K, EPI_NONE, 0)
+    assert_close_bf16(host(Xd), ref_linear(A, W, res=X), what="in-place residual")
+
+
+def test_gemm_rejects_bad_shapes(L):
+    with pytest.raises(KarantaHipError):
+        L.kr_gemm_bf16(256, 100, 256, 0, 0, 0, 256, 128, 4, 128, 100, 0, 0)
+
+
+# ----------------------------------------------------------------------------- GEMV
+def run_gemv(L, x, W, bias=None, res=None, epi=EPI_NONE, norm_w=None, f32=False, eps=1e-6):
+    M, K = x.shape
+    N = W.shape[0]
+    nc = N // 2 if epi == EPI_SILU_MUL else N
+    xd, Wd = dev_bf16(x), dev_bf16(W)
+    out = torch.full((M, nc), 9.0, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    bd = dev_bf16(bias) if bias is not None else None
+    rd = dev_bf16(res) if res is not None else None
+    nd = dev_bf16(norm_w) if norm_w is not None else None
+    L.kr_gemv_bf16(ptr(xd), K, ptr(Wd), ptr(bd), ptr(rd), nc if res is not None else 0, 0 if f32 else ptr(out),
+                   ptr(out) if f32 else 0, nc, M, N, K, epi, ptr(nd), eps, 0)
+    return host(out)
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(16, 64), (48, 128), (2048, 256), (512, 1536), (96, 8960)])
+def test_gemv_exact_on_integers(L, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    if K > 256:
+        W[:, 256:] = 0
+        W[:, :256] = np.roll(W[:, :256], 7, axis=1)
+        x = np.roll(x, 3, axis=1)
+    np.testing.assert_array_equal(run_gemv(L, x, W), ref_linear(x, W))
+
+
+def test_gemv_k_order_sensitivity(L):
+    """x = one-hot at each k in turn picks out column k of W: any k-permutation mismatch between the
+    weight and activation fragments shows up as a wrong column."""
+    N, K = 32, 256
+    W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] % 11).astype(np.float32) % 13
+    for k0 in (0, 5, 8, 17, 63, 64, 100, 255):
+        x = np.zeros((2, K), np.float32); x[0, k0] = 1; x[1, (k0 + 1) % K] = 2
+        got = run_gemv(L, x, W)
+        np.testing.assert_array_equal(got, ref_linear(x, W))
+
+
+@pytest.mark.parametrize("M", [1, 8])
+def test_gemv_bias_residual_f32(L, M):
+    rng = np.random.default_rng(30 + M)
+    N, K = 512, 1536
+    x, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    bias, res = rnd(rng, N, scale=0.1), rnd(rng, M, N)
+    assert_close_bf16(run_gemv(L, x, W, bias=bias, res=res), ref_linear(x, W, bias, res), what="gemv bias+res")
+    got32 = run_gemv(L, x, W, bias=bias, f32=True)
+    np.testing.assert_allclose(got32, ref_linear(x, W, bias), atol=2e-3, rtol=1e-4)
+
+
+def test_gemv_wide_n_two_tiles_per_block(L):
+    rng = np.random.default_rng(31)
+    M, N, K = 8, 16 * 2 * 512 + 32, 256      # "wide" path, with a ragged last block
+    x, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    got32 = run_gemv(L, x, W, f32=True)
+    np.testing.assert_allclose(got32, ref_linear(x, W), atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,K", [(8, 1536), (5, 256), (16, 3584)])
+def test_gemv_fused_rmsnorm(L, M, K):
+    rng = np.random.default_rng(32 + M)
+    N = 256
+    x, W, nw = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(run_gemv(L, x, W, norm_w=nw), ref_linear(xn, W), what="gemv fused rmsnorm")
+
+
+def test_gemv_silu_mul(L):
+    rng = np.random.default_rng(33)
+    M, ff, K = 8, 1024, 1536
+    x, Wp = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5)
+    got = run_gemv(L, x, Wp, epi=EPI_SILU_MUL)
+    assert got.shape == (M, ff)
+    assert_close_bf16(got, ref_linear(x, Wp, epi=EPI_SILU_MUL), what="gemv silu")
+    # big K (x not staged in LDS) + SILU
+    K2 = 8960
+    x2, W2 = rnd(rng, 2, K2), rnd(rng, 64, K2, scale=K2 ** -0.5)
+    assert_close_bf16(run_gemv(L, x2, W2, epi=EPI_SILU_MUL), ref_linear(x2, W2, epi=EPI_SILU_MUL), what="gemv silu bigK")
+
+
+def test_gemv_in_place_residual(L):
+    rng = np.random.default_rng(34)
+    M, N, K = 8, 256, 512
+    a, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
+    Xd = dev_bf16(X)
+    L.kr_gemv_bf16(ptr(dev_bf16(a)), K, ptr(dev_bf16(W)), 0, ptr(Xd), N, ptr(Xd), 0, N, M, N, K, EPI_NONE, 0, 0.0, 0)
+    assert_close_bf16(host(Xd), ref_linear(a, W, res=X), what="gemv in-place")
+
+
+# ----------------------------------------------------------------------------- rotary
+@pytest.mark.parametrize("hd", [80, 128])
+def test_rope_inplace(L, hd):
+    rng = np.random.default_rng(40 + hd)
+    n, H = 33, 3
+    x = rnd(rng, n, H, hd)
+    ang = rng.uniform(0, 6.28, size=(n, hd // 2)).astype(np.float32)
+    cos = np.concatenate([np.cos(ang), np.cos(ang)], -1).astype(np.float32)
+    sin = np.concatenate([np.sin(ang), np.sin(ang)], -1).astype(np.float32)
+    xd = dev_bf16(x.reshape(n, H * hd))
+    fn = L.kr_rope2d_vision if hd == 80 else L.kr_mrope
+    fn(ptr(xd), ptr(torch.from_numpy(cos).to(DEV)), ptr(torch.from_numpy(sin).to(DEV)), n, H, hd, H * hd, 0)
+    ref = x * cos[:, None] + O.rotate_half(x) * sin[:, None]
+    assert_close_bf16(host(xd).reshape(n, H, hd), ref, abs_=1e-3, what="rope")
+
+
+# ----------------------------------------------------------------------------- prep + varlen attention
+def np_attention(q, k, v, scale, causal, q_pos0=0):
+    """q [H,nq,hd], k/v [KVH,nk,hd] -> [nq, H*hd]; fp64 reference with bf16-rounded P like the kernel/HF."""
+    H, nq, hd = q.shape
+    KVH = k.shape[0]
+    g = H // KVH
+    out = np.zeros((nq, H, hd), np.float64)
+    for h in range(H):
+        s = (q[h].astype(np.float64) @ k[h // g].astype(np.float64).T) * scale
+        if causal:
+            mask = np.arange(k.shape[1])[None, :] <= (np.arange(nq)[:, None] + q_pos0)
+            s = np.where(mask, s, -np.inf)
+        p = np.exp(s - s.max(-1, keepdims=True))
+        p = p / p.sum(-1, keepdims=True)
+        out[:, h] = p @ v[h // g].astype(np.float64)
+    return out.reshape(nq, H * hd).astype(np.float32)
+
+
+def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256):
+    """Fused qkv rows -> kr_qkv_prep -> kr_attn_varlen, against numpy, for ragged segments."""
+    rng = np.random.default_rng(seed)
+    n = sum(lens)
+    qd, kd = H * hd, KVH * hd
+    qkv = rnd(rng, n, qd + 2 * kd)
+    ang = rng.uniform(0, 6.28, size=(n, hd // 2)).astype(np.float32)
+    cos = np.concatenate([np.cos(ang)] * 2, -1).astype(np.float32)
+    sin = np.concatenate([np.sin(ang)] * 2, -1).astype(np.float32)
+    if as_cache:
+        plan = POS.prefill_attn_plan(lens, list(range(len(lens))), KVH, s_max)
+        B = len(lens)
+        k_out = torch.zeros(B, KVH, s_max, hd, dtype=torch.bfloat16, device=DEV)
+        vt_out = torch.zeros(B, KVH, s_max // 64, hd, 64, dtype=torch.bfloat16, device=DEV)
+        k_hs, vt_hs = s_max * hd, (s_max // 64) * hd * 64
+    else:
+        assert KVH == H
+        plan = POS.make_attn_plan(lens, np.concatenate([[0], np.cumsum(lens)[:-1]]),
+                                  np.concatenate([[0], np.cumsum([(x + 63) // 64 for x in lens])[:-1]]), causal)
+        k_out = torch.zeros(KVH, n, hd, dtype=torch.bfloat16, device=DEV)
+        vt_out = torch.full((KVH, plan.n_vt_blocks, hd, 64), 3.0, dtype=torch.bfloat16, device=DEV)
+        k_hs, vt_hs = n * hd, plan.n_vt_blocks * hd * 64
+    q_out = torch.zeros(H, n, hd, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(n, qd, dtype=torch.bfloat16, device=DEV)
+    t_ = lambda a: torch.from_numpy(a).to(DEV)
+    args = [t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk), t_(plan.qblk), t_(plan.qblk_len)]
+    qkv_d, cos_d, sin_d = dev_bf16(qkv), t_(cos), t_(sin)
+    L.kr_qkv_prep(ptr(qkv_d), qd + 2 * kd, 0, qd, qd + kd, ptr(cos_d), ptr(sin_d), ptr(args[0]), ptr(args[1]), ptr(args[2]),
+                  ptr(args[3]), len(plan.blk_tok0), ptr(q_out), n * hd, ptr(k_out), k_hs, ptr(vt_out), vt_hs, H, KVH, hd, 0)
+    scale = hd ** -0.5
+    L.kr_attn_varlen(ptr(q_out), ptr(k_out), ptr(vt_out), ptr(o), ptr(args[4]), ptr(args[5]), plan.qblk.shape[0], n, H,
+                     KVH, hd, k_hs, vt_hs, scale, 1 if causal else 0, 0)
+    # ---- reference
+    q = qkv[:, :qd].reshape(n, H, hd)
+    k = qkv[:, qd:qd + kd].reshape(n, KVH, hd)
+    v = qkv[:, qd + kd:].reshape(n, KVH, hd)
+    qr = bf16_round(q * cos[:, None] + O.rotate_half(q) * sin[:, None])
+    kr = bf16_round(k * cos[:, None] + O.rotate_half(k) * sin[:, None])
+    got_q = host(q_out)
+    assert_close_bf16(got_q, qr.transpose(1, 0, 2), abs_=1e-3, what="prep q")
+    ref = np.zeros((n, qd), np.float32)
+    off = 0
+    for s_i, ln in enumerate(lens):
+        sl = slice(off, off + ln)
+        if as_cache:
+            gk = host(k_out)[s_i, :, :ln]
+            gvt = host(vt_out)[s_i]  # [KVH, blocks, hd, 64]
+            gv = gvt.transpose(0, 1, 3, 2).reshape(KVH, -1, hd)[:, :ln]
+            assert not host(vt_out)[s_i].transpose(0, 1, 3, 2).reshape(KVH, -1, hd)[:, ln:((ln + 63) // 64) * 64].any()
+        else:
+            gk = host(k_out)[:, sl]
+            b0 = int(plan.qblk[[i for i in range(len(plan.qblk)) if plan.qblk[i, 0] == off][0], 3])
+            nb = (ln + 63) // 64
+            gv = host(vt_out)[:, b0:b0 + nb].transpose(0, 1, 3, 2).reshape(KVH, -1, hd)
+            assert not gv[:, ln:].any(), "V^T padding must be zero"
+            gv = gv[:, :ln]
+        assert_close_bf16(gk, kr[sl].transpose(1, 0, 2), abs_=1e-3, what="prep k")
+        np.testing.assert_array_equal(gv, v[sl].transpose(1, 0, 2))
+        ref[sl] = np_attention(qr[sl].transpose(1, 0, 2), kr[sl].transpose(1, 0, 2), v[sl].transpose(1, 0, 2), scale, causal)
+        off += ln
+    assert_close_bf16(host(o), ref, rel=2 ** -6, abs_=2e-2, what="attention out")
+
+
+@pytest.mark.parametrize("lens", [[24], [64], [130, 5, 200], [129], [1, 63, 65]])
+def test_vit_attention_hd80(L, lens):
+    run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens))
+
+
+@pytest.mark.parametrize("lens", [[36], [130, 5, 200], [257]])
+@pytest.mark.parametrize("H,KVH", [(2, 1), (6, 2), (3, 3)])
+def test_prefill_attention_hd128_causal_gqa(L, lens, H, KVH):
+    run_prep_attn(L, lens, H=H, KVH=KVH, hd=128, causal=True, seed=sum(lens) + H, as_cache=True, s_max=320)
+
+
+def test_attention_online_softmax_rescale_branch(L):
+    """Force the running max to jump in a late KV tile (cdna_hip_programming.md §5.4 rule 26):
+    one key far down the sequence matches one query strongly."""
+    rng = np.random.default_rng(77)
+    H, hd, n = 1, 80, 300
+    q, k, v = rnd(rng, H, n, hd, scale=0.3), rnd(rng, H, n, hd, scale=0.3), rnd(rng, H, n, hd)
+    k[0, 250] = bf16_round(q[0, 17] * 12)  # spike in tile 3 for query 17
+    k[0, 3] = bf16_round(q[0, 200] * 12)   # and an early spike for a query of the second q-block
+    qd, kd = dev_bf16(q), dev_bf16(k)
+    vt = np.zeros((H, 5, hd, 64), np.float32)
+    vt.reshape(H, 5, hd, 64)
+    vpad = np.concatenate([v, np.zeros((H, 320 - n, hd), np.float32)], 1)
+    vt = vpad.reshape(H, 5, 64, hd).transpose(0, 1, 3, 2)
+    plan = POS.make_attn_plan([n], [0], [0], False)
+    o = torch.zeros(n, hd, dtype=torch.bfloat16, device=DEV)
+    t_ = lambda a: torch.from_numpy(a).to(DEV)
+    qb, ql = t_(plan.qblk), t_(plan.qblk_len)
+    L.kr_attn_varlen(ptr(qd), ptr(kd), ptr(dev_bf16(vt)), ptr(o), ptr(qb), ptr(ql), plan.qblk.shape[0], n, H, H, hd,
+                     n * hd, 5 * hd * 64, 1.0, 0, 0)
+    ref = np_attention(q, k, v, 1.0, False)
+    assert_close_bf16(host(o), ref, rel=2 ** -6, abs_=2e-2, what="rescale branch")
+
+
+# ----------------------------------------------------------------------------- decode path
+@pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4), (3, 1)])
+@pytest.mark.parametrize("ctxs", [[0, 5, 63], [64, 100, 700], [1, 1279, 2047]])
+def test_decode_prep_and_attention(L, H, KVH, ctxs):
+    rng = np.random.default_rng(H * 100 + sum(ctxs))
+    hd, s_max, B, n_split = 128, 2048, len(ctxs), 4
+    kc = np.zeros((B, KVH, s_max, hd), np.float32)
+    vc = np.zeros((B, KVH, s_max, hd), np.float32)
+    for b, c in enumerate(ctxs):
+        kc[b, :, :c] = rnd(rng, KVH, c, hd)
+        vc[b, :, :c] = rnd(rng, KVH, c, hd)
+    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    kc_d, vt_d = dev_bf16(kc), dev_bf16(vt)
+    qkv = rnd(rng, B, (H + 2 * KVH) * hd)
+    delta = np.asarray([-3, 0, -1190][:B], np.int32)
+    inv = POS.rope_inv_freq(hd, 1e6)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    q_d = torch.zeros(B, H, hd, dtype=torch.bfloat16, device=DEV)
+    L.kr_decode_qkv_prep(ptr(dev_bf16(qkv)), ptr(torch.from_numpy(inv).to(DEV)), ptr(ctx_d),
+                         ptr(torch.from_numpy(delta).to(DEV)), ptr(q_d), ptr(kc_d), ptr(vt_d), B, H, KVH, hd, 0, s_max, 0)
+    ws = torch.zeros(B * H * n_split * 4 * (hd + 2), dtype=torch.float32, device=DEV)
+    o_d = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
+    scale = hd ** -0.5
+    L.kr_attn_decode_gqa(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), ptr(o_d), ptr(ws), B, H, KVH, hd, 0, s_max, n_split,
+                         scale, 0)
+    # ---- reference: rope with bf16-rounded cos/sin at position ctx+delta
+    q = qkv[:, :H * hd].reshape(B, H, hd)
+    k = qkv[:, H * hd:(H + KVH) * hd].reshape(B, KVH, hd)
+    v = qkv[:, (H + KVH) * hd:].reshape(B, KVH, hd)
+    got_k, got_vt, got_q, got_o = host(kc_d), host(vt_d), host(q_d), host(o_d)
+    for b, c in enumerate(ctxs):
+        ang = np.float32(c + delta[b]) * inv
+        cos = bf16_round(np.concatenate([np.cos(ang)] * 2).astype(np.float32))
+        sin = bf16_round(np.concatenate([np.sin(ang)] * 2).astype(np.float32))
+        qr = bf16_round(q[b] * cos + O.rotate_half(q[b]) * sin)
+        kr = bf16_round(k[b] * cos + O.rotate_half(k[b]) * sin)
+        assert_close_bf16(got_q[b], qr, abs_=2e-2, what="decode q rope")   # cos/sin may round differently by 1 bf16 ulp
+        assert_close_bf16(got_k[b, :, c], kr, abs_=2e-2, what="decode k append")
+        gv = got_vt[b].transpose(0, 1, 3, 2).reshape(KVH, s_max, hd)
+        np.testing.assert_array_equal(gv[:, c], v[b])
+        np.testing.assert_array_equal(gv[:, :c], vc[b, :, :c])           # earlier columns untouched
+        kk = np.concatenate([kc[b, :, :c], got_k[b, :, c:c + 1]], 1)
+        vv = np.concatenate([vc[b, :, :c], v[b][:, None]], 1)
+        ref = np_attention(got_q[b][:, None], kk, vv, scale, False)
+        assert_close_bf16(got_o[b:b + 1], ref, rel=2 ** -6, abs_=2e-2, what=f"decode attention b={b}")
+
+
+def test_graph_capture_and_replay(L):
+    """A captured kr_* launch replays with device-side state (the decode step pattern)."""
+    stream = torch.cuda.Stream()
+    s = stream.cuda_stream
+    B, V, d = 2, 512, 64
+    rng = np.random.default_rng(5)
+    table = dev_bf16(rnd(rng, V, d))
+    logits = torch.full((B, V), -1.0, device=DEV); logits[0, 7] = 3; logits[1, 9] = 3
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.zeros(8, B, dtype=torch.int32, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV); ctx = torch.zeros(B, dtype=torch.int32, device=DEV)
+    fin = torch.zeros(B, dtype=torch.int32, device=DEV); eos = torch.tensor([1], dtype=torch.int32, device=DEV)
+    xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
+    torch.cuda.synchronize()
+    L.kr_graph_begin_capture(s)
+    L.kr_argmax_embed(ptr(logits), V, V, ptr(table), d, ptr(tok), ptr(hist), ptr(step), ptr(ctx), ptr(fin), ptr(eos), 1, 0, 1,
+                      ptr(xn), B, s)
+    g = C.c_void_p()
+    L.kr_graph_end_capture(s, C.byref(g))
+    for _ in range(5):
+        L.kr_graph_launch(g.value, s)
+    L.kr_stream_synchronize(s)
+    assert int(step.item()) == 5 and ctx.cpu().tolist() == [5, 5]
+    np.testing.assert_array_equal(hist.cpu().numpy()[:5], [[7, 9]] * 5)
+    L.kr_graph_destroy(g.value)
+
+
+def test_events_time_a_kernel(L):
+    stream = torch.cuda.Stream()
+    s = stream.cuda_stream
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
+    x = torch.zeros(4096, 1536, dtype=torch.bfloat16, device=DEV)
+    w = torch.ones(1536, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    L.kr_event_record(e0, s)
+    L.kr_rmsnorm(ptr(x), 1536, ptr(w), ptr(y), 4096, 1536, 1e-6, s)
+    L.kr_event_record(e1, s)
+    L.kr_event_synchronize(e1)
+    ms = C.c_float()
+    L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+    assert 0 < ms.value < 50
+    L.kr_event_destroy(e0); L.kr_event_destroy(e1)
+
+
+def test_rccl_single_rank_broadcast(L):
+    """kr_comm_* + kr_bcast_weights with a 1-rank communicator (the only multi-GPU primitive on the path)."""
+    uid = (C.c_uint8 * 128)()
+    L.kr_comm_unique_id(uid)
+    comm = C.c_void_p()
+    L.kr_comm_init(C.byref(comm), 1, 0, uid)
+    buf = torch.arange(1 << 20, dtype=torch.int32, device=DEV)
+    L.kr_bcast_weights(comm, ptr(buf), buf.numel() * 4, 0, 0)
+    torch.cuda.synchronize()
+    assert int(buf[12345].item()) == 12345
+    L.kr_comm_destroy(comm)

@@ -1,0 +1,172 @@
+"""Host-side product logic (no GPU): image front end, position ids, attention work lists,
+weight packing — checked against the HF golden fixtures and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from karanta_ocr_amd import image_processing as IP
+from karanta_ocr_amd import positions as POS
+from karanta_ocr_amd.config import CONFIGS, QWEN2_VL_2B, QWEN2_VL_7B
+from karanta_ocr_amd.weights import bf16_round, from_bf16_bits, random_weights, to_bf16_bits, weight_shapes
+from oracle import qwen2vl_oracle as O
+
+MODELS = ["tiny", "tiny-gqa"]
+
+
+def test_smart_resize_matches_hf_table(golden):
+    for h, w, mp, eh, ew in golden["smart_resize_table"]:
+        assert IP.smart_resize(int(h), int(w), 28, 3136, int(mp)) == (int(eh), int(ew))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_image_to_patches_matches_hf(golden, tag):
+    pv, grid = IP.image_to_patches(golden[f"pre_img_{tag}"])
+    assert grid == tuple(golden[f"pre_grid_{tag}"][0])
+    np.testing.assert_allclose(pv, golden[f"pre_pv_{tag}"], rtol=0, atol=2e-6)
+
+
+def test_data_url_round_trip():
+    img = IP.synthetic_page(3, 120, 90)
+    url = IP.encode_png_data_url(img)
+    assert url.startswith("data:image/png;base64,")
+    back = np.asarray(IP.decode_data_url(url))
+    np.testing.assert_array_equal(back, img)
+
+
+def test_synthetic_page_is_seeded():
+    a, b = IP.synthetic_page(0, 64, 64), IP.synthetic_page(0, 64, 64)
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, IP.synthetic_page(1, 64, 64))
+    assert a.dtype == np.uint8 and a.shape == (64, 64, 3)
+
+
+def test_bench_grid_sizes():
+    """1024² -> 70x70 patches (grid A) / 74x74 (grid B)."""
+    pv, g = IP.image_to_patches(IP.synthetic_page(0, 1024, 1024))
+    assert g == (1, 70, 70) and pv.shape == (4900, 1176)
+    assert IP.smart_resize(1024, 1024, 28, 3136, IP.MAX_PIXELS_HUB) == (1036, 1036)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_vision_tables(golden, tiny_models, name):
+    cfg, _, P = tiny_models[name]
+    grid = golden[P + "vit_grid"]
+    np.testing.assert_array_equal(POS.vision_position_ids(grid, 2), golden[P + "vit_pos_ids"])
+    cos, sin = POS.vision_rotary_tables(grid, cfg.vision.head_dim, 2)
+    np.testing.assert_allclose(cos, golden[P + "vit_cos"], atol=1e-6)
+    np.testing.assert_allclose(sin, golden[P + "vit_sin"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("tag", ["1img", "2img"])
+def test_rope_index(golden, tiny_models, name, tag):
+    cfg, _, P = tiny_models[name]
+    pos, delta = POS.rope_index_one(golden[P + f"rope_{tag}_ids"][0], golden[P + f"rope_{tag}_grid"], cfg.image_token_id, 2)
+    np.testing.assert_array_equal(pos, golden[P + f"rope_{tag}_pos"][:, 0])
+    assert delta == int(golden[P + f"rope_{tag}_delta"][0])
+
+
+def test_rope_index_errors():
+    with pytest.raises(ValueError, match="do not match"):
+        POS.rope_index_one(np.asarray([1, 9, 9, 9, 2]), [(1, 4, 4)], 9, 2)
+    with pytest.raises(ValueError):
+        POS.rope_index_one(np.asarray([1, 2, 3]), [(1, 4, 4)], 9, 2)
+
+
+def test_rope_index_text_only():
+    pos, delta = POS.rope_index_one(np.arange(7), [], 9999, 2)
+    np.testing.assert_array_equal(pos, np.tile(np.arange(7), (3, 1)))
+    assert delta == 0
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_mrope_tables_match_oracle(golden, tiny_models, name):
+    cfg, _, P = tiny_models[name]
+    pos = golden[P + "mrope_pos"]  # [3,1,7]
+    co, so = O.mrope_cos_sin(pos, cfg.text.head_dim, cfg.text.rope_theta, cfg.text.mrope_section)
+    c, s = POS.mrope_tables(pos[:, 0], cfg.text.head_dim, cfg.text.rope_theta, cfg.text.mrope_section, round_bf16=False)
+    np.testing.assert_array_equal(c, co[0])
+    np.testing.assert_array_equal(s, so[0])
+    cb, _ = POS.mrope_tables(pos[:, 0], cfg.text.head_dim, cfg.text.rope_theta, cfg.text.mrope_section)
+    np.testing.assert_array_equal(cb, bf16_round(c))
+
+
+def test_attn_plan_vit():
+    plan = POS.vit_attn_plan([(1, 4, 6), (1, 14, 14), (1, 2, 2)])  # 24, 196, 4 tokens
+    assert plan.n_tokens == 224 and plan.n_vt_blocks == 1 + 4 + 1
+    np.testing.assert_array_equal(plan.blk_tok0, [0, 24, 88, 152, 216, 220])
+    np.testing.assert_array_equal(plan.blk_ntok, [24, 64, 64, 64, 4, 4])
+    np.testing.assert_array_equal(plan.blk_vt_blk, [0, 1, 2, 3, 4, 5])
+    np.testing.assert_array_equal(plan.blk_k_row0, [0, 24, 88, 152, 216, 220])
+    # q blocks of <=128 rows: (24), (128, 68), (4)
+    np.testing.assert_array_equal(plan.qblk[:, 0], [0, 24, 152, 220])
+    np.testing.assert_array_equal(plan.qblk[:, 1], [24, 128, 68, 4])
+    np.testing.assert_array_equal(plan.qblk[:, 2], [0, 24, 24, 220])
+    np.testing.assert_array_equal(plan.qblk[:, 3], [0, 1, 1, 5])
+    np.testing.assert_array_equal(plan.qblk_len, [[24, 0], [196, 0], [196, 128], [4, 0]])
+
+
+def test_attn_plan_prefill():
+    plan = POS.prefill_attn_plan([130, 5], [0, 1], kv_heads=2, s_max=256)
+    np.testing.assert_array_equal(plan.blk_k_row0, [0, 64, 128, 512])
+    np.testing.assert_array_equal(plan.blk_vt_blk, [0, 1, 2, 8])
+    np.testing.assert_array_equal(plan.qblk[:, 2], [0, 0, 512])
+    np.testing.assert_array_equal(plan.qblk_len, [[130, 0], [130, 128], [5, 0]])
+
+
+def test_bf16_helpers():
+    x = np.asarray([1.0, 1.00390625, 1.005859375, -3.1415927, 1e-40, 65504.0, np.inf], np.float32)
+    bits = to_bf16_bits(x)
+    back = from_bf16_bits(bits)
+    np.testing.assert_array_equal(back, bf16_round(x))
+    t = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(back, t)  # same rounding as torch (RNE)
+
+
+def test_random_weights_are_deterministic_and_bf16():
+    cfg = CONFIGS["tiny"]
+    a, b = random_weights(cfg, 7), random_weights(cfg, 7)
+    assert set(a) == set(weight_shapes(cfg))
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+        np.testing.assert_array_equal(a[k], bf16_round(a[k]))
+    bits = random_weights(cfg, 7, as_bits=True)
+    k = "model.language_model.layers.0.mlp.down_proj.weight"
+    np.testing.assert_array_equal(from_bf16_bits(bits[k]), a[k])
+
+
+def test_decoder_weight_bytes_match_survey():
+    assert QWEN2_VL_2B.decoder_weight_bytes() == 3_087_428_608
+    assert QWEN2_VL_7B.decoder_weight_bytes() == 14_141_238_272
+    assert QWEN2_VL_2B.text.kv_bytes_per_token == 28_672
+    assert QWEN2_VL_7B.text.kv_bytes_per_token == 57_344
+
+
+def test_weight_arena_packing_on_cpu():
+    """Fused qkv, 16-row gate/up interleave and the K-padded patch embed, checked without a GPU."""
+    from karanta_ocr_amd.engine import DeviceWeights
+
+    cfg = CONFIGS["tiny-gqa"]
+    w = random_weights(cfg, 11)
+    dw = DeviceWeights(cfg, torch.device("cpu"))
+    dw.arena = torch.zeros(dw.nbytes, dtype=torch.uint8)
+    dw.load.__func__  # exists
+    # load() ends with a cuda synchronize; replicate its body on CPU through _put-level checks
+    import unittest.mock as mock
+    with mock.patch("torch.cuda.synchronize"):
+        dw.load(w)
+    t = cfg.text
+    gu = dw.view("llm.1.gate_up.w").float().numpy()
+    g, u = w["model.language_model.layers.1.mlp.gate_proj.weight"], w["model.language_model.layers.1.mlp.up_proj.weight"]
+    np.testing.assert_array_equal(gu[0:16], g[0:16])
+    np.testing.assert_array_equal(gu[16:32], u[0:16])
+    np.testing.assert_array_equal(gu[32:48], g[16:32])
+    qkv = dw.view("llm.0.qkv.w").float().numpy()
+    np.testing.assert_array_equal(qkv[: t.q_dim], w["model.language_model.layers.0.self_attn.q_proj.weight"])
+    np.testing.assert_array_equal(qkv[t.q_dim + t.kv_dim:], w["model.language_model.layers.0.self_attn.v_proj.weight"])
+    pe = dw.view("vit.patch").float().numpy()
+    assert pe.shape == (cfg.vision.embed_dim, 1216)
+    np.testing.assert_array_equal(pe[:, :1176], w["model.visual.patch_embed.proj.weight"].reshape(cfg.vision.embed_dim, -1))
+    assert not pe[:, 1176:].any()
+    # tied lm_head aliases the embedding table
+    assert dw.view("llm.lm_head").data_ptr() == dw.view("llm.embed").data_ptr()
