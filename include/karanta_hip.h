@@ -191,14 +191,14 @@ int kr_attn_decode_gqa(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* v
 
 /* Greedy sampling (`generate(do_sample=False)`, reference test_trained_model.py:91): argmax of
  * fp32 logits [batch, vocab] (lowest index wins ties), token written to tokens_out[b] and to
- * history[step_ptr[0]*batch + b]; the token's embedding row is gathered into x_next [batch, d];
+ * history[step_ptr[0]*hist_stride + b]; the token's embedding row is gathered into x_next [batch, d];
  * ctx_len[b] += 1; step_ptr[0] += 1 (by a trailing 1-thread kernel).  Sequences with finished[b] != 0 emit pad_id; a
  * sequence becomes finished when it emits one of eos[0..n_eos).  */
 int kr_argmax_embed(const float* logits, int64_t ld_logits, int vocab,
                     const kr_bf16* embed_table, int d,
                     int32_t* tokens_out, int32_t* history, int32_t* step_ptr, int32_t* ctx_len,
                     int32_t* finished, const int32_t* eos, int n_eos, int pad_id, int ignore_eos,
-                    kr_bf16* x_next, int batch, kr_stream s);
+                    kr_bf16* x_next, int batch, int hist_stride, kr_stream s);
 
 /* Plain argmax (SURVEY §8 b2 `kr_argmax`). */
 int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, int batch, kr_stream s);

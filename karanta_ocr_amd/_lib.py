@@ -52,7 +52,7 @@ SIGNATURES = {
     "kr_kv_append": [c_p, c_p, i64, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p],
     "kr_decode_qkv_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p],
     "kr_attn_decode_gqa": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
-    "kr_argmax_embed": [c_p, i64, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
+    "kr_argmax_embed": [c_p, i64, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, i32, c_p],
     "kr_argmax": [c_p, i64, i32, c_p, i32, c_p],
     "kr_comm_unique_id": [c_p],
     "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],

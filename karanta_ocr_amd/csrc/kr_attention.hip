@@ -104,15 +104,10 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
     // ---- V: [64 tok][HD] -> LDS transposed -> V^T block [HD][64], zero padded past ntok
     for (int e = threadIdx.x; e < 64 * (HD / 8); e += 256) {
         const int j = e / (HD / 8), c = e - j * (HD / 8);
-        bf16x8 v;
-        if (j < ntok) {
-            v = ld8(qkv + (int64_t)(tok0 + j) * ld_qkv + v_off + head * HD + c * 8);
-        } else {
+        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+        if (j < ntok) v = *reinterpret_cast<const u32x4*>(qkv + (int64_t)(tok0 + j) * ld_qkv + v_off + head * HD + c * 8);
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) v[jj] = f2bf(0.f);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) vt_s[c * 8 + jj][j] = __builtin_bit_cast(kr_bf16, v[jj]);
+        for (int jj = 0; jj < 8; ++jj) vt_s[c * 8 + jj][j] = (kr_bf16)((v[jj >> 1] >> ((jj & 1) * 16)) & 0xffffu);
     }
     __syncthreads();
     kr_bf16* vt = vt_out + (int64_t)head * vt_head_stride + blk_vt_blk[i] * (int64_t)(HD * 64);

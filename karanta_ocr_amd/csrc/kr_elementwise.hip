@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(1024) argmax_embed_kernel(const float* __restr
                                                             int32_t* __restrict__ step_ptr, int32_t* __restrict__ ctx_len,
                                                             int32_t* __restrict__ finished, const int32_t* __restrict__ eos,
                                                             int n_eos, int pad_id, int ignore_eos,
-                                                            kr_bf16* __restrict__ x_next, int batch) {
+                                                            kr_bf16* __restrict__ x_next, int hist_stride) {
     const int b = blockIdx.x;
     float bv;
     int tok;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) argmax_embed_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         tokens_out[b] = tok;
-        history[(int64_t)step * batch + b] = tok;
+        history[(int64_t)step * hist_stride + b] = tok;
         ctx_len[b] += 1;
         if (!ignore_eos && !was_finished) {
             int hit = 0;
@@ -262,13 +262,14 @@ __global__ void bump_kernel(int32_t* p) { p[0] += 1; }
 extern "C" int kr_argmax_embed(const float* logits, int64_t ld_logits, int vocab, const kr_bf16* embed_table, int d,
                                int32_t* tokens_out, int32_t* history, int32_t* step_ptr, int32_t* ctx_len,
                                int32_t* finished, const int32_t* eos, int n_eos, int pad_id, int ignore_eos,
-                               kr_bf16* x_next, int batch, kr_stream s) {
+                               kr_bf16* x_next, int batch, int hist_stride, kr_stream s) {
     KR_CHECK_ARG(logits && embed_table && tokens_out && history && step_ptr && ctx_len && finished && x_next &&
-                     vocab > 0 && batch > 0 && (d & 7) == 0 && ld_logits >= vocab && (n_eos == 0 || eos),
+                     vocab > 0 && batch > 0 && hist_stride >= batch && (d & 7) == 0 && ld_logits >= vocab &&
+                     (n_eos == 0 || eos),
                  "kr_argmax_embed: bad args");
     argmax_embed_kernel<<<batch, 1024, 0, kr_hs(s)>>>(logits, ld_logits, vocab, embed_table, d, tokens_out, history,
                                                        step_ptr, ctx_len, finished, eos, n_eos, pad_id, ignore_eos,
-                                                       x_next, batch);
+                                                       x_next, hist_stride);
     KR_CHECK_LAUNCH();
     bump_kernel<<<1, 1, 0, kr_hs(s)>>>(step_ptr);
     KR_CHECK_LAUNCH();

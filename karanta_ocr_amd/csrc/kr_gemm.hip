@@ -411,8 +411,8 @@ extern "C" int kr_gemv_bf16(const kr_bf16* x, int64_t ldx, const kr_bf16* W, con
     KR_CHECK_ARG(K > 0 && K % 64 == 0, "kr_gemv_bf16: K=%d must be a multiple of 64", K);
     KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && (ldc & 3) == 0, "kr_gemv_bf16: ldx/ldc");
     KR_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0, "kr_gemv_bf16: pointer alignment");
-    const bool xlds = (size_t)M * (K * 2 + 16) <= 96 * 1024;
-    KR_CHECK_ARG(!norm_w || xlds, "kr_gemv_bf16: fused RMSNorm needs M*K <= 48K elements (M=%d K=%d)", M, K);
+    const bool xlds = (size_t)M * (K * 2 + 16) <= 148 * 1024;
+    KR_CHECK_ARG(!norm_w || xlds, "kr_gemv_bf16: fused RMSNorm needs M*(2K+16) <= 148 KiB of LDS (M=%d K=%d)", M, K);
     if (epilogue == KR_EPI_SILU_MUL) {
         KR_CHECK_ARG(N % 32 == 0 && !bias && !residual && out && !out_f32 && ldc >= N / 2, "kr_gemv_bf16: SILU_MUL args");
         return xlds ? launch_gemv<2, KR_EPI_SILU_MUL, true, false>(x, ldx, W, bias, residual, ldr, out, out_f32, ldc, M, N,

@@ -187,6 +187,10 @@ class Engine:
             raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
         self.w = DeviceWeights(cfg, self.device)
         self._graphs: Dict[Tuple[int, bool], int] = {}
+        self._prof_on = False
+        self._prof_events: List[Tuple[C.c_void_p, C.c_void_p]] = []
+        self._prof_next = 0
+        self._last_batch = max_batch
         self._alloc()
 
     # ------------------------------------------------------------------ buffers
@@ -207,8 +211,7 @@ class Engine:
         self.v_o = z(N, v.embed_dim)
         self.v_f = z(N, v.mlp_dim)
         self.v_m1 = z(N // 4 + 1, v.merge_dim)
-        self.v_cos = z(N, v.head_dim, dtype=torch.float32)
-        self.v_sin = z(N, v.head_dim, dtype=torch.float32)
+        self._vit_cache = {}
         self.img_embeds = z(N // 4 + 1, t.hidden_size)
         # decoder prefill
         self.p_x = z(M, t.hidden_size)
@@ -264,28 +267,45 @@ class Engine:
         dst.view(-1)[:src.numel()].copy_(src.view(-1), non_blocking=False)
 
     # ------------------------------------------------------------------ vision tower
-    def vit_forward(self, pixel_values: np.ndarray, grids: Sequence[Sequence[int]]) -> torch.Tensor:
-        """Qwen2VisionTransformerPretrainedModel.forward (TF:700-731).  Returns a view of the merged
-        image embeddings ``[T, d]`` (bf16, device)."""
+    def _vit_tables(self, grids):
+        """Rotary tables and attention work lists depend only on the image grids: build once per
+        distinct batch geometry and keep them resident in HBM."""
+        key = tuple(tuple(int(x) for x in g) for g in grids)
+        hit = self._vit_cache.get(key)
+        if hit is None:
+            v, dev = self.cfg.vision, self.device
+            plan = POS.vit_attn_plan(key)
+            cos, sin = POS.vision_rotary_tables(key, v.head_dim, v.spatial_merge_size)
+            t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            hit = (plan, t_(cos), t_(sin), t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0),
+                   t_(plan.blk_vt_blk), t_(plan.qblk), t_(plan.qblk_len))
+            if len(self._vit_cache) > 16:
+                self._vit_cache.clear()
+            self._vit_cache[key] = hit
+        return hit
+
+    def vit_forward(self, pixel_values, grids: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Qwen2VisionTransformerPretrainedModel.forward (TF:700-731).  ``pixel_values`` is fp32
+        ``[n, 1176]`` — a numpy array (copied to the device here) or a torch tensor already resident
+        in HBM.  Returns a view of the merged image embeddings ``[T, d]`` (bf16, device)."""
         v, L, s, w = self.cfg.vision, self.L, self.s, self.w
         n = int(pixel_values.shape[0])
         if n == 0:
             return self.img_embeds[:0]
         if n > self.max_patches:
             raise KarantaHipError(f"{n} patches > max_patches {self.max_patches}")
-        plan = POS.vit_attn_plan(grids)
-        assert plan.n_tokens == n, (plan.n_tokens, n)
-        cos, sin = POS.vision_rotary_tables(grids, v.head_dim, v.spatial_merge_size)
-        dev = self.device
         with torch.cuda.stream(self.stream):
-            self._h2d(self.v_pix, pixel_values.astype(np.float32, copy=False))
-            self._h2d(self.v_cos, cos)
-            self._h2d(self.v_sin, sin)
-            t_ = lambda a: torch.from_numpy(a).to(dev)
-            blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
-            qblk, qlen = t_(plan.qblk), t_(plan.qblk_len)
+            plan, cos_d, sin_d, blk_tok0, blk_ntok, blk_kr, blk_vb, qblk, qlen = self._vit_tables(grids)
+            assert plan.n_tokens == n, (plan.n_tokens, n)
+            if isinstance(pixel_values, torch.Tensor):
+                pix = pixel_values
+                if pix.dtype != torch.float32 or not pix.is_cuda or not pix.is_contiguous():
+                    raise KarantaHipError("device pixel_values must be a contiguous fp32 CUDA tensor")
+            else:
+                self._h2d(self.v_pix, np.asarray(pixel_values, dtype=np.float32))
+                pix = self.v_pix
             D, H, hd = v.embed_dim, v.num_heads, v.head_dim
-            L.kr_cast_pad_f32_bf16(ptr(self.v_pix), ptr(self.v_in), n, v.patch_dim, v.patch_dim_padded, s)
+            L.kr_cast_pad_f32_bf16(ptr(pix), ptr(self.v_in), n, v.patch_dim, v.patch_dim_padded, s)
             self._gemm(self.v_in, w.view("vit.patch"), self.v_x, n)
             nvb_total = self.v_vt.shape[1]
             if plan.n_vt_blocks > nvb_total:
@@ -294,7 +314,7 @@ class Engine:
                 p = f"vit.{i}."
                 L.kr_layernorm(ptr(self.v_x), ptr(w.view(p + "ln1.w")), ptr(w.view(p + "ln1.b")), ptr(self.v_h), n, D, 1e-6, s)
                 self._gemm(self.v_h, w.view(p + "qkv.w"), self.v_qkv, n, bias=w.view(p + "qkv.b"))
-                L.kr_qkv_prep(ptr(self.v_qkv), 3 * D, 0, D, 2 * D, ptr(self.v_cos), ptr(self.v_sin),
+                L.kr_qkv_prep(ptr(self.v_qkv), 3 * D, 0, D, 2 * D, ptr(cos_d), ptr(sin_d),
                               ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
                               ptr(self.v_q), self.v_q.stride(0), ptr(self.v_k), self.v_k.stride(0),
                               ptr(self.v_vt), self.v_vt.stride(0), H, H, hd, s)
@@ -396,7 +416,7 @@ class Engine:
         L.kr_argmax_embed(ptr(self.d_logits), self.d_logits.stride(0), t.vocab_size, ptr(w.view("llm.embed")),
                           t.hidden_size, ptr(self.d_tok), ptr(self.d_hist), ptr(self.d_step), ptr(self.d_ctx),
                           ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
-                          1 if self._ignore_eos else 0, ptr(self.d_x), B, s)
+                          1 if self._ignore_eos else 0, ptr(self.d_x), B, self.d_hist.stride(0), s)
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
@@ -413,9 +433,43 @@ class Engine:
             L.kr_attn_decode_gqa(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o),
                                  ptr(self.d_ws), B, H, KVH, hd, 0, self.s_max, self.n_split, hd ** -0.5, s)
             self._gemv(self.d_o, w.view(p + "o.w"), self.d_x, B, res=self.d_x)
+            if self._prof_on:
+                e0, e1 = self._prof_event_pair()
+                L.kr_event_record(e0, s)
             self._gemv(self.d_x, w.view(p + "gate_up.w"), self.d_act, B, epi=EPI_SILU_MUL, norm_w=w.view(p + "ln2.w"))
+            if self._prof_on:
+                L.kr_event_record(e1, s)
             self._gemv(self.d_act, w.view(p + "down.w"), self.d_x, B, res=self.d_x)
         self._lm_head_and_sample(B)
+
+    # ------------------------------------------------------------------ live kernel timing (bench.py roofline)
+    def _prof_event_pair(self):
+        if self._prof_next == len(self._prof_events):
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            self.L.kr_event_create(C.byref(e0))
+            self.L.kr_event_create(C.byref(e1))
+            self._prof_events.append((e0, e1))
+        pair = self._prof_events[self._prof_next]
+        self._prof_next += 1
+        return pair
+
+    def kernel_profile(self, reset: bool = True) -> Dict[str, float]:
+        """Durations of the decode gate/up GEMV (`gemv_kernel<2, SILU_MUL, ...>`, the kernel that moves
+        half of the decoder's bytes) measured with HIP events on the launch stream during the profiled
+        eager steps.  Returns {launches, avg_us, min_us, bytes_per_launch}."""
+        self.stream.synchronize()
+        ms = C.c_float()
+        vals = []
+        for e0, e1 in self._prof_events[: self._prof_next]:
+            self.L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+            vals.append(ms.value * 1e3)
+        if reset:
+            self._prof_next = 0
+        t = self.cfg.text
+        B = self._last_batch
+        nbytes = 2 * (2 * t.intermediate_size * t.hidden_size + t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
+        return {"launches": len(vals), "avg_us": float(np.mean(vals)) if vals else 0.0,
+                "min_us": float(np.min(vals)) if vals else 0.0, "bytes_per_launch": nbytes}
 
     def _graph_for(self, B: int) -> int:
         key = (B, self._ignore_eos)
@@ -434,9 +488,14 @@ class Engine:
 
     # ------------------------------------------------------------------ public API
     def generate(self, pages: Sequence[PageRequest], max_new_tokens: int, ignore_eos: bool = False,
-                 use_graph: bool = True, return_logits: bool = False, sync_every: int = 32) -> GenerateResult:
+                 use_graph: bool = True, return_logits: bool = False, sync_every: int = 32,
+                 pixel_values_device: Optional[torch.Tensor] = None, profile_every: int = 0) -> GenerateResult:
         """Greedy generation for a static batch of pages (temperature 0 — the reference's
-        ``build_page_query`` default, /root/reference/karanta/pipeline.py:166-171)."""
+        ``build_page_query`` default, /root/reference/karanta/pipeline.py:166-171).
+
+        ``pixel_values_device``: all pages' patches already resident in HBM (fp32 ``[n, 1176]``), used
+        instead of the per-page host arrays.  ``profile_every`` > 0: every that many decode steps one
+        step runs eagerly with HIP events around the dominant kernel (see :meth:`kernel_profile`)."""
         B = len(pages)
         if not 1 <= B <= self.B:
             raise KarantaHipError(f"batch {B} not in 1..{self.B}")
@@ -444,6 +503,7 @@ class Engine:
             raise ValueError("max_new_tokens must be >= 1")
         t0 = time.perf_counter()
         self._ignore_eos = bool(ignore_eos)
+        self._last_batch = B
         if self.d_hist is None or self.max_new < max_new_tokens:
             self.max_new = max_new_tokens
             self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
@@ -451,12 +511,14 @@ class Engine:
             for g in self._graphs.values():
                 self.L.kr_graph_destroy(g)
             self._graphs.clear()
-        pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
         grids = [g for p in pages for g in p.grids]
         n_img_tok = 0
-        if pvs:
-            emb = self.vit_forward(np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0], grids)
-            n_img_tok = emb.shape[0]
+        if pixel_values_device is not None:
+            n_img_tok = self.vit_forward(pixel_values_device, grids).shape[0]
+        else:
+            pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
+            if pvs:
+                n_img_tok = self.vit_forward(np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0], grids).shape[0]
         self.stream.synchronize()
         t1 = time.perf_counter()
         lens = self.prefill(pages, n_img_tok)
@@ -471,7 +533,11 @@ class Engine:
             want_graph = use_graph and not return_logits
             graph = self._graphs.get((B, self._ignore_eos)) if want_graph else None
             while steps_done < max_new_tokens:
-                if graph is not None:
+                if graph is not None and profile_every and steps_done % profile_every == 0:
+                    self._prof_on = True
+                    self._decode_step_launches(B)
+                    self._prof_on = False
+                elif graph is not None:
                     self.L.kr_graph_launch(graph, self.s)
                 else:
                     # eager step; the first one also sets per-kernel attributes, so capture only

@@ -102,7 +102,10 @@ def quick_gelu(x: np.ndarray) -> np.ndarray:
 def gelu_erf(x: np.ndarray) -> np.ndarray:
     """Exact GELU of the PatchMerger MLP (``nn.GELU()``, TF:modeling_qwen2_vl.py:277-290)."""
     x = x.astype(np.float64)
-    erf = np.vectorize(math.erf, otypes=[np.float64])
+    try:  # scipy's vectorised erf when present (same values; ~100x faster than math.erf per element)
+        from scipy.special import erf
+    except Exception:  # pragma: no cover
+        erf = np.vectorize(math.erf, otypes=[np.float64])
     return (0.5 * x * (1.0 + erf(x / math.sqrt(2.0)))).astype(F32)
 
 
@@ -319,9 +322,10 @@ def vit_forward(pixel_values: np.ndarray, grid_thw: Sequence[Sequence[int]], wei
         o = np.zeros((n, H, hd), dtype=F32)
         for s in range(len(seg) - 1):
             a, b = seg[s], seg[s + 1]
-            sc = np.einsum("qhd,khd->hqk", q[a:b], k[a:b]).astype(F32) * scale
+            qh, kh, vh = (np.ascontiguousarray(t[a:b].transpose(1, 0, 2)) for t in (q, k, v))  # [H,n,hd]
+            sc = np.matmul(qh, kh.transpose(0, 2, 1)).astype(F32) * scale
             pr = pol(softmax_lastdim(sc))  # softmax fp32, cast to activation dtype (:334)
-            o[a:b] = np.einsum("hqk,khd->qhd", pr, v[a:b])
+            o[a:b] = np.matmul(pr, vh).transpose(1, 0, 2)
         o = pol(o.reshape(n, D))
         x = pol(x + linear(o, _w(weights, p + "attn.proj.weight"), _w(weights, p + "attn.proj.bias")))
         h2 = pol(layer_norm(x, _w(weights, p + "norm2.weight"), _w(weights, p + "norm2.bias")))
@@ -391,7 +395,7 @@ def decoder_layer(x: np.ndarray, li: int, weights, tcfg, cos, sin, cache: KVCach
     g = H // KVH
     kk_r = np.repeat(kk, g, axis=1)
     vv_r = np.repeat(vv, g, axis=1)
-    sc = np.einsum("bhqd,bhkd->bhqk", q, kk_r).astype(F32) * F32(hd ** -0.5)
+    sc = np.matmul(q, kk_r.transpose(0, 1, 3, 2)).astype(F32) * F32(hd ** -0.5)
     qi = np.arange(S)[:, None] + past
     ki = np.arange(St)[None, :]
     mask = ki <= qi  # causal
@@ -399,7 +403,7 @@ def decoder_layer(x: np.ndarray, li: int, weights, tcfg, cos, sin, cache: KVCach
         mask = mask[None, None] & attn_valid[:, None, None, :]
     sc = np.where(mask, sc, np.finfo(F32).min)  # HF masks with finfo.min, not -inf
     pr = pol(softmax_lastdim(sc))
-    o = np.einsum("bhqk,bhkd->bhqd", pr, vv_r).astype(F32)
+    o = np.matmul(pr, vv_r).astype(F32)
     o = pol(o.transpose(0, 2, 1, 3).reshape(B, S, H * hd))
     x = pol(x + linear(o, _w(weights, p + "self_attn.o_proj.weight")))
     h2 = pol(rms_norm(x, _w(weights, p + "post_attention_layernorm.weight"), tcfg.rms_norm_eps, pol))

@@ -85,7 +85,8 @@ def test_layernorm(L, d, rows):
     x, w, b = rnd(rng, rows, d, scale=2.0) + 0.5, rnd(rng, d) + 1, rnd(rng, d, scale=0.1)
     x = bf16_round(x)
     y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
-    L.kr_layernorm(ptr(dev_bf16(x)), ptr(dev_bf16(w)), ptr(dev_bf16(b)), ptr(y), rows, d, 1e-6, 0)
+    xd, wd, bd = dev_bf16(x), dev_bf16(w), dev_bf16(b)  # keep alive: ptr() of a temporary dangles
+    L.kr_layernorm(ptr(xd), ptr(wd), ptr(bd), ptr(y), rows, d, 1e-6, 0)
     ref = O.layer_norm(x, bf16_round(w), bf16_round(b), 1e-6)
     assert_close_bf16(host(y), ref, what="layernorm")
 
@@ -97,7 +98,8 @@ def test_rmsnorm_matches_oracle_bit_exact_policy(L, d):
     x, w = rnd(rng, rows, d, scale=3.0), bf16_round(rnd(rng, d) * 0.1 + 1)
     big = dev_bf16(np.concatenate([x, np.zeros((rows, 8), np.float32)], 1))  # row stride d+8
     y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
-    L.kr_rmsnorm(ptr(big), d + 8, ptr(dev_bf16(w)), ptr(y), rows, d, 1e-6, 0)
+    wd = dev_bf16(w)
+    L.kr_rmsnorm(ptr(big), d + 8, ptr(wd), ptr(y), rows, d, 1e-6, 0)
     ref = bf16_round(O.rms_norm(x, w, 1e-6, O._Policy("bf16")))
     got = host(y)
     # identical rounding points; rsqrt / summation order may move a value by one bf16 ulp
@@ -110,7 +112,8 @@ def test_embed_scatter(L):
     table, img = rnd(rng, 50, 64), rnd(rng, 6, 64)
     src = np.asarray([3, -1, -2, 49, 0, -6, 7], np.int32)
     out = torch.empty(len(src), 64, dtype=torch.bfloat16, device=DEV)
-    L.kr_embed_scatter(ptr(torch.from_numpy(src).to(DEV)), ptr(dev_bf16(table)), ptr(dev_bf16(img)), ptr(out), len(src), 64, 0)
+    sd, td, idv = torch.from_numpy(src).to(DEV), dev_bf16(table), dev_bf16(img)
+    L.kr_embed_scatter(ptr(sd), ptr(td), ptr(idv), ptr(out), len(src), 64, 0)
     ref = np.stack([table[i] if i >= 0 else img[-i - 1] for i in src])
     np.testing.assert_array_equal(host(out), ref)
 
@@ -125,7 +128,8 @@ def test_argmax_lowest_index_wins_ties(L):
     x[3] = -np.inf
     x[3, 77777] = -1e30
     out = torch.zeros(5, dtype=torch.int32, device=DEV)
-    L.kr_argmax(ptr(torch.from_numpy(x).to(DEV)), v, v, ptr(out), 5, 0)
+    xd = torch.from_numpy(x).to(DEV)
+    L.kr_argmax(ptr(xd), v, v, ptr(out), 5, 0)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), x.argmax(1))
 
@@ -147,7 +151,7 @@ def test_argmax_embed_state_machine(L):
     xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
     for _ in range(2):
         L.kr_argmax_embed(ptr(dl), V, V, ptr(dt), d, ptr(tok), ptr(hist), ptr(step), ptr(ctx), ptr(fin), ptr(eos), 2,
-                          496, 0, ptr(xn), B, 0)
+                          496, 0, ptr(xn), B, B, 0)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(hist.cpu().numpy()[:2], [[11, 497, 300], [11, 496, 300]])  # pad after EOS
     np.testing.assert_array_equal(fin.cpu().numpy(), [0, 1, 0])
@@ -234,7 +238,8 @@ def test_gemm_in_place_residual(L):
     M, N, K = 130, 256, 128
     A, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
     Xd = dev_bf16(X)
-    L.kr_gemm_bf16(ptr(dev_bf16(A)), K, ptr(dev_bf16(W)), 0, ptr(Xd), N, ptr(Xd), N, M, N, K, EPI_NONE, 0)
+    Ad, Wd = dev_bf16(A), dev_bf16(W)
+    L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, ptr(Xd), N, ptr(Xd), N, M, N, K, EPI_NONE, 0)
     assert_close_bf16(host(Xd), ref_linear(A, W, res=X), what="in-place residual")
 
 
@@ -327,7 +332,8 @@ def test_gemv_in_place_residual(L):
     M, N, K = 8, 256, 512
     a, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
     Xd = dev_bf16(X)
-    L.kr_gemv_bf16(ptr(dev_bf16(a)), K, ptr(dev_bf16(W)), 0, ptr(Xd), N, ptr(Xd), 0, N, M, N, K, EPI_NONE, 0, 0.0, 0)
+    ad, Wd = dev_bf16(a), dev_bf16(W)
+    L.kr_gemv_bf16(ptr(ad), K, ptr(Wd), 0, ptr(Xd), N, ptr(Xd), 0, N, M, N, K, EPI_NONE, 0, 0.0, 0)
     assert_close_bf16(host(Xd), ref_linear(a, W, res=X), what="gemv in-place")
 
 
@@ -342,7 +348,8 @@ def test_rope_inplace(L, hd):
     sin = np.concatenate([np.sin(ang), np.sin(ang)], -1).astype(np.float32)
     xd = dev_bf16(x.reshape(n, H * hd))
     fn = L.kr_rope2d_vision if hd == 80 else L.kr_mrope
-    fn(ptr(xd), ptr(torch.from_numpy(cos).to(DEV)), ptr(torch.from_numpy(sin).to(DEV)), n, H, hd, H * hd, 0)
+    cd, sd = torch.from_numpy(cos).to(DEV), torch.from_numpy(sin).to(DEV)
+    fn(ptr(xd), ptr(cd), ptr(sd), n, H, hd, H * hd, 0)
     ref = x * cos[:, None] + O.rotate_half(x) * sin[:, None]
     assert_close_bf16(host(xd).reshape(n, H, hd), ref, abs_=1e-3, what="rope")
 
@@ -456,7 +463,8 @@ def test_attention_online_softmax_rescale_branch(L):
     o = torch.zeros(n, hd, dtype=torch.bfloat16, device=DEV)
     t_ = lambda a: torch.from_numpy(a).to(DEV)
     qb, ql = t_(plan.qblk), t_(plan.qblk_len)
-    L.kr_attn_varlen(ptr(qd), ptr(kd), ptr(dev_bf16(vt)), ptr(o), ptr(qb), ptr(ql), plan.qblk.shape[0], n, H, H, hd,
+    vtd = dev_bf16(vt)
+    L.kr_attn_varlen(ptr(qd), ptr(kd), ptr(vtd), ptr(o), ptr(qb), ptr(ql), plan.qblk.shape[0], n, H, H, hd,
                      n * hd, 5 * hd * 64, 1.0, 0, 0)
     ref = np_attention(q, k, v, 1.0, False)
     assert_close_bf16(host(o), ref, rel=2 ** -6, abs_=2e-2, what="rescale branch")
@@ -480,8 +488,9 @@ def test_decode_prep_and_attention(L, H, KVH, ctxs):
     inv = POS.rope_inv_freq(hd, 1e6)
     ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
     q_d = torch.zeros(B, H, hd, dtype=torch.bfloat16, device=DEV)
-    L.kr_decode_qkv_prep(ptr(dev_bf16(qkv)), ptr(torch.from_numpy(inv).to(DEV)), ptr(ctx_d),
-                         ptr(torch.from_numpy(delta).to(DEV)), ptr(q_d), ptr(kc_d), ptr(vt_d), B, H, KVH, hd, 0, s_max, 0)
+    qkv_d, inv_d, delta_d = dev_bf16(qkv), torch.from_numpy(inv).to(DEV), torch.from_numpy(delta).to(DEV)
+    L.kr_decode_qkv_prep(ptr(qkv_d), ptr(inv_d), ptr(ctx_d),
+                         ptr(delta_d), ptr(q_d), ptr(kc_d), ptr(vt_d), B, H, KVH, hd, 0, s_max, 0)
     ws = torch.zeros(B * H * n_split * 4 * (hd + 2), dtype=torch.float32, device=DEV)
     o_d = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
     scale = hd ** -0.5
@@ -524,7 +533,7 @@ def test_graph_capture_and_replay(L):
     torch.cuda.synchronize()
     L.kr_graph_begin_capture(s)
     L.kr_argmax_embed(ptr(logits), V, V, ptr(table), d, ptr(tok), ptr(hist), ptr(step), ptr(ctx), ptr(fin), ptr(eos), 1, 0, 1,
-                      ptr(xn), B, s)
+                      ptr(xn), B, B, s)
     g = C.c_void_p()
     L.kr_graph_end_capture(s, C.byref(g))
     for _ in range(5):
