@@ -93,11 +93,13 @@ int kr_rmsnorm(const kr_bf16* x, int64_t ldx, const kr_bf16* w, kr_bf16* y,
  * native [out,in] layout.  bf16 in, fp32 MFMA accumulate, bf16 out.  K % 64 == 0.
  * bias / residual may be NULL.  With KR_EPI_SILU_MUL, W holds gate/up rows interleaved in groups
  * of 16 (g0..g15,u0..u15,g16..), N counts both, C is [M, N/2] and N % 32 == 0.
- * lda / ldc / ldr are row strides in elements.  Used for every ViT Linear, the merger, and every
- * decoder Linear at prefill. */
+ * lda / ldc / ldr are row strides in elements.  w_packed != 0: W is stored in the decode layout
+ * [N/16][K/64][16][64] (see kr_linear_decode) instead of row-major — one copy of the decoder
+ * weights serves prefill and decode.  Used for every ViT Linear, the merger, and every decoder
+ * Linear at prefill. */
 int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
                  const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc,
-                 int64_t M, int N, int K, int epilogue, kr_stream s);
+                 int64_t M, int N, int K, int epilogue, int w_packed, kr_stream s);
 
 /* Decode-time Linear for M <= 16 rows (one row per live sequence): the weight matrix is streamed
  * exactly once from HBM (this is the HBM-roofline kernel of the decode loop).
@@ -202,6 +204,51 @@ int kr_argmax_embed(const float* logits, int64_t ld_logits, int vocab,
 
 /* Plain argmax (SURVEY §8 b2 `kr_argmax`). */
 int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, int batch, kr_stream s);
+
+/* ------------------------------------------------------------------ fused decode step (5 launches per layer + 2)
+ * Decode linears over PACKED weights: W[N][K] stored as [N/16][K/64][16][64] bf16 tiles, so the
+ * matrix is read from HBM as one linear stream (each wave-instruction pair = one contiguous 2 KiB
+ * block).  y[M<=16, N] = epi(x W^T); optional fused Qwen2VLRMSNorm on x (norm_w, K <= 4096);
+ * ksplit > 1 splits K over workgroups with a deterministic in-launch reduction (ws: f32
+ * [N/16][ksplit][256] slabs, counters: int32 [N/16], zero-initialised, left zero).
+ * mode 0 PLAIN   : +bias, +residual, bf16 `out` or fp32 `out_f32` [M, ldc]      (o_proj, down_proj)
+ *      1 SILU    : silu(gate)*up, rows interleaved in 16-row groups, out [M, N/2] (gate/up)
+ *      2 ROPE_KV : fused q/k/v projection (+bias) -> M-RoPE with cs_table (fp32 [M][128]: cos[0..64),
+ *                  sin[0..64) of each row's position) -> q_out [M, heads, 128]; k -> kcache row
+ *                  ctx_len[b]; v -> vtcache column ctx_len[b] (cache pointers = this layer's base,
+ *                  layout as kr_decode_qkv_prep).  head_dim 128 only.          (TF:469-556, :180-222)
+ *      3 ARGMAX  : lm_head: per-workgroup (max, lowest index) partials amax_val/amax_idx
+ *                  [M][ceil(N/32)]; fp32 logits also written when out_f32 != NULL   (TF:1320-1323) */
+#define KR_DEC_PLAIN 0
+#define KR_DEC_SILU 1
+#define KR_DEC_ROPE_KV 2
+#define KR_DEC_ARGMAX 3
+int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
+                     const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int ksplit,
+                     float* ws, int32_t* counters,
+                     const float* cs_table, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
+                     kr_bf16* vtcache, int heads, int kv_heads, int s_max,
+                     float* amax_val, int32_t* amax_idx, kr_stream s);
+
+/* kr_attn_decode_gqa with the split merge done in-launch by the last-arriving workgroup
+ * (workspace: fp32 batch*heads*n_split*(hd+2); counters: int32 [batch*kv_heads], zero-initialised).
+ * kcache / vtcache are the layer's base pointers. */
+int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache,
+                         const int32_t* ctx_len, kr_bf16* out, float* workspace, int32_t* counters,
+                         int batch, int heads, int kv_heads, int hd, int s_max, int n_split,
+                         float scale, kr_stream s);
+
+/* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out / history
+ * (as kr_argmax_embed), EOS / pad handling, ctx_len[b] += 1, embedding gather into x_next, step
+ * counter, and the rotary table of the NEXT decode step: cs_table[b] = bf16(cos / sin((ctx_len[b] +
+ * rope_delta[b]) * inv_freq[i])) — one evaluation per step instead of one per layer. */
+int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part,
+                     const kr_bf16* embed_table, int d, int32_t* tokens_out, int32_t* history,
+                     int hist_stride, int32_t* step_ptr, int32_t* ctx_len, int32_t* finished,
+                     const int32_t* eos, int n_eos, int pad_id, int ignore_eos, kr_bf16* x_next,
+                     const int32_t* rope_delta, const float* inv_freq, float* cs_table, int hd,
+                     int batch, kr_stream s);
 
 /* ------------------------------------------------------------------ multi-GPU: one-time weight broadcast (RCCL)
  * One process per GPU.  Rank 0 calls kr_comm_unique_id and shares the 128 bytes through any host

@@ -41,7 +41,7 @@ SIGNATURES = {
     "kr_cast_pad_f32_bf16": [c_p, c_p, i64, i32, i32, c_p],
     "kr_layernorm": [c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
-    "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
+    "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p],
     "kr_gemv_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, c_p, f32, c_p],
     "kr_qkv_prep": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p, i64, c_p, i64, c_p, i64,
                     i32, i32, i32, c_p],
@@ -54,6 +54,11 @@ SIGNATURES = {
     "kr_attn_decode_gqa": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
     "kr_argmax_embed": [c_p, i64, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, i32, c_p],
     "kr_argmax": [c_p, i64, i32, c_p, i32, c_p],
+    "kr_linear_decode": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, c_p, c_p,
+                         c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p],
+    "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
+    "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p,
+                         c_p, i32, i32, c_p],
     "kr_comm_unique_id": [c_p],
     "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],
     "kr_comm_destroy": [c_p],
@@ -63,6 +68,7 @@ SIGNATURES = {
 _RESTYPES = {"kr_last_error": C.c_char_p}
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SILU_MUL = 0, 1, 2, 3
+DEC_PLAIN, DEC_SILU, DEC_ROPE_KV, DEC_ARGMAX = 0, 1, 2, 3
 
 
 class _Lib:

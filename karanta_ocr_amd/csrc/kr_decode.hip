@@ -1,0 +1,630 @@
+// Decode-step kernels (one new token per live sequence): 5 launches per decoder layer + 2 per step.
+//
+//   dec_linear_kernel   y[M<=16, N] = epi(x W^T): the weight matrix is read from HBM exactly once, as
+//                       one linear stream — weights are stored PACKED in [N/16][K/64][16][64] tiles so
+//                       every wave-instruction pair fetches one contiguous 2 KiB block; K is split over
+//                       the 4 waves of a workgroup and, for narrow N, over several workgroups with a
+//                       deterministic in-launch reduction (slabs + arrival counter, agent-scope
+//                       release/acquire).  Fused prologue: Qwen2VLRMSNorm.  Fused epilogues:
+//                         PLAIN   (+bias, +residual, bf16 or fp32 out)        o_proj, down_proj
+//                         SILU    silu(gate)*up                              gate/up projection
+//                         ROPE_KV +bias, M-RoPE, q -> q buffer, k/v -> KV cache (V transposed)
+//                         ARGMAX  per-workgroup (max, index) partials [+ fp32 logits]   lm_head
+//   attn_decode2_kernel split-KV MFMA attention with the cross-workgroup merge done in-launch by the
+//                       last-arriving workgroup of each (sequence, kv head).
+//   sample_greedy_kernel final argmax over the lm_head partials, token history, EOS bookkeeping,
+//                       next-token embedding gather, context advance, and the rotary table of the
+//                       NEXT step (one cos/sin evaluation per step instead of one per layer).
+#include "kr_common.h"
+
+namespace {
+
+constexpr int DEPI_PLAIN = 0, DEPI_SILU = 1, DEPI_ROPE_KV = 2, DEPI_ARGMAX = 3;
+
+struct DecLinArgs {
+    const kr_bf16* x; int64_t ldx;
+    const kr_bf16* wp;                 // packed weights
+    const kr_bf16* bias;
+    const kr_bf16* norm_w; float norm_eps;
+    const kr_bf16* residual; int64_t ldr;
+    kr_bf16* out; float* out_f32; int64_t ldc;
+    int M, N, K, ksplit;
+    float* ws; int* counters;          // split-K slabs [groups][ksplit][NT][256] f32, arrival counters [groups]
+    // ROPE_KV
+    const float* cs_table;             // [M][hd]: cos[0..hd/2) then sin[0..hd/2) of the row's position (bf16 values)
+    const int32_t* ctx_len;
+    kr_bf16* q_out; kr_bf16* kcache; kr_bf16* vtcache;
+    int heads, kv_heads, s_max;
+    // ARGMAX
+    float* amax_val; int32_t* amax_idx;  // [M][gridDim.x]
+};
+
+__device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+
+template <int NT, int EPI>
+__global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int U = 8 / NT;  // chunks (64 k) in flight per wave: 16 x 16-byte loads outstanding
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int g = blockIdx.x, ks = blockIdx.y;
+    const int M = a.M, K = a.K;
+    const int nchunks = K >> 6, ntiles = a.N >> 4;
+
+    int tile[NT];
+    if (EPI == DEPI_ROPE_KV) {  // tiles t and t+4: the two rotary halves of 16 head channels
+        tile[0] = (g >> 2) * 8 + (g & 3);
+        tile[NT - 1] = tile[0] + 4;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile[t] = g * NT + t;
+    }
+    // K range of this workgroup, then of this wave (contiguous => one linear HBM stream per wave)
+    const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
+    const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
+    const int nblk = cb1 - cb0;
+    const int per = (nblk + 3) >> 2;
+    const int c0 = min(cb0 + wave * per, cb1), c1 = min(c0 + per, cb1);
+
+    const kr_bf16* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tt = tile[t] < ntiles ? tile[t] : ntiles - 1;
+        wp[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + fr * 64 + fg * 16;
+    }
+    bf16x8 wbuf[U][NT][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + u;
+        if (c < c1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)c * 1024);
+                wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 8);
+            }
+        }
+    }
+
+    // ---- x slice -> LDS (RMS-normalised on the way when norm_w is given)
+    const int xrow = nblk * 128 + 16;
+    float* red = reinterpret_cast<float*>(smem + ((M * xrow + 127) & ~127));  // [4][NT][64][4]
+    if (a.norm_w) {
+        const int kc = K >> 3;
+        for (int b = wave; b < M; b += 4) {
+            bf16x8 v[8];
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + i * 64;
+                if (c < kc) {
+                    v[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += bf2f(v[i][j]) * bf2f(v[i][j]);
+                }
+            }
+            ss = wave_sum(ss);
+            const float rs = rsqrtf(ss / (float)K + a.norm_eps);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + i * 64;
+                if (c < kc && c >= cb0 * 8 && c < cb1 * 8) {
+                    const bf16x8 nw = ld8(a.norm_w + c * 8);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[j]) * bfround(bf2f(v[i][j]) * rs));
+                    *reinterpret_cast<bf16x8*>(smem + b * xrow + (c - cb0 * 8) * 16) = o;
+                }
+            }
+        }
+    } else {
+        const int cpr = nblk * 8;  // 16-byte chunks per row slice
+        for (int i = tid; i < M * cpr; i += 256) {
+            const int b = i / cpr, c = i - b * cpr;
+            *reinterpret_cast<bf16x8*>(smem + b * xrow + c * 16) = ld8(a.x + (int64_t)b * a.ldx + (cb0 * 8 + c) * 8);
+        }
+    }
+    __syncthreads();
+
+    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 32;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = c0; cc < c1; cc += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cc + u;
+            if (c < c1) {
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][0], x0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][1], x1, acc[t], 0, 0, 0);
+                }
+                const int cn = c + U;
+                if (cn < c1) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
+                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 8);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- reduce the 4 waves' K slices through LDS; wave 0 owns the rest
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 sum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
+        }
+    }
+    // ---- split-K across workgroups: slab + arrival counter; the last arriver reduces in fixed order
+    if (a.ksplit > 1) {
+        float* slab = a.ws + ((int64_t)(g * a.ksplit + ks) * NT) * 256;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(slab + t * 256 + lane * 4) = sum[t];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            old = __hip_atomic_fetch_add(a.counters + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != a.ksplit - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.counters + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < a.ksplit; ++s) {
+            const float* sl = a.ws + ((int64_t)(g * a.ksplit + s) * NT) * 256;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(sl + t * 256 + lane * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
+            }
+        }
+    }
+
+    // ---- epilogues: lane = (row b = fr, 4 consecutive features 4*fg..4*fg+3 of each tile)
+    const int b = fr;
+    if (EPI == DEPI_ARGMAX) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = tile[t] * 16 + fg * 4;
+            if (tile[t] < ntiles) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) better(bv, bi, sum[t][j], n + j);
+                if (a.out_f32 && b < M) *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = sum[t];
+            }
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            better(bv, bi, ov, oi);
+        }
+        if (fg == 0 && b < M) {
+            a.amax_val[(int64_t)b * gridDim.x + g] = bv;
+            a.amax_idx[(int64_t)b * gridDim.x + g] = bi;
+        }
+        return;
+    }
+    if (b >= M) return;
+    if (EPI == DEPI_SILU) {
+        if (tile[0] >= ntiles) return;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(sum[0][j]) * sum[NT - 1][j]);
+        *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + g * 16 + fg * 4) = o;
+        return;
+    }
+    if (EPI == DEPI_ROPE_KV) {
+        const int hh = tile[0] >> 3;                   // global head index in [q heads | k heads | v heads]
+        const int i0 = (tile[0] & 7) * 16 + fg * 4;    // channel in [0, 64)
+        float lo[4], hi[4];
+        {
+            const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(a.bias + tile[0] * 16 + fg * 4);
+            const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(a.bias + tile[NT - 1] * 16 + fg * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = bfround(sum[0][j] + bf2f(b0[j]));       // the projection output is a bf16 tensor
+                hi[j] = bfround(sum[NT - 1][j] + bf2f(b1[j]));
+            }
+        }
+        const int pos = a.ctx_len[b];
+        if (hh < a.heads + a.kv_heads) {
+            const float* cs = a.cs_table + b * 128;
+            bf16x4 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = cs[i0 + j], s = cs[64 + i0 + j];
+                o0[j] = f2bf(lo[j] * c - hi[j] * s);
+                o1[j] = f2bf(hi[j] * c + lo[j] * s);
+            }
+            kr_bf16* dst = hh < a.heads
+                               ? a.q_out + ((int64_t)b * a.heads + hh) * 128
+                               : a.kcache + (((int64_t)b * a.kv_heads + (hh - a.heads)) * a.s_max + pos) * 128;
+            *reinterpret_cast<bf16x4*>(dst + i0) = o0;
+            *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
+        } else {
+            const int kvh = hh - a.heads - a.kv_heads;
+            kr_bf16* vt = a.vtcache + ((((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * 128) * 64 + (pos & 63);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
+                vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+            }
+        }
+        return;
+    }
+    // PLAIN
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (tile[t] >= ntiles) continue;
+        const int n = tile[t] * 16 + fg * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sum[t][j];
+        if (a.bias) {
+            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
+        }
+        if (a.residual) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
+        }
+        if (a.out_f32) {
+            *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+            *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
+        }
+    }
+}
+
+// =====================================================================================
+// decode attention with in-launch merge
+// =====================================================================================
+// grid = (n_split, kv_heads, batch); 4 waves; wave `part` = split*4 + wave walks 64-key blocks
+// part, part + 4*n_split, ...   Layouts as in kr_attention.hip (K rows, V^T 64-key blocks).
+__global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
+                                                           const kr_bf16* __restrict__ vtcache,
+                                                           const int32_t* __restrict__ ctx_len, kr_bf16* __restrict__ out,
+                                                           float* __restrict__ ws, int* __restrict__ counters, int heads,
+                                                           int kv_heads, int s_max, float scale_log2e) {
+    constexpr int HD = 128, DT = HD / 16;
+    __shared__ __attribute__((aligned(16))) float o_s[4][16][HD];
+    __shared__ float m_s[4][16], l_s[4][16];
+    __shared__ int last_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int split = blockIdx.x, n_split = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int group = heads / kv_heads;
+    const int n_part = n_split * 4, part = split * 4 + wave;
+    const int ctx = ctx_len[b] + 1;
+    const int nb = (ctx + 63) >> 6;
+
+    const int g = fr < group ? fr : 0;
+    const kr_bf16* qp = q + ((int64_t)b * heads + kvh * group + g) * HD + fg * 32;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qf[i] = ld8(qp + i * 8);
+    const int64_t kv_base = (int64_t)b * kv_heads + kvh;
+    const kr_bf16* kc = kcache + kv_base * s_max * HD;
+    const kr_bf16* vc = vtcache + kv_base * (int64_t)(s_max >> 6) * (HD * 64);
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+    for (int blk = part; blk < nb; blk += n_part) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int key0 = blk * 64 + hf * 32;
+            if (key0 >= ctx) break;
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kf[kt][i] = ld8_nt(kp + i * 8);
+            }
+            bf16x8 vf[DT];
+            const kr_bf16* vp = vc + (int64_t)blk * (HD * 64) + hf * 32 + fg * 8;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = ld8_nt(vp + (dt * 16 + fr) * 64);
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][i], qf[i], s[kt], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + 8 * fg + 4 * kt + r;
+                    const float v = key < ctx ? s[kt][r] * scale_log2e : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            bf16x8 pf;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const __bf16 pb = f2bf(__builtin_amdgcn_exp2f(s[kt][r] - m_new));
+                    psum += bf2f(pb);
+                    pf[kt * 4 + r] = pb;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    // ---- merge the 4 waves through LDS
+    if (fr < group) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(&o_s[wave][fr][dt * 16 + fg * 4]) = o[dt];
+        if (fg == 0) {
+            m_s[wave][fr] = m_run;
+            l_s[wave][fr] = l_run;
+        }
+    }
+    __syncthreads();
+    const int bh0 = b * heads + kvh * group;
+    for (int e = tid; e < group * HD; e += 256) {
+        const int gg = e >> 7, d = e & 127;
+        float mm = m_s[0][gg];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mm = fmaxf(mm, m_s[w][gg]);
+        float acc = 0.f, ll = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __builtin_amdgcn_exp2f(m_s[w][gg] - mm);
+            acc += o_s[w][gg][d] * sc;
+            ll += l_s[w][gg] * sc;
+        }
+        if (n_split == 1) {
+            out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+        } else {
+            float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * (HD + 2);
+            w[d] = acc;
+            if (d == 0) {
+                w[HD] = mm;
+                w[HD + 1] = ll;
+            }
+        }
+    }
+    if (n_split == 1) return;
+    // ---- cross-workgroup merge by the last arriver (agent-scope release / acquire)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(counters + b * kv_heads + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (old == n_split - 1);
+        if (old == n_split - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counters + b * kv_heads + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!last_s) return;
+    for (int e = tid; e < group * HD; e += 256) {
+        const int gg = e >> 7, d = e & 127;
+        const float* w = ws + (int64_t)(bh0 + gg) * n_split * (HD + 2);
+        float mm = -1e30f;
+        for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * (HD + 2) + HD]);
+        float acc = 0.f, ll = 0.f;
+        for (int p = 0; p < n_split; ++p) {
+            const float sc = __builtin_amdgcn_exp2f(w[p * (HD + 2) + HD] - mm);
+            acc += w[p * (HD + 2) + d] * sc;
+            ll += w[p * (HD + 2) + HD + 1] * sc;
+        }
+        out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+    }
+}
+
+// =====================================================================================
+// greedy sampling from the lm_head partials + per-step bookkeeping
+// =====================================================================================
+__global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restrict__ amax_val,
+                                                            const int32_t* __restrict__ amax_idx, int n_part,
+                                                            const kr_bf16* __restrict__ table, int d,
+                                                            int32_t* __restrict__ tokens_out, int32_t* __restrict__ history,
+                                                            int hist_stride, int32_t* __restrict__ step_ptr,
+                                                            int32_t* __restrict__ ctx_len, int32_t* __restrict__ finished,
+                                                            const int32_t* __restrict__ eos, int n_eos, int pad_id,
+                                                            int ignore_eos, kr_bf16* __restrict__ x_next,
+                                                            const int32_t* __restrict__ rope_delta,
+                                                            const float* __restrict__ inv_freq, float* __restrict__ cs_table,
+                                                            int half) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n_part; i += 256) better(bv, bi, amax_val[(int64_t)b * n_part + i], amax_idx[(int64_t)b * n_part + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        better(bv, bi, ov, oi);
+    }
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    bv = s_v[0];
+    bi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) better(bv, bi, s_v[w], s_i[w]);
+    int tok = bi;
+    const int was_finished = finished[b];
+    if (was_finished && !ignore_eos) tok = pad_id;
+    const int step = step_ptr[0];
+    const int new_ctx = ctx_len[b] + 1;
+    __syncthreads();
+    if (tid == 0) {
+        tokens_out[b] = tok;
+        history[(int64_t)step * hist_stride + b] = tok;
+        ctx_len[b] = new_ctx;
+        if (!ignore_eos && !was_finished) {
+            int hit = 0;
+            for (int i = 0; i < n_eos; ++i) hit |= (tok == eos[i]);
+            if (hit) finished[b] = 1;
+        }
+    }
+    for (int c = tid; c < (d >> 3); c += 256) st8(x_next + (int64_t)b * d + c * 8, ld8(table + (int64_t)tok * d + c * 8));
+    // rotary table of the next decode step: position = cached tokens + rope delta (TF:1124-1136),
+    // cos/sin rounded to the activation dtype (TF:169)
+    const float rp = (float)(new_ctx + rope_delta[b]);
+    for (int i = tid; i < half; i += 256) {
+        const float ang = rp * inv_freq[i];
+        cs_table[b * 2 * half + i] = bfround(cosf(ang));
+        cs_table[b * 2 * half + half + i] = bfround(sinf(ang));
+    }
+}
+
+__global__ void bump2_kernel(int32_t* p) { p[0] += 1; }
+
+template <int NT, int EPI>
+int launch_dec(const DecLinArgs& a, int groups, kr_stream s) {
+    const int nchunks = a.K >> 6;
+    const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
+    const size_t xbytes = ((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127;
+    const size_t lds = xbytes + (size_t)4 * NT * 256 * 4;
+    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode: needs %zu bytes of LDS (M=%d K=%d ksplit=%d)", lds, a.M, a.K, a.ksplit);
+    auto fn = &dec_linear_kernel<NT, EPI>;
+    static bool attr = false;
+    if (!attr) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    fn<<<dim3(groups, a.ksplit), 256, lds, kr_hs(s)>>>(a);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
+                                const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr, kr_bf16* out,
+                                float* out_f32, int64_t ldc, int M, int N, int K, int ksplit, float* ws, int32_t* counters,
+                                const float* cs_table, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
+                                kr_bf16* vtcache, int heads, int kv_heads, int s_max, float* amax_val, int32_t* amax_idx,
+                                kr_stream s) {
+    KR_CHECK_ARG(x && w_packed, "kr_linear_decode: null pointer");
+    KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode: M=%d must be in 1..16", M);
+    KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 64 == 0, "kr_linear_decode: N=%d K=%d (N%%16, K%%64)", N, K);
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode: ldx");
+    KR_CHECK_ARG(ksplit >= 1 && ksplit <= (K >> 6), "kr_linear_decode: ksplit=%d", ksplit);
+    KR_CHECK_ARG(ksplit == 1 || (ws && counters), "kr_linear_decode: split-K needs workspace and counters");
+    KR_CHECK_ARG(!norm_w || K <= 4096, "kr_linear_decode: fused RMSNorm supports K <= 4096");
+    DecLinArgs a{};
+    a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.ksplit = ksplit; a.ws = ws; a.counters = counters;
+    a.cs_table = cs_table; a.ctx_len = ctx_len; a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
+    a.heads = heads; a.kv_heads = kv_heads; a.s_max = s_max; a.amax_val = amax_val; a.amax_idx = amax_idx;
+    const int ntiles = N >> 4;
+    switch (mode) {
+        case DEPI_PLAIN: {
+            KR_CHECK_ARG((out || out_f32) && ldc >= N && (ldc & 3) == 0, "kr_linear_decode: PLAIN output");
+            KR_CHECK_ARG(!residual || (ldr & 3) == 0, "kr_linear_decode: ldr");
+            if (ntiles >= 1024) return launch_dec<2, DEPI_PLAIN>(a, (ntiles + 1) / 2, s);
+            return launch_dec<1, DEPI_PLAIN>(a, ntiles, s);
+        }
+        case DEPI_SILU:
+            KR_CHECK_ARG(out && N % 32 == 0 && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode: SILU output");
+            return launch_dec<2, DEPI_SILU>(a, ntiles / 2, s);
+        case DEPI_ROPE_KV:
+            KR_CHECK_ARG(bias && cs_table && ctx_len && q_out && kcache && vtcache, "kr_linear_decode: ROPE_KV pointers");
+            KR_CHECK_ARG(N == (heads + 2 * kv_heads) * 128 && s_max % 64 == 0, "kr_linear_decode: ROPE_KV needs head_dim 128");
+            return launch_dec<2, DEPI_ROPE_KV>(a, ntiles / 2, s);
+        case DEPI_ARGMAX:
+            KR_CHECK_ARG(amax_val && amax_idx && ksplit == 1, "kr_linear_decode: ARGMAX pointers / ksplit");
+            KR_CHECK_ARG(!out_f32 || ldc >= N, "kr_linear_decode: ARGMAX logits ldc");
+            return launch_dec<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, s);
+        default:
+            kr_set_error("kr_linear_decode: unknown mode %d", mode);
+            return KR_ERR_ARG;
+    }
+}
+
+extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
+                                    kr_bf16* out, float* workspace, int32_t* counters, int batch, int heads, int kv_heads,
+                                    int hd, int s_max, int n_split, float scale, kr_stream s) {
+    KR_CHECK_ARG(q && kcache && vtcache && ctx_len && out, "kr_attn_decode_fused: null pointer");
+    KR_CHECK_ARG(hd == 128, "kr_attn_decode_fused: hd=%d (only 128)", hd);
+    KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_fused: GQA group must be <= 16");
+    KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
+    KR_CHECK_ARG(n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
+    attn_decode2_kernel<<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
+        q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part, const kr_bf16* embed_table,
+                                int d, int32_t* tokens_out, int32_t* history, int hist_stride, int32_t* step_ptr,
+                                int32_t* ctx_len, int32_t* finished, const int32_t* eos, int n_eos, int pad_id,
+                                int ignore_eos, kr_bf16* x_next, const int32_t* rope_delta, const float* inv_freq,
+                                float* cs_table, int hd, int batch, kr_stream s) {
+    KR_CHECK_ARG(amax_val && amax_idx && embed_table && tokens_out && history && step_ptr && ctx_len && finished &&
+                     x_next && rope_delta && inv_freq && cs_table,
+                 "kr_sample_greedy: null pointer");
+    KR_CHECK_ARG(n_part > 0 && batch > 0 && (d & 7) == 0 && hist_stride >= batch && hd % 2 == 0 && (n_eos == 0 || eos),
+                 "kr_sample_greedy: bad sizes");
+    sample_greedy_kernel<<<batch, 256, 0, kr_hs(s)>>>(amax_val, amax_idx, n_part, embed_table, d, tokens_out, history,
+                                                      hist_stride, step_ptr, ctx_len, finished, eos, n_eos, pad_id,
+                                                      ignore_eos, x_next, rope_delta, inv_freq, cs_table, hd / 2);
+    KR_CHECK_LAUNCH();
+    bump2_kernel<<<1, 1, 0, kr_hs(s)>>>(step_ptr);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}

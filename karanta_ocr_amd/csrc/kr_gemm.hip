@@ -26,6 +26,9 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((
 
 // Stage one [128][64] tile (rows row0.., k k0..) of a row-major [rows_total][ld] matrix.
 // Each wave-instruction writes 1 KiB contiguous LDS (= 8 tile rows).
+// PACKED: the matrix is stored as [rows/16][ld/64][16][64] tiles (the decode layout): the same
+// 1 KiB-per-wave-instruction pattern, read from fully contiguous 2 KiB blocks.
+template <bool PACKED>
 __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_total,
                                            int k0, char* lds_tile, int tid, int wave) {
 #pragma unroll
@@ -35,14 +38,15 @@ __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_
         const int c = cp ^ ((r >> 1) & 7);  // which global chunk lands at this LDS position
         int64_t gr = row0 + r;
         gr = gr < rows_total ? gr : rows_total - 1;
-        const kr_bf16* src = g + gr * ld + k0 + c * 8;
+        const kr_bf16* src = PACKED ? g + ((gr >> 4) * (ld >> 6) + (k0 >> 6)) * 1024 + (gr & 15) * 64 + c * 8
+                                    : g + gr * ld + k0 + c * 8;
         char* dst = lds_tile + (p * 256 + wave * 64) * 16;  // wave-uniform; hardware adds lane*16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 }
 
-template <int EPI>
+template <int EPI, bool WPACK>
 __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
                                                    const kr_bf16* __restrict__ W, const kr_bf16* __restrict__ bias,
                                                    const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C,
@@ -64,8 +68,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    stage_tile(A, lda, m0, M, 0, smem, tid, wave);
-    stage_tile(W, K, n0, N, 0, smem + TILE_BYTES, tid, wave);
+    stage_tile<false>(A, lda, m0, M, 0, smem, tid, wave);
+    stage_tile<WPACK>(W, K, n0, N, 0, smem + TILE_BYTES, tid, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -74,8 +78,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
         char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nk) {
             char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile(A, lda, m0, M, (kt + 1) * BK, nxt, tid, wave);
-            stage_tile(W, K, n0, N, (kt + 1) * BK, nxt + TILE_BYTES, tid, wave);
+            stage_tile<false>(A, lda, m0, M, (kt + 1) * BK, nxt, tid, wave);
+            stage_tile<WPACK>(W, K, n0, N, (kt + 1) * BK, nxt + TILE_BYTES, tid, wave);
         }
         const char* At = cur;
         const char* Wt = cur + TILE_BYTES;
@@ -147,30 +151,37 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
     }
 }
 
-template <int EPI>
-int launch_gemm(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
-                kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
+template <int EPI, bool WPACK>
+int launch_gemm2(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                 kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
     const int64_t tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
     const int64_t nwg = tiles_m * tiles_n;
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI>),
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
         attr_set = true;
     }
-    gemm_kernel<EPI><<<(unsigned)nwg, 256, 4 * TILE_BYTES, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
-                                                                       (unsigned)nwg);
+    gemm_kernel<EPI, WPACK><<<(unsigned)nwg, 256, 4 * TILE_BYTES, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
+                                                                              tiles_n, (unsigned)nwg);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+template <int EPI>
+int launch_gemm(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int w_packed, kr_stream s) {
+    return w_packed ? launch_gemm2<EPI, true>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s)
+                    : launch_gemm2<EPI, false>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
 }
 
 }  // namespace
 
 extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
                             const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K,
-                            int epilogue, kr_stream s) {
+                            int epilogue, int w_packed, kr_stream s) {
     KR_CHECK_ARG(A && W && C, "kr_gemm_bf16: null pointer");
     KR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "kr_gemm_bf16: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
     KR_CHECK_ARG(K % BK == 0, "kr_gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -183,17 +194,17 @@ extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, con
     switch (epilogue) {
         case KR_EPI_NONE:
             KR_CHECK_ARG(ldc >= N, "kr_gemm_bf16: ldc < N");
-            return launch_gemm<KR_EPI_NONE>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, s);
+            return launch_gemm<KR_EPI_NONE>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         case KR_EPI_QUICK_GELU:
             KR_CHECK_ARG(ldc >= N, "kr_gemm_bf16: ldc < N");
-            return launch_gemm<KR_EPI_QUICK_GELU>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, s);
+            return launch_gemm<KR_EPI_QUICK_GELU>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         case KR_EPI_GELU_ERF:
             KR_CHECK_ARG(ldc >= N, "kr_gemm_bf16: ldc < N");
-            return launch_gemm<KR_EPI_GELU_ERF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, s);
+            return launch_gemm<KR_EPI_GELU_ERF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         case KR_EPI_SILU_MUL:
             KR_CHECK_ARG(N % 32 == 0 && ldc >= N / 2 && !bias && !residual,
                          "kr_gemm_bf16: SILU_MUL needs N%%32==0, no bias/residual");
-            return launch_gemm<KR_EPI_SILU_MUL>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, s);
+            return launch_gemm<KR_EPI_SILU_MUL>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         default:
             kr_set_error("kr_gemm_bf16: unknown epilogue %d", epilogue);
             return KR_ERR_ARG;

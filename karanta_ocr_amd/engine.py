@@ -21,9 +21,10 @@ import numpy as np
 import torch
 
 from . import positions as POS
-from ._lib import EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL, KarantaHipError, lib, ptr
+from ._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL,
+                   KarantaHipError, lib, ptr)
 from .config import ModelConfig
-from .weights import to_bf16_bits
+from .weights import pack_w16x64, to_bf16_bits
 
 BF16 = torch.bfloat16
 
@@ -42,9 +43,13 @@ def _align(n: int, a: int = 256) -> int:
 class DeviceWeights:
     """All parameters in one contiguous HBM arena, laid out for the kernels:
 
-    * every Linear keeps its [out, in] row-major layout (K contiguous = MFMA fragment order);
+    * ViT Linears keep their [out, in] row-major layout (K contiguous = MFMA fragment order);
     * decoder q/k/v are fused into one [q+2kv, d] matrix, gate/up into one [2*ff, d] matrix with
       rows interleaved in groups of 16 (KR_EPI_SILU_MUL);
+    * every decoder Linear and the lm_head are stored PACKED as [N/16][K/64][16][64] tiles
+      (weights.pack_w16x64): decode streams them linearly from HBM, prefill reads the same copy
+      through kr_gemm_bf16(w_packed=1).  A tied lm_head gets its own packed copy (the embedding
+      table itself stays row-major for the gather);
     * the patch-embed kernel matrix is zero-padded from K=1176 to 1216 (GEMM BK=64).
     """
 
@@ -84,15 +89,12 @@ class DeviceWeights:
             self._add(p + "gate_up.w", (2 * t.intermediate_size, t.hidden_size))
             self._add(p + "down.w", (t.hidden_size, t.intermediate_size))
         self._add("llm.norm.w", (t.hidden_size,))
-        if not t.tie_word_embeddings:
-            self._add("llm.lm_head", (t.vocab_size, t.hidden_size))
+        self._add("llm.lm_head", (t.vocab_size, t.hidden_size))
 
     def allocate(self):
         self.arena = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
 
     def view(self, name: str) -> torch.Tensor:
-        if name == "llm.lm_head" and self.cfg.text.tie_word_embeddings:
-            name = "llm.embed"
         off, shape = self.layout[name]
         n = int(np.prod(shape))
         return self.arena[off:off + 2 * n].view(BF16).view(*shape)
@@ -131,16 +133,16 @@ class DeviceWeights:
             s, d = f"{Lm}layers.{i}.", f"llm.{i}."
             self._put(d + "ln1.w", _bits(w[s + "input_layernorm.weight"]))
             self._put(d + "ln2.w", _bits(w[s + "post_attention_layernorm.weight"]))
-            self._put(d + "qkv.w", np.concatenate([_bits(w[s + f"self_attn.{n}_proj.weight"]) for n in "qkv"], 0))
+            self._put(d + "qkv.w", pack_w16x64(np.concatenate([_bits(w[s + f"self_attn.{n}_proj.weight"]) for n in "qkv"], 0)))
             self._put(d + "qkv.b", np.concatenate([_bits(w[s + f"self_attn.{n}_proj.bias"]) for n in "qkv"], 0))
-            self._put(d + "o.w", _bits(w[s + "self_attn.o_proj.weight"]))
+            self._put(d + "o.w", pack_w16x64(_bits(w[s + "self_attn.o_proj.weight"])))
             g = _bits(w[s + "mlp.gate_proj.weight"]).reshape(ff // 16, 16, -1)
             u = _bits(w[s + "mlp.up_proj.weight"]).reshape(ff // 16, 16, -1)
-            self._put(d + "gate_up.w", np.stack([g, u], 1).reshape(2 * ff, -1))
-            self._put(d + "down.w", _bits(w[s + "mlp.down_proj.weight"]))
+            self._put(d + "gate_up.w", pack_w16x64(np.stack([g, u], 1).reshape(2 * ff, -1)))
+            self._put(d + "down.w", pack_w16x64(_bits(w[s + "mlp.down_proj.weight"])))
         self._put("llm.norm.w", _bits(w[Lm + "norm.weight"]))
-        if not t.tie_word_embeddings:
-            self._put("llm.lm_head", _bits(w["lm_head.weight"]))
+        head = w[Lm + "embed_tokens.weight"] if (t.tie_word_embeddings or "lm_head.weight" not in w) else w["lm_head.weight"]
+        self._put("llm.lm_head", pack_w16x64(_bits(head)))
         torch.cuda.synchronize(self.device)
 
 
@@ -233,7 +235,20 @@ class Engine:
         self.d_o = z(B, t.q_dim)
         self.d_act = z(B, t.intermediate_size)
         self.d_logits = z(B, t.vocab_size, dtype=torch.float32)
-        self.d_ws = z(B * t.num_heads * self.n_split * 4 * (t.head_dim + 2), dtype=torch.float32)
+        self.d_ws = z(B * t.num_heads * self.n_split * (t.head_dim + 2), dtype=torch.float32)
+        self.d_attn_cnt = z(B * t.num_kv_heads, dtype=torch.int32)
+        # split-K plan of the narrow decode linears + their slab workspace / arrival counters
+        nck = t.hidden_size // 64
+        self.ks_qkv = self._ksplit(t.qkv_dim // 32, nck)
+        self.ks_o = self._ksplit(t.hidden_size // 16, t.q_dim // 64)
+        self.ks_down = self._ksplit(t.hidden_size // 16, t.intermediate_size // 64)
+        slab = max(t.qkv_dim // 32 * self.ks_qkv * 2, t.hidden_size // 16 * max(self.ks_o, self.ks_down)) * 256
+        self.d_lin_ws = z(slab, dtype=torch.float32)
+        self.d_lin_cnt = z(max(t.qkv_dim // 32, t.hidden_size // 16), dtype=torch.int32)
+        self.n_amax = (t.vocab_size // 16 + 1) // 2
+        self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
+        self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
+        self.d_cs = z(B, t.head_dim, dtype=torch.float32)
         self.d_ctx = z(B, dtype=torch.int32)
         self.d_delta = z(B, dtype=torch.int32)
         self.d_tok = z(B, dtype=torch.int32)
@@ -246,14 +261,32 @@ class Engine:
         self.d_last = z(B, dtype=torch.int32)
         torch.cuda.synchronize(dev)
 
+    def _ksplit(self, groups: int, nchunks: int, target: int = 384) -> int:
+        """K-split of a decode linear: enough workgroups to cover the 256 CUs (~target), at least two
+        64-wide K chunks per wave, and an x slice of at most 64 KiB of LDS."""
+        ks = max(1, min(int(round(target / groups)), nchunks // 8))
+        ks = max(ks, -(-self.B * nchunks * 128 // 65536))
+        return min(ks, nchunks)
+
     def load_weights(self, weights: Dict[str, np.ndarray]):
         self.w.load(weights)
 
     # ------------------------------------------------------------------ small launch helpers
-    def _gemm(self, A, W, C_, M, bias=None, res=None, epi=EPI_NONE):
+    def _gemm(self, A, W, C_, M, bias=None, res=None, epi=EPI_NONE, packed=False):
         N, K = W.shape
         self.L.kr_gemm_bf16(ptr(A), A.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
-                            ptr(C_), C_.stride(0), M, N, K, epi, self.s)
+                            ptr(C_), C_.stride(0), M, N, K, epi, 1 if packed else 0, self.s)
+
+    def _dec(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, ksplit=1, kc=0, vc=0):
+        """kr_linear_decode on packed weights."""
+        t = self.cfg.text
+        N, K = W.shape
+        o = out if out is not None else out_f32
+        self.L.kr_linear_decode(mode, ptr(x), x.stride(0), ptr(W), ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res),
+                                res.stride(0) if res is not None else 0, ptr(out), ptr(out_f32),
+                                o.stride(0) if o is not None else 0, M, N, K, ksplit, ptr(self.d_lin_ws),
+                                ptr(self.d_lin_cnt), ptr(self.d_cs), ptr(self.d_ctx), ptr(self.d_q), kc, vc,
+                                t.num_heads, t.num_kv_heads, self.s_max, ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _gemv(self, x, W, out, M, bias=None, res=None, epi=EPI_NONE, norm_w=None, out_f32=None):
         N, K = W.shape
@@ -392,7 +425,7 @@ class Engine:
             for i in range(t.num_layers):
                 p = f"llm.{i}."
                 L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln1.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
-                self._gemm(self.p_h, w.view(p + "qkv.w"), self.p_qkv, M, bias=w.view(p + "qkv.b"))
+                self._gemm(self.p_h, w.view(p + "qkv.w"), self.p_qkv, M, bias=w.view(p + "qkv.b"), packed=True)
                 kc, vc = self.kcache[i], self.vtcache[i]
                 L.kr_qkv_prep(ptr(self.p_qkv), t.qkv_dim, 0, t.q_dim, t.q_dim + t.kv_dim, ptr(self.p_cos), ptr(self.p_sin),
                               ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
@@ -401,45 +434,50 @@ class Engine:
                 L.kr_attn_varlen(ptr(self.p_q), ptr(kc), ptr(vc), ptr(self.p_o), ptr(qblk), ptr(qlen),
                                  plan.qblk.shape[0], self.p_q.shape[1], H, KVH, hd, k_head_stride, vt_head_stride,
                                  hd ** -0.5, 1, s)
-                self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x)
+                self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x, packed=True)
                 L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln2.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
-                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL)
-                self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x)
+                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL, packed=True)
+                self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x, packed=True)
             # last position of every sequence -> final norm (fused) -> lm_head -> greedy token
             L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)
             self._lm_head_and_sample(B)
         return lens
 
     def _lm_head_and_sample(self, B: int):
+        """final RMSNorm (fused) -> lm_head with per-workgroup argmax partials -> greedy token,
+        bookkeeping and the next step's rotary table (TF:839, :1320-1323; generate(do_sample=False))."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
-        self._gemv(self.d_x, w.view("llm.lm_head"), None, B, norm_w=w.view("llm.norm.w"), out_f32=self.d_logits)
-        L.kr_argmax_embed(ptr(self.d_logits), self.d_logits.stride(0), t.vocab_size, ptr(w.view("llm.embed")),
-                          t.hidden_size, ptr(self.d_tok), ptr(self.d_hist), ptr(self.d_step), ptr(self.d_ctx),
-                          ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
-                          1 if self._ignore_eos else 0, ptr(self.d_x), B, self.d_hist.stride(0), s)
+        self._dec(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
+                  out_f32=self.d_logits if self._want_logits else None)
+        L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
+                           ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_step), ptr(self.d_ctx),
+                           ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
+                           1 if self._ignore_eos else 0, ptr(self.d_x), ptr(self.d_delta), ptr(self.d_invfreq),
+                           ptr(self.d_cs), t.head_dim, B, s)
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
-        """One decode step = 7 launches per layer + 3 (TF:559-624 per layer, TF:839, :1320-1323)."""
+        """One decode step = 5 launches per layer + 2 (Qwen2VLDecoderLayer TF:559-624, final norm
+        TF:839, lm_head TF:1320-1323): [RMSNorm+QKV+bias+M-RoPE+KV append] -> attention ->
+        [o_proj+residual] -> [RMSNorm+gate/up+SiLU*mul] -> [down_proj+residual]."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         H, KVH, hd = t.num_heads, t.num_kv_heads, t.head_dim
         for i in range(t.num_layers):
             p = f"llm.{i}."
-            self._gemv(self.d_x, w.view(p + "qkv.w"), self.d_qkv, B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"))
-            # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base (layer=0)
+            # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base
             kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])
-            L.kr_decode_qkv_prep(ptr(self.d_qkv), ptr(self.d_invfreq), ptr(self.d_ctx), ptr(self.d_delta), ptr(self.d_q),
-                                 kc, vc, B, H, KVH, hd, 0, self.s_max, s)
-            L.kr_attn_decode_gqa(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o),
-                                 ptr(self.d_ws), B, H, KVH, hd, 0, self.s_max, self.n_split, hd ** -0.5, s)
-            self._gemv(self.d_o, w.view(p + "o.w"), self.d_x, B, res=self.d_x)
+            self._dec(DEC_ROPE_KV, self.d_x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
+                      ksplit=self.ks_qkv, kc=kc, vc=vc)
+            L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o), ptr(self.d_ws),
+                                   ptr(self.d_attn_cnt), B, H, KVH, hd, self.s_max, self.n_split, hd ** -0.5, s)
+            self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, ksplit=self.ks_o)
             if self._prof_on:
                 e0, e1 = self._prof_event_pair()
                 L.kr_event_record(e0, s)
-            self._gemv(self.d_x, w.view(p + "gate_up.w"), self.d_act, B, epi=EPI_SILU_MUL, norm_w=w.view(p + "ln2.w"))
+            self._dec(DEC_SILU, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
             if self._prof_on:
                 L.kr_event_record(e1, s)
-            self._gemv(self.d_act, w.view(p + "down.w"), self.d_x, B, res=self.d_x)
+            self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, ksplit=self.ks_down)
         self._lm_head_and_sample(B)
 
     # ------------------------------------------------------------------ live kernel timing (bench.py roofline)
@@ -454,7 +492,7 @@ class Engine:
         return pair
 
     def kernel_profile(self, reset: bool = True) -> Dict[str, float]:
-        """Durations of the decode gate/up GEMV (`gemv_kernel<2, SILU_MUL, ...>`, the kernel that moves
+        """Durations of the decode gate/up projection (`dec_linear_kernel<2, SILU>`, the kernel that moves
         half of the decoder's bytes) measured with HIP events on the launch stream during the profiled
         eager steps.  Returns {launches, avg_us, min_us, bytes_per_launch}."""
         self.stream.synchronize()
@@ -473,6 +511,7 @@ class Engine:
 
     def _graph_for(self, B: int) -> int:
         key = (B, self._ignore_eos)
+        assert not self._want_logits
         g = self._graphs.get(key)
         if g is None:
             L = self.L
@@ -503,6 +542,7 @@ class Engine:
             raise ValueError("max_new_tokens must be >= 1")
         t0 = time.perf_counter()
         self._ignore_eos = bool(ignore_eos)
+        self._want_logits = bool(return_logits)
         self._last_batch = B
         if self.d_hist is None or self.max_new < max_new_tokens:
             self.max_new = max_new_tokens

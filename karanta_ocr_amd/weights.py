@@ -171,3 +171,19 @@ def load_checkpoint(model_dir: str) -> tuple:
 
 def as_f32(w: np.ndarray) -> np.ndarray:
     return from_bf16_bits(w) if w.dtype == np.uint16 else np.asarray(w, dtype=np.float32)
+
+
+def pack_w16x64(w: np.ndarray) -> np.ndarray:
+    """Row-major ``[N, K]`` -> the decode layout ``[N/16][K/64][16][64]`` (flattened to ``[N, K]``
+    shape for bookkeeping): each (16-row, 64-column) tile is one contiguous 2 KiB block, tiles of
+    one 16-row group follow each other along K.  kr_linear_decode streams it linearly; kr_gemm_bf16
+    reads it with ``w_packed=1``."""
+    n, k = w.shape
+    if n % 16 or k % 64:
+        raise ValueError(f"pack_w16x64: shape {w.shape} is not a multiple of (16, 64)")
+    return np.ascontiguousarray(w.reshape(n // 16, 16, k // 64, 64).transpose(0, 2, 1, 3)).reshape(n, k)
+
+
+def unpack_w16x64(p: np.ndarray) -> np.ndarray:
+    n, k = p.shape
+    return np.ascontiguousarray(p.reshape(n // 16, k // 64, 16, 64).transpose(0, 2, 1, 3)).reshape(n, k)

@@ -31,7 +31,8 @@ def built_lib():
 def test_header_has_the_survey_operator_set():
     protos = header_prototypes()
     for name in ("kr_layernorm", "kr_rmsnorm", "kr_gemm_bf16", "kr_rope2d_vision", "kr_mrope", "kr_attn_varlen",
-                 "kr_kv_append", "kr_attn_decode_gqa", "kr_embed_scatter", "kr_argmax", "kr_bcast_weights"):
+                 "kr_kv_append", "kr_attn_decode_gqa", "kr_embed_scatter", "kr_argmax", "kr_bcast_weights",
+                 "kr_linear_decode", "kr_attn_decode_fused", "kr_sample_greedy"):
         assert name in protos, name
 
 
@@ -69,7 +70,7 @@ def test_host_side_argument_validation_needs_no_gpu(built_lib):
 
     L = lib()
     with pytest.raises(KarantaHipError, match="multiple of 64"):
-        L.kr_gemm_bf16(16, 100, 16, 0, 0, 0, 16, 128, 4, 128, 100, 0, 0)
+        L.kr_gemm_bf16(16, 100, 16, 0, 0, 0, 16, 128, 4, 128, 100, 0, 0, 0)
     with pytest.raises(KarantaHipError, match="1..16"):
         L.kr_gemv_bf16(16, 64, 16, 0, 0, 0, 16, 0, 64, 17, 64, 64, 0, 0, 0.0, 0)
     with pytest.raises(KarantaHipError, match="hd=64"):

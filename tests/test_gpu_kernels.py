@@ -11,9 +11,9 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from karanta_ocr_amd import positions as POS  # noqa: E402
-from karanta_ocr_amd._lib import (EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL, KarantaHipError, lib,  # noqa: E402
-                                  ptr)
-from karanta_ocr_amd.weights import bf16_round  # noqa: E402
+from karanta_ocr_amd._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU, EPI_GELU_ERF, EPI_NONE,  # noqa: E402
+                                  EPI_QUICK_GELU, EPI_SILU_MUL, KarantaHipError, lib, ptr)
+from karanta_ocr_amd.weights import bf16_round, pack_w16x64  # noqa: E402
 from oracle import qwen2vl_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
@@ -179,17 +179,17 @@ def ref_linear(A, W, bias=None, res=None, epi=EPI_NONE):
     return acc.astype(np.float32)
 
 
-def run_gemm(L, A, W, bias=None, res=None, epi=EPI_NONE, lda_pad=0):
+def run_gemm(L, A, W, bias=None, res=None, epi=EPI_NONE, lda_pad=0, packed=False):
     M, K = A.shape
     N = W.shape[0]
     Ad = dev_bf16(np.concatenate([A, np.zeros((M, lda_pad), np.float32)], 1)) if lda_pad else dev_bf16(A)
-    Wd = dev_bf16(W)
+    Wd = dev_bf16(pack_w16x64(W) if packed else W)
     nc = N // 2 if epi == EPI_SILU_MUL else N
     Cd = torch.full((M, nc), 9.0, dtype=torch.bfloat16, device=DEV)
     bd = dev_bf16(bias) if bias is not None else None
     rd = dev_bf16(res) if res is not None else None
     L.kr_gemm_bf16(ptr(Ad), K + lda_pad, ptr(Wd), ptr(bd), ptr(rd), nc if res is not None else 0, ptr(Cd), nc, M, N, K,
-                   epi, 0)
+                   epi, 1 if packed else 0, 0)
     return host(Cd)
 
 
@@ -233,19 +233,33 @@ def test_gemm_silu_mul_interleaved(L):
     assert_close_bf16(got, ref_linear(A, Wp, epi=EPI_SILU_MUL), what="gemm silu_mul")
 
 
+@pytest.mark.parametrize("M,N,K", [(129, 144, 192), (300, 272, 64)])
+def test_gemm_packed_weights_exact(L, M, N, K):
+    rng = np.random.default_rng(M + N + K + 1)
+    A, W = ints(rng, M, K), ints(rng, N, K)
+    np.testing.assert_array_equal(run_gemm(L, A, W, packed=True), ref_linear(A, W))
+
+
+def test_gemm_packed_silu(L):
+    rng = np.random.default_rng(22)
+    M, ff, K = 150, 512, 256
+    A, Wp = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5)
+    assert_close_bf16(run_gemm(L, A, Wp, epi=EPI_SILU_MUL, packed=True), ref_linear(A, Wp, epi=EPI_SILU_MUL), what="packed silu")
+
+
 def test_gemm_in_place_residual(L):
     rng = np.random.default_rng(21)
     M, N, K = 130, 256, 128
     A, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
     Xd = dev_bf16(X)
     Ad, Wd = dev_bf16(A), dev_bf16(W)
-    L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, ptr(Xd), N, ptr(Xd), N, M, N, K, EPI_NONE, 0)
+    L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, ptr(Xd), N, ptr(Xd), N, M, N, K, EPI_NONE, 0, 0)
     assert_close_bf16(host(Xd), ref_linear(A, W, res=X), what="in-place residual")
 
 
 def test_gemm_rejects_bad_shapes(L):
     with pytest.raises(KarantaHipError):
-        L.kr_gemm_bf16(256, 100, 256, 0, 0, 0, 256, 128, 4, 128, 100, 0, 0)
+        L.kr_gemm_bf16(256, 100, 256, 0, 0, 0, 256, 128, 4, 128, 100, 0, 0, 0)
 
 
 # ----------------------------------------------------------------------------- GEMV
@@ -516,6 +530,194 @@ def test_decode_prep_and_attention(L, H, KVH, ctxs):
         vv = np.concatenate([vc[b, :, :c], v[b][:, None]], 1)
         ref = np_attention(got_q[b][:, None], kk, vv, scale, False)
         assert_close_bf16(got_o[b:b + 1], ref, rel=2 ** -6, abs_=2e-2, what=f"decode attention b={b}")
+
+
+# ----------------------------------------------------------------------------- fused decode step kernels
+def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False, extra=None):
+    M, K = x.shape
+    N = W.shape[0]
+    nc = N // 2 if mode == DEC_SILU else N
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    out = torch.full((M, nc), 9.0, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    bd = dev_bf16(bias) if bias is not None else None
+    rd = dev_bf16(res) if res is not None else None
+    nd = dev_bf16(norm_w) if norm_w is not None else None
+    groups = N // 16
+    ws = torch.zeros(groups * max(ksplit, 1) * 2 * 256, dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(groups, dtype=torch.int32, device=DEV)
+    L.kr_linear_decode(mode, ptr(xd), K, ptr(Wd), ptr(bd), ptr(nd), 1e-6, ptr(rd), nc if res is not None else 0,
+                       0 if f32 else ptr(out), ptr(out) if f32 else 0, nc, M, N, K, ksplit, ptr(ws), ptr(cnt),
+                       0, 0, 0, 0, 0, 0, 0, 64, 0, 0, 0)
+    res_ = host(out)
+    assert not cnt.cpu().numpy().any(), "arrival counters must be left at zero"
+    return res_
+
+
+@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("N,K,ksplit", [(16, 64, 1), (48, 256, 1), (48, 256, 4), (1536, 1536, 3), (96, 8960, 4), (96, 8960, 7),
+                                        (16 * 2 * 1024 + 16, 128, 1)])
+def test_linear_decode_plain_exact_on_integers(L, M, N, K, ksplit):
+    rng = np.random.default_rng(M + N + K + ksplit)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    if K > 256:
+        keep = rng.choice(K, 200, replace=False)
+        mask = np.zeros(K, bool); mask[keep] = True
+        W[:, ~mask] = 0
+    np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit), ref_linear(x, W))
+
+
+def test_linear_decode_k_order(L):
+    N, K = 32, 512
+    W = ((np.arange(N)[:, None] * 3 + np.arange(K)[None, :]) % 13).astype(np.float32)
+    for k0 in (0, 7, 8, 15, 16, 63, 64, 130, 511):
+        x = np.zeros((2, K), np.float32); x[0, k0] = 1; x[1, (k0 + 1) % K] = 2
+        np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, ksplit=2), ref_linear(x, W))
+
+
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_linear_decode_bias_residual_norm(L, ksplit):
+    rng = np.random.default_rng(50 + ksplit)
+    M, N, K = 8, 512, 1536
+    x, W = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
+    bias, res, nw = rnd(rng, N, scale=0.1), rnd(rng, M, N), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, bias=bias, res=res, norm_w=nw),
+                      ref_linear(xn, W, bias, res), what="dec plain norm+bias+res")
+    got32 = run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, f32=True)
+    np.testing.assert_allclose(got32, ref_linear(x, W), atol=3e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,K", [(8, 1536), (16, 3584), (3, 256)])
+def test_linear_decode_silu_norm(L, M, K):
+    rng = np.random.default_rng(60 + M)
+    ff = 1024
+    x, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    got = run_dec(L, DEC_SILU, x, Wp, norm_w=nw)
+    assert got.shape == (M, ff)
+    assert_close_bf16(got, ref_linear(xn, Wp, epi=EPI_SILU_MUL), what="dec silu")
+
+
+def test_linear_decode_in_place_residual_splitk(L):
+    rng = np.random.default_rng(61)
+    M, N, K = 8, 256, 8960
+    a, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
+    ad, Wd, Xd = dev_bf16(a), dev_bf16(pack_w16x64(W)), dev_bf16(X)
+    ws = torch.zeros(16 * 4 * 256, dtype=torch.float32, device=DEV); cnt = torch.zeros(16, dtype=torch.int32, device=DEV)
+    for _ in range(2):  # second call reuses the (reset) counters
+        Xd = dev_bf16(X)
+        L.kr_linear_decode(DEC_PLAIN, ptr(ad), K, ptr(Wd), 0, 0, 0.0, ptr(Xd), N, ptr(Xd), 0, N, M, N, K, 4, ptr(ws), ptr(cnt),
+                           0, 0, 0, 0, 0, 0, 0, 64, 0, 0, 0)
+        assert_close_bf16(host(Xd), ref_linear(a, W, res=X), what="dec in-place split-K")
+
+
+@pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (3, 1)])
+@pytest.mark.parametrize("ksplit", [1, 2])
+def test_linear_decode_rope_kv(L, H, KVH, ksplit):
+    """Fused RMSNorm + qkv projection + bias + M-RoPE + q / K-cache / V^T-cache writes."""
+    rng = np.random.default_rng(70 + H + ksplit)
+    hd, B, s_max, K = 128, 5, 256, 256
+    N = (H + 2 * KVH) * hd
+    ctxs = np.asarray([0, 5, 63, 64, 200], np.int32)
+    x, W = rnd(rng, B, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
+    bias, nw = rnd(rng, N, scale=0.1), bf16_round(1 + 0.1 * rnd(rng, K))
+    ang = rng.uniform(0, 6.28, size=(B, 64)).astype(np.float32)
+    cs = np.concatenate([bf16_round(np.cos(ang)), bf16_round(np.sin(ang))], -1).astype(np.float32)
+    kc = rnd(rng, B, KVH, s_max, hd); vt = rnd(rng, B, KVH, s_max // 64, hd, 64)
+    kc_d, vt_d = dev_bf16(kc), dev_bf16(vt)
+    q_d = torch.zeros(B, H, hd, dtype=torch.bfloat16, device=DEV)
+    xd, Wd, bd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(bias), dev_bf16(nw)
+    cs_d, ctx_d = torch.from_numpy(cs).to(DEV), torch.from_numpy(ctxs).to(DEV)
+    ws = torch.zeros((N // 32) * ksplit * 2 * 256, dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(N // 32, dtype=torch.int32, device=DEV)
+    L.kr_linear_decode(DEC_ROPE_KV, ptr(xd), K, ptr(Wd), ptr(bd), ptr(nd), 1e-6, 0, 0, 0, 0, 0, B, N, K, ksplit, ptr(ws),
+                       ptr(cnt), ptr(cs_d), ptr(ctx_d), ptr(q_d), ptr(kc_d), ptr(vt_d), H, KVH, s_max, 0, 0, 0)
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    qkv = bf16_round(ref_linear(xn, W, bias))
+    q = qkv[:, :H * hd].reshape(B, H, hd); k = qkv[:, H * hd:(H + KVH) * hd].reshape(B, KVH, hd)
+    v = qkv[:, (H + KVH) * hd:].reshape(B, KVH, hd)
+    cos, sin = np.concatenate([cs[:, :64]] * 2, -1), np.concatenate([cs[:, 64:]] * 2, -1)
+    qr = q * cos[:, None] + O.rotate_half(q) * sin[:, None]
+    kr = k * cos[:, None] + O.rotate_half(k) * sin[:, None]
+    assert_close_bf16(host(q_d), qr, abs_=3e-2, what="fused q")
+    got_k, got_vt = host(kc_d), host(vt_d)
+    gv = got_vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd)
+    ref_v_all = vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd).copy()
+    ref_k_all = kc.copy()
+    for b, c in enumerate(ctxs):
+        assert_close_bf16(got_k[b, :, c], kr[b], abs_=3e-2, what="fused k append")
+        assert_close_bf16(gv[b, :, c], v[b], abs_=3e-2, what="fused v append")
+        ref_k_all[b, :, c] = got_k[b, :, c]
+        ref_v_all[b, :, c] = gv[b, :, c]
+    np.testing.assert_array_equal(got_k, ref_k_all)   # nothing else in the cache was touched
+    np.testing.assert_array_equal(gv, ref_v_all)
+    assert not cnt.cpu().numpy().any()
+
+
+def test_linear_decode_argmax_and_sample(L):
+    """lm_head partial argmax + kr_sample_greedy: ties -> lowest index; logits optional; bookkeeping."""
+    rng = np.random.default_rng(80)
+    B, V, d, hd = 3, 16 * 2 * 40 + 16, 256, 128     # odd tile count: last workgroup has one tile
+    x, W = ints(rng, B, d), ints(rng, V, d)
+    W[:, 200:] = 0
+    nw = np.ones(d, np.float32)
+    logits_ref = ref_linear(bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16"))), W)
+    xd, Wd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw)
+    n_part = (V // 16 + 1) // 2
+    av = torch.zeros(B, n_part, dtype=torch.float32, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
+    lg = torch.zeros(B, V, dtype=torch.float32, device=DEV)
+    L.kr_linear_decode(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, ptr(lg), V, B, V, d, 1, 0, 0,
+                       0, 0, 0, 0, 0, 0, 0, 64, ptr(av), ptr(ai), 0)
+    got = host(lg)
+    np.testing.assert_allclose(got, logits_ref, atol=2e-2, rtol=1e-2)
+    table = rnd(rng, V, d); td = dev_bf16(table)
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.full((4, 4), -1, dtype=torch.int32, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV); ctx = torch.tensor([10, 20, 30], dtype=torch.int32, device=DEV)
+    fin = torch.zeros(B, dtype=torch.int32, device=DEV); eos = torch.tensor([-5], dtype=torch.int32, device=DEV)
+    xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
+    delta = torch.tensor([-3, 0, 7], dtype=torch.int32, device=DEV)
+    inv = POS.rope_inv_freq(hd, 1e6); inv_d = torch.from_numpy(inv).to(DEV)
+    cs = torch.zeros(B, hd, dtype=torch.float32, device=DEV)
+    L.kr_sample_greedy(ptr(av), ptr(ai), n_part, ptr(td), d, ptr(tok), ptr(hist), 4, ptr(step), ptr(ctx), ptr(fin), ptr(eos), 1,
+                       0, 0, ptr(xn), ptr(delta), ptr(inv_d), ptr(cs), hd, B, 0)
+    torch.cuda.synchronize()
+    want = got.argmax(1)           # numpy argmax = lowest index among ties (integer logits tie often)
+    np.testing.assert_array_equal(tok.cpu().numpy(), want)
+    np.testing.assert_array_equal(hist.cpu().numpy()[0, :3], want)
+    assert ctx.cpu().tolist() == [11, 21, 31] and int(step.item()) == 1
+    np.testing.assert_array_equal(host(xn), table[want])
+    for b, p in enumerate([11 - 3, 21, 31 + 7]):
+        ang = np.float32(p) * inv
+        np.testing.assert_allclose(cs.cpu().numpy()[b, :64], bf16_round(np.cos(ang).astype(np.float32)), atol=8e-3)
+        np.testing.assert_allclose(cs.cpu().numpy()[b, 64:], bf16_round(np.sin(ang).astype(np.float32)), atol=8e-3)
+
+
+@pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4)])
+@pytest.mark.parametrize("n_split", [1, 4, 8])
+def test_attn_decode_fused(L, H, KVH, n_split):
+    rng = np.random.default_rng(H * 10 + n_split)
+    hd, s_max = 128, 2048
+    ctxs = [0, 64, 100, 1279, 2047]
+    B = len(ctxs)
+    kc = np.zeros((B, KVH, s_max, hd), np.float32); vc = np.zeros((B, KVH, s_max, hd), np.float32)
+    for b, c in enumerate(ctxs):
+        kc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
+        vc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
+    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    q = rnd(rng, B, H, hd)
+    kc_d, vt_d, q_d = dev_bf16(kc), dev_bf16(vt), dev_bf16(q)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(B * H * n_split * (hd + 2), dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(B * KVH, dtype=torch.int32, device=DEV)
+    o_d = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):
+        L.kr_attn_decode_fused(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), ptr(o_d), ptr(ws), ptr(cnt), B, H, KVH, hd, s_max,
+                               n_split, hd ** -0.5, 0)
+    got = host(o_d)
+    assert not cnt.cpu().numpy().any()
+    for b, c in enumerate(ctxs):
+        ref = np_attention(q[b][:, None], kc[b, :, :c + 1], vc[b, :, :c + 1], hd ** -0.5, False)
+        assert_close_bf16(got[b:b + 1], ref, rel=2 ** -6, abs_=2e-2, what=f"fused decode attention b={b}")
 
 
 def test_graph_capture_and_replay(L):

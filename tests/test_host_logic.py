@@ -155,18 +155,34 @@ def test_weight_arena_packing_on_cpu():
     import unittest.mock as mock
     with mock.patch("torch.cuda.synchronize"):
         dw.load(w)
+    from karanta_ocr_amd.weights import pack_w16x64, unpack_w16x64
+
     t = cfg.text
-    gu = dw.view("llm.1.gate_up.w").float().numpy()
+    gu = unpack_w16x64(dw.view("llm.1.gate_up.w").float().numpy())
     g, u = w["model.language_model.layers.1.mlp.gate_proj.weight"], w["model.language_model.layers.1.mlp.up_proj.weight"]
     np.testing.assert_array_equal(gu[0:16], g[0:16])
     np.testing.assert_array_equal(gu[16:32], u[0:16])
     np.testing.assert_array_equal(gu[32:48], g[16:32])
-    qkv = dw.view("llm.0.qkv.w").float().numpy()
+    qkv = unpack_w16x64(dw.view("llm.0.qkv.w").float().numpy())
     np.testing.assert_array_equal(qkv[: t.q_dim], w["model.language_model.layers.0.self_attn.q_proj.weight"])
     np.testing.assert_array_equal(qkv[t.q_dim + t.kv_dim:], w["model.language_model.layers.0.self_attn.v_proj.weight"])
     pe = dw.view("vit.patch").float().numpy()
     assert pe.shape == (cfg.vision.embed_dim, 1216)
     np.testing.assert_array_equal(pe[:, :1176], w["model.visual.patch_embed.proj.weight"].reshape(cfg.vision.embed_dim, -1))
     assert not pe[:, 1176:].any()
-    # tied lm_head aliases the embedding table
-    assert dw.view("llm.lm_head").data_ptr() == dw.view("llm.embed").data_ptr()
+    # tied lm_head: a packed copy of the embedding table (the table itself stays row-major for the gather)
+    emb = w["model.language_model.embed_tokens.weight"]
+    np.testing.assert_array_equal(dw.view("llm.embed").float().numpy(), emb)
+    np.testing.assert_array_equal(unpack_w16x64(dw.view("llm.lm_head").float().numpy()), emb)
+
+
+def test_pack_w16x64_layout():
+    from karanta_ocr_amd.weights import pack_w16x64, unpack_w16x64
+
+    w = np.arange(32 * 128, dtype=np.float32).reshape(32, 128)
+    p = pack_w16x64(w).reshape(-1)
+    # tile (row group 1, k chunk 1) starts at ((1*2)+1)*1024; its row 3, column 5 is w[16+3, 64+5]
+    assert p[3 * 1024 + 3 * 64 + 5] == w[19, 69]
+    np.testing.assert_array_equal(unpack_w16x64(pack_w16x64(w)), w)
+    with pytest.raises(ValueError):
+        pack_w16x64(np.zeros((8, 64), np.float32))
