@@ -208,15 +208,20 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
 /* ------------------------------------------------------------------ fused decode step (5 launches per layer + 2)
  * Decode linears over PACKED weights: W[N][K] stored as [N/16][K/64][16][64] bf16 tiles, so the
  * matrix is read from HBM as one linear stream (each wave-instruction pair = one contiguous 2 KiB
- * block).  y[M<=16, N] = epi(x W^T); optional fused Qwen2VLRMSNorm on x (norm_w, K <= 4096);
- * ksplit > 1 splits K over workgroups with a deterministic in-launch reduction (ws: f32
- * [N/16][ksplit][256] slabs, counters: int32 [N/16], zero-initialised, left zero).
+ * block).  y[M<=16, N] = epi(x W^T).  K is split over the `waves` (4, 8 or 16) waves of a
+ * workgroup; ksplit > 1 additionally splits K over workgroups with a deterministic in-launch
+ * reduction (ws: f32 [N/16][ksplit][256] slabs, counters: int32 [N/16], zero-initialised, left
+ * zero).  Prologues: Qwen2VLRMSNorm on x (norm_w, K <= 4096), or x = merge of the decode
+ * attention partials (attn_partials [M][K/128][attn_split][130] f32 as kr_attn_decode_fused
+ * leaves them with out == NULL; x itself may then be NULL).
  * mode 0 PLAIN   : +bias, +residual, bf16 `out` or fp32 `out_f32` [M, ldc]      (o_proj, down_proj)
  *      1 SILU    : silu(gate)*up, rows interleaved in 16-row groups, out [M, N/2] (gate/up)
- *      2 ROPE_KV : fused q/k/v projection (+bias) -> M-RoPE with cs_table (fp32 [M][128]: cos[0..64),
- *                  sin[0..64) of each row's position) -> q_out [M, heads, 128]; k -> kcache row
- *                  ctx_len[b]; v -> vtcache column ctx_len[b] (cache pointers = this layer's base,
- *                  layout as kr_decode_qkv_prep).  head_dim 128 only.          (TF:469-556, :180-222)
+ *      2 ROPE_KV : fused q/k/v projection (+bias) -> M-RoPE -> q_out [M, heads, 128]; k -> kcache
+ *                  row ctx_len[b]; v -> vtcache column ctx_len[b] (cache pointers = this layer's
+ *                  base, layout as kr_decode_qkv_prep).  cos/sin come from cs_table
+ *                  [M][cs_stride][128] fp32 (cos[0..64), sin[0..64)), entry ctx_len[b] -
+ *                  prompt_len[b] = index of the decode position.  head_dim 128 only.
+ *                  (TF:469-556, :180-222)
  *      3 ARGMAX  : lm_head: per-workgroup (max, lowest index) partials amax_val/amax_idx
  *                  [M][ceil(N/32)]; fp32 logits also written when out_f32 != NULL   (TF:1320-1323) */
 #define KR_DEC_PLAIN 0
@@ -225,29 +230,29 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
 #define KR_DEC_ARGMAX 3
 int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                      const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
-                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int ksplit,
-                     float* ws, int32_t* counters,
-                     const float* cs_table, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
-                     kr_bf16* vtcache, int heads, int kv_heads, int s_max,
+                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
+                     float* ws, int32_t* counters, const float* attn_partials, int attn_split,
+                     const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
+                     kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
                      float* amax_val, int32_t* amax_idx, kr_stream s);
 
-/* kr_attn_decode_gqa with the split merge done in-launch by the last-arriving workgroup
- * (workspace: fp32 batch*heads*n_split*(hd+2); counters: int32 [batch*kv_heads], zero-initialised).
- * kcache / vtcache are the layer's base pointers. */
+/* Decode attention (q_len 1, GQA, MFMA, split over n_split key ranges), kcache / vtcache = the
+ * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+2] partials (o, m, l).
+ * out != NULL: the splits are merged in-launch by the last-arriving workgroup (counters: int32
+ * [batch*kv_heads], zero-initialised, left zero) and written as bf16 [batch, heads*hd].
+ * out == NULL: only the partials are produced; the consumer merges them (kr_linear_decode). */
 int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache,
                          const int32_t* ctx_len, kr_bf16* out, float* workspace, int32_t* counters,
                          int batch, int heads, int kv_heads, int hd, int s_max, int n_split,
                          float scale, kr_stream s);
 
-/* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out / history
- * (as kr_argmax_embed), EOS / pad handling, ctx_len[b] += 1, embedding gather into x_next, step
- * counter, and the rotary table of the NEXT decode step: cs_table[b] = bf16(cos / sin((ctx_len[b] +
- * rope_delta[b]) * inv_freq[i])) — one evaluation per step instead of one per layer. */
+/* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out[b] and
+ * history[(ctx_len[b] + 1 - prompt_len[b]) * hist_stride + b] (= this sequence's generated-token
+ * index), EOS / pad handling as kr_argmax_embed, ctx_len[b] += 1, embedding gather into x_next. */
 int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part,
                      const kr_bf16* embed_table, int d, int32_t* tokens_out, int32_t* history,
-                     int hist_stride, int32_t* step_ptr, int32_t* ctx_len, int32_t* finished,
+                     int hist_stride, const int32_t* prompt_len, int32_t* ctx_len, int32_t* finished,
                      const int32_t* eos, int n_eos, int pad_id, int ignore_eos, kr_bf16* x_next,
-                     const int32_t* rope_delta, const float* inv_freq, float* cs_table, int hd,
                      int batch, kr_stream s);
 
 /* ------------------------------------------------------------------ multi-GPU: one-time weight broadcast (RCCL)
@@ -264,6 +269,9 @@ int kr_bcast_weights(void* comm, void* buf, size_t bytes, int root, kr_stream s)
 /* ------------------------------------------------------------------ device self-tests (used by tests/ -m gpu) */
 /* Runs an MFMA lane-layout check (A=I, asymmetric B) on the device; returns 0 if exact. */
 int kr_selftest_mfma(kr_stream s);
+/* Diagnostic: microseconds per kernel of a dependent chain of `n` tiny kernels (`blocks` x 256
+ * threads; dirty != 0: each block also writes 4 KiB) replayed from a hipGraph on stream `s`. */
+int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, float* us_per_kernel);
 
 #ifdef __cplusplus
 }

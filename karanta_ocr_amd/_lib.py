@@ -54,16 +54,16 @@ SIGNATURES = {
     "kr_attn_decode_gqa": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
     "kr_argmax_embed": [c_p, i64, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, i32, c_p],
     "kr_argmax": [c_p, i64, i32, c_p, i32, c_p],
-    "kr_linear_decode": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, c_p, c_p,
-                         c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p],
+    "kr_linear_decode": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p,
+                         c_p, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
-    "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p,
-                         c_p, i32, i32, c_p],
+    "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
     "kr_comm_unique_id": [c_p],
     "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],
     "kr_comm_destroy": [c_p],
     "kr_bcast_weights": [c_p, c_p, C.c_size_t, i32, c_p],
     "kr_selftest_mfma": [c_p],
+    "kr_probe_launch_floor": [c_p, i32, i32, i32, C.POINTER(f32)],
 }
 _RESTYPES = {"kr_last_error": C.c_char_p}
 

@@ -3,18 +3,23 @@
 //   dec_linear_kernel   y[M<=16, N] = epi(x W^T): the weight matrix is read from HBM exactly once, as
 //                       one linear stream — weights are stored PACKED in [N/16][K/64][16][64] tiles so
 //                       every wave-instruction pair fetches one contiguous 2 KiB block; K is split over
-//                       the 4 waves of a workgroup and, for narrow N, over several workgroups with a
-//                       deterministic in-launch reduction (slabs + arrival counter, agent-scope
-//                       release/acquire).  Fused prologue: Qwen2VLRMSNorm.  Fused epilogues:
+//                       the 4 / 8 / 16 waves of a workgroup (narrow layers get more waves per workgroup
+//                       instead of a cross-workgroup split: every fence / atomic hop between workgroups
+//                       costs microseconds, measured, and a decode step is a chain of 142 launches).
+//                       An optional cross-workgroup split-K with a deterministic in-launch reduction
+//                       (slabs + arrival counter, agent-scope release/acquire) is kept for wide-K shapes.
+//                       Fused prologues: Qwen2VLRMSNorm, or the merge of the attention split partials.
+//                       Fused epilogues:
 //                         PLAIN   (+bias, +residual, bf16 or fp32 out)        o_proj, down_proj
 //                         SILU    silu(gate)*up                              gate/up projection
 //                         ROPE_KV +bias, M-RoPE, q -> q buffer, k/v -> KV cache (V transposed)
 //                         ARGMAX  per-workgroup (max, index) partials [+ fp32 logits]   lm_head
-//   attn_decode2_kernel split-KV MFMA attention with the cross-workgroup merge done in-launch by the
+//   attn_decode2_kernel split-KV MFMA attention; the split partials are merged either by the consumer
+//                       (the o_proj prologue, out == NULL: the engine's path) or in-launch by the
 //                       last-arriving workgroup of each (sequence, kv head).
 //   sample_greedy_kernel final argmax over the lm_head partials, token history, EOS bookkeeping,
-//                       next-token embedding gather, context advance, and the rotary table of the
-//                       NEXT step (one cos/sin evaluation per step instead of one per layer).
+//                       next-token embedding gather, context advance.  (The rotary table of every
+//                       decode position is built once per request on the host.)
 #include "kr_common.h"
 
 namespace {
@@ -30,8 +35,12 @@ struct DecLinArgs {
     kr_bf16* out; float* out_f32; int64_t ldc;
     int M, N, K, ksplit;
     float* ws; int* counters;          // split-K slabs [groups][ksplit][NT][256] f32, arrival counters [groups]
+    // x = merge of attention partials [M][heads][n_split][130] f32 (xmode 3)
+    const float* attn_ws; int attn_split;
+    int xmode;                         // 0: x straight from global, 1: LDS stage, 2: LDS stage + RMSNorm, 3: attention merge
     // ROPE_KV
-    const float* cs_table;             // [M][hd]: cos[0..hd/2) then sin[0..hd/2) of the row's position (bf16 values)
+    const float* cs_table;             // [M][cs_stride][128]: cos[0..64) then sin[0..64) per decode position (bf16 values)
+    const int32_t* prompt_len; int cs_stride;
     const int32_t* ctx_len;
     kr_bf16* q_out; kr_bf16* kcache; kr_bf16* vtcache;
     int heads, kv_heads, s_max;
@@ -43,10 +52,11 @@ __device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
 }
 
-template <int NT, int EPI>
-__global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
+template <int NT, int EPI, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int U = 8 / NT;  // chunks (64 k) in flight per wave: 16 x 16-byte loads outstanding
+    constexpr int NTHR = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -66,7 +76,7 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
     const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
     const int nblk = cb1 - cb0;
-    const int per = (nblk + 3) >> 2;
+    const int per = (nblk + WAVES - 1) / WAVES;
     const int c0 = min(cb0 + wave * per, cb1), c1 = min(c0 + per, cb1);
 
     const kr_bf16* wp[NT];
@@ -88,12 +98,13 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
         }
     }
 
-    // ---- x slice -> LDS (RMS-normalised on the way when norm_w is given)
+    // ---- x slice -> LDS (RMS-normalised, or merged from the attention partials, on the way)
+    const bool xlds = a.xmode != 0;
     const int xrow = nblk * 128 + 16;
-    float* red = reinterpret_cast<float*>(smem + ((M * xrow + 127) & ~127));  // [4][NT][64][4]
-    if (a.norm_w) {
+    float* red = reinterpret_cast<float*>(smem + (xlds ? ((M * xrow + 127) & ~127) : 0));  // [WAVES][NT][64][4]
+    if (a.xmode == 2) {
         const int kc = K >> 3;
-        for (int b = wave; b < M; b += 4) {
+        for (int b = wave; b < M; b += WAVES) {
             bf16x8 v[8];
             float ss = 0.f;
 #pragma unroll
@@ -119,16 +130,52 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
                 }
             }
         }
-    } else {
+        __syncthreads();
+    } else if (a.xmode == 1) {
         const int cpr = nblk * 8;  // 16-byte chunks per row slice
-        for (int i = tid; i < M * cpr; i += 256) {
+        for (int i = tid; i < M * cpr; i += NTHR) {
             const int b = i / cpr, c = i - b * cpr;
             *reinterpret_cast<bf16x8*>(smem + b * xrow + c * 16) = ld8(a.x + (int64_t)b * a.ldx + (cb0 * 8 + c) * 8);
         }
+        __syncthreads();
+    } else if (a.xmode == 3) {
+        // x[b][h*128 + d] = sum_p o_p[d] * 2^(m_p - m) / sum_p l_p * 2^(m_p - m): the split-KV merge of
+        // the decode attention, done here instead of in a kernel of its own (K = heads * 128).
+        const int ns = a.attn_split, nbh = M * (K >> 7);
+        float* wts = red;  // [nbh][ns] scratch, consumed before `red` is used for the K reduction
+        for (int bh = tid; bh < nbh; bh += NTHR) {
+            const float* w = a.attn_ws + (int64_t)bh * ns * 130;
+            float mm = -1e30f;
+            for (int p = 0; p < ns; ++p) mm = fmaxf(mm, w[p * 130 + 128]);
+            float ll = 0.f;
+            for (int p = 0; p < ns; ++p) ll += w[p * 130 + 129] * __builtin_amdgcn_exp2f(w[p * 130 + 128] - mm);
+            const float inv = ll > 0.f ? 1.0f / ll : 0.f;
+            for (int p = 0; p < ns; ++p) wts[bh * ns + p] = __builtin_amdgcn_exp2f(w[p * 130 + 128] - mm) * inv;
+        }
+        __syncthreads();
+        const int cpr = K >> 3;
+        for (int i = tid; i < M * cpr; i += NTHR) {
+            const int b = i / cpr, c = i - b * cpr;  // chunk c of row b: head c>>4, d = (c&15)*8
+            if (c < cb0 * 8 || c >= cb1 * 8) continue;
+            const int bh = b * (K >> 7) + (c >> 4);
+            const float* w = a.attn_ws + (int64_t)bh * ns * 130 + (c & 15) * 8;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < ns; ++p) {
+                const float wp_ = wts[bh * ns + p];
+                const float* o = w + p * 130;  // 130-float records: 8-byte aligned only
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += o[j] * wp_;
+            }
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = f2bf(acc[j]);
+            *reinterpret_cast<bf16x8*>(smem + b * xrow + (c - cb0 * 8) * 16) = ov;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 32;
+    const kr_bf16* xg = a.x + (int64_t)(fr < M ? fr : 0) * a.ldx + fg * 16;
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -137,8 +184,14 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
         for (int u = 0; u < U; ++u) {
             const int c = cc + u;
             if (c < c1) {
-                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
-                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 16);
+                bf16x8 x0, x1;
+                if (xlds) {
+                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
+                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 16);
+                } else {
+                    x0 = ld8(xg + c * 64);
+                    x1 = ld8(xg + c * 64 + 8);
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][0], x0, acc[t], 0, 0, 0);
@@ -156,7 +209,8 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
         }
     }
 
-    // ---- reduce the 4 waves' K slices through LDS; wave 0 owns the rest
+    // ---- reduce the waves' K slices through LDS; wave 0 owns the rest
+    if (a.xmode == 3) __syncthreads();  // `red` doubled as the merge-weight scratch
 #pragma unroll
     for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
     __syncthreads();
@@ -166,7 +220,7 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
     for (int t = 0; t < NT; ++t) {
         sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
@@ -252,7 +306,7 @@ __global__ void __launch_bounds__(256) dec_linear_kernel(const DecLinArgs a) {
         }
         const int pos = a.ctx_len[b];
         if (hh < a.heads + a.kv_heads) {
-            const float* cs = a.cs_table + b * 128;
+            const float* cs = a.cs_table + ((int64_t)b * a.cs_stride + (pos - a.prompt_len[b])) * 128;
             bf16x4 o0, o1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -422,7 +476,7 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
             acc += o_s[w][gg][d] * sc;
             ll += l_s[w][gg] * sc;
         }
-        if (n_split == 1) {
+        if (n_split == 1 && out) {
             out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
         } else {
             float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * (HD + 2);
@@ -433,7 +487,7 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
             }
         }
     }
-    if (n_split == 1) return;
+    if (n_split == 1 || !out) return;  // out == NULL: the consumer (o_proj prologue) merges the partials
     // ---- cross-workgroup merge by the last arriver (agent-scope release / acquire)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -472,13 +526,10 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
                                                             const int32_t* __restrict__ amax_idx, int n_part,
                                                             const kr_bf16* __restrict__ table, int d,
                                                             int32_t* __restrict__ tokens_out, int32_t* __restrict__ history,
-                                                            int hist_stride, int32_t* __restrict__ step_ptr,
+                                                            int hist_stride, const int32_t* __restrict__ prompt_len,
                                                             int32_t* __restrict__ ctx_len, int32_t* __restrict__ finished,
                                                             const int32_t* __restrict__ eos, int n_eos, int pad_id,
-                                                            int ignore_eos, kr_bf16* __restrict__ x_next,
-                                                            const int32_t* __restrict__ rope_delta,
-                                                            const float* __restrict__ inv_freq, float* __restrict__ cs_table,
-                                                            int half) {
+                                                            int ignore_eos, kr_bf16* __restrict__ x_next) {
     __shared__ float s_v[4];
     __shared__ int s_i[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -503,12 +554,11 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
     int tok = bi;
     const int was_finished = finished[b];
     if (was_finished && !ignore_eos) tok = pad_id;
-    const int step = step_ptr[0];
-    const int new_ctx = ctx_len[b] + 1;
+    const int new_ctx = ctx_len[b] + 1;  // tokens cached once the sampled token has been fed back
     __syncthreads();
     if (tid == 0) {
         tokens_out[b] = tok;
-        history[(int64_t)step * hist_stride + b] = tok;
+        history[(int64_t)(new_ctx - prompt_len[b]) * hist_stride + b] = tok;  // generated-token index of this sequence
         ctx_len[b] = new_ctx;
         if (!ignore_eos && !was_finished) {
             int hit = 0;
@@ -517,34 +567,36 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
         }
     }
     for (int c = tid; c < (d >> 3); c += 256) st8(x_next + (int64_t)b * d + c * 8, ld8(table + (int64_t)tok * d + c * 8));
-    // rotary table of the next decode step: position = cached tokens + rope delta (TF:1124-1136),
-    // cos/sin rounded to the activation dtype (TF:169)
-    const float rp = (float)(new_ctx + rope_delta[b]);
-    for (int i = tid; i < half; i += 256) {
-        const float ang = rp * inv_freq[i];
-        cs_table[b * 2 * half + i] = bfround(cosf(ang));
-        cs_table[b * 2 * half + half + i] = bfround(sinf(ang));
-    }
 }
 
-__global__ void bump2_kernel(int32_t* p) { p[0] += 1; }
-
-template <int NT, int EPI>
+template <int NT, int EPI, int WAVES>
 int launch_dec(const DecLinArgs& a, int groups, kr_stream s) {
     const int nchunks = a.K >> 6;
     const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
-    const size_t xbytes = ((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127;
-    const size_t lds = xbytes + (size_t)4 * NT * 256 * 4;
+    const size_t xbytes = a.xmode ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
+    size_t red = (size_t)WAVES * NT * 256 * 4;
+    if (a.xmode == 3) red = red > (size_t)a.M * (a.K >> 7) * a.attn_split * 4 ? red : (size_t)a.M * (a.K >> 7) * a.attn_split * 4;
+    const size_t lds = xbytes + red;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode: needs %zu bytes of LDS (M=%d K=%d ksplit=%d)", lds, a.M, a.K, a.ksplit);
-    auto fn = &dec_linear_kernel<NT, EPI>;
+    auto fn = &dec_linear_kernel<NT, EPI, WAVES>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    fn<<<dim3(groups, a.ksplit), 256, lds, kr_hs(s)>>>(a);
+    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+template <int NT, int EPI>
+int launch_dec_w(const DecLinArgs& a, int groups, int waves, kr_stream s) {
+    switch (waves) {
+        case 4: return launch_dec<NT, EPI, 4>(a, groups, s);
+        case 8: return launch_dec<NT, EPI, 8>(a, groups, s);
+        case 16: return launch_dec<NT, EPI, 16>(a, groups, s);
+        default: kr_set_error("kr_linear_decode: waves=%d (4, 8 or 16)", waves); return KR_ERR_ARG;
+    }
 }
 
 }  // namespace
@@ -554,42 +606,53 @@ int launch_dec(const DecLinArgs& a, int groups, kr_stream s) {
 // =====================================================================================
 extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                                 const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr, kr_bf16* out,
-                                float* out_f32, int64_t ldc, int M, int N, int K, int ksplit, float* ws, int32_t* counters,
-                                const float* cs_table, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
-                                kr_bf16* vtcache, int heads, int kv_heads, int s_max, float* amax_val, int32_t* amax_idx,
-                                kr_stream s) {
-    KR_CHECK_ARG(x && w_packed, "kr_linear_decode: null pointer");
+                                float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit, float* ws,
+                                int32_t* counters, const float* attn_partials, int attn_split, const float* cs_table,
+                                int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len, kr_bf16* q_out,
+                                kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max, float* amax_val,
+                                int32_t* amax_idx, kr_stream s) {
+    KR_CHECK_ARG(w_packed && (x || attn_partials), "kr_linear_decode: null pointer");
     KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode: M=%d must be in 1..16", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 64 == 0, "kr_linear_decode: N=%d K=%d (N%%16, K%%64)", N, K);
-    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode: ldx");
+    KR_CHECK_ARG(attn_partials || (ldx >= K && (ldx & 7) == 0), "kr_linear_decode: ldx");
     KR_CHECK_ARG(ksplit >= 1 && ksplit <= (K >> 6), "kr_linear_decode: ksplit=%d", ksplit);
     KR_CHECK_ARG(ksplit == 1 || (ws && counters), "kr_linear_decode: split-K needs workspace and counters");
     KR_CHECK_ARG(!norm_w || K <= 4096, "kr_linear_decode: fused RMSNorm supports K <= 4096");
+    KR_CHECK_ARG(!(norm_w && attn_partials), "kr_linear_decode: norm and attention-merge prologues are exclusive");
+    KR_CHECK_ARG(!attn_partials || (K % 128 == 0 && attn_split >= 1 && ksplit == 1),
+                 "kr_linear_decode: attention merge needs K = heads*128, ksplit 1");
     DecLinArgs a{};
     a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias; a.norm_w = norm_w; a.norm_eps = norm_eps;
     a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.ksplit = ksplit; a.ws = ws; a.counters = counters;
-    a.cs_table = cs_table; a.ctx_len = ctx_len; a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
+    a.attn_ws = attn_partials; a.attn_split = attn_split;
+    // x staged in LDS unless the row slice is too large (wide-K layers read x fragments from L2)
+    const int cpb = ((K >> 6) + ksplit - 1) / ksplit;
+    const bool fits = (size_t)M * (cpb * 128 + 16) <= 96 * 1024;
+    a.xmode = attn_partials ? 3 : norm_w ? 2 : fits ? 1 : 0;
+    a.cs_table = cs_table; a.cs_stride = cs_stride; a.prompt_len = prompt_len; a.ctx_len = ctx_len;
+    a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
     a.heads = heads; a.kv_heads = kv_heads; a.s_max = s_max; a.amax_val = amax_val; a.amax_idx = amax_idx;
     const int ntiles = N >> 4;
     switch (mode) {
         case DEPI_PLAIN: {
             KR_CHECK_ARG((out || out_f32) && ldc >= N && (ldc & 3) == 0, "kr_linear_decode: PLAIN output");
             KR_CHECK_ARG(!residual || (ldr & 3) == 0, "kr_linear_decode: ldr");
-            if (ntiles >= 1024) return launch_dec<2, DEPI_PLAIN>(a, (ntiles + 1) / 2, s);
-            return launch_dec<1, DEPI_PLAIN>(a, ntiles, s);
+            if (ntiles >= 1024) return launch_dec_w<2, DEPI_PLAIN>(a, (ntiles + 1) / 2, waves, s);
+            return launch_dec_w<1, DEPI_PLAIN>(a, ntiles, waves, s);
         }
         case DEPI_SILU:
             KR_CHECK_ARG(out && N % 32 == 0 && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode: SILU output");
-            return launch_dec<2, DEPI_SILU>(a, ntiles / 2, s);
+            return launch_dec_w<2, DEPI_SILU>(a, ntiles / 2, waves, s);
         case DEPI_ROPE_KV:
-            KR_CHECK_ARG(bias && cs_table && ctx_len && q_out && kcache && vtcache, "kr_linear_decode: ROPE_KV pointers");
+            KR_CHECK_ARG(bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
+                         "kr_linear_decode: ROPE_KV pointers");
             KR_CHECK_ARG(N == (heads + 2 * kv_heads) * 128 && s_max % 64 == 0, "kr_linear_decode: ROPE_KV needs head_dim 128");
-            return launch_dec<2, DEPI_ROPE_KV>(a, ntiles / 2, s);
+            return launch_dec_w<2, DEPI_ROPE_KV>(a, ntiles / 2, waves, s);
         case DEPI_ARGMAX:
             KR_CHECK_ARG(amax_val && amax_idx && ksplit == 1, "kr_linear_decode: ARGMAX pointers / ksplit");
             KR_CHECK_ARG(!out_f32 || ldc >= N, "kr_linear_decode: ARGMAX logits ldc");
-            return launch_dec<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, s);
+            return launch_dec_w<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, waves, s);
         default:
             kr_set_error("kr_linear_decode: unknown mode %d", mode);
             return KR_ERR_ARG;
@@ -599,11 +662,11 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
 extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
                                     kr_bf16* out, float* workspace, int32_t* counters, int batch, int heads, int kv_heads,
                                     int hd, int s_max, int n_split, float scale, kr_stream s) {
-    KR_CHECK_ARG(q && kcache && vtcache && ctx_len && out, "kr_attn_decode_fused: null pointer");
+    KR_CHECK_ARG(q && kcache && vtcache && ctx_len && (out || workspace), "kr_attn_decode_fused: null pointer");
     KR_CHECK_ARG(hd == 128, "kr_attn_decode_fused: hd=%d (only 128)", hd);
     KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_fused: GQA group must be <= 16");
     KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
-    KR_CHECK_ARG(n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
+    KR_CHECK_ARG(!out || n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
     attn_decode2_kernel<<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
         q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
     KR_CHECK_LAUNCH();
@@ -611,20 +674,16 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
 }
 
 extern "C" int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part, const kr_bf16* embed_table,
-                                int d, int32_t* tokens_out, int32_t* history, int hist_stride, int32_t* step_ptr,
+                                int d, int32_t* tokens_out, int32_t* history, int hist_stride, const int32_t* prompt_len,
                                 int32_t* ctx_len, int32_t* finished, const int32_t* eos, int n_eos, int pad_id,
-                                int ignore_eos, kr_bf16* x_next, const int32_t* rope_delta, const float* inv_freq,
-                                float* cs_table, int hd, int batch, kr_stream s) {
-    KR_CHECK_ARG(amax_val && amax_idx && embed_table && tokens_out && history && step_ptr && ctx_len && finished &&
-                     x_next && rope_delta && inv_freq && cs_table,
+                                int ignore_eos, kr_bf16* x_next, int batch, kr_stream s) {
+    KR_CHECK_ARG(amax_val && amax_idx && embed_table && tokens_out && history && prompt_len && ctx_len && finished && x_next,
                  "kr_sample_greedy: null pointer");
-    KR_CHECK_ARG(n_part > 0 && batch > 0 && (d & 7) == 0 && hist_stride >= batch && hd % 2 == 0 && (n_eos == 0 || eos),
+    KR_CHECK_ARG(n_part > 0 && batch > 0 && (d & 7) == 0 && hist_stride >= batch && (n_eos == 0 || eos),
                  "kr_sample_greedy: bad sizes");
     sample_greedy_kernel<<<batch, 256, 0, kr_hs(s)>>>(amax_val, amax_idx, n_part, embed_table, d, tokens_out, history,
-                                                      hist_stride, step_ptr, ctx_len, finished, eos, n_eos, pad_id,
-                                                      ignore_eos, x_next, rope_delta, inv_freq, cs_table, hd / 2);
-    KR_CHECK_LAUNCH();
-    bump2_kernel<<<1, 1, 0, kr_hs(s)>>>(step_ptr);
+                                                      hist_stride, prompt_len, ctx_len, finished, eos, n_eos, pad_id,
+                                                      ignore_eos, x_next);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

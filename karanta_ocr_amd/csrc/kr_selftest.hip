@@ -69,3 +69,57 @@ extern "C" int kr_selftest_mfma(kr_stream s) {
     }
     return KR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Launch-floor probe (diagnostic, used by tools/ and tests): time a dependent chain of `n` tiny
+// kernels replayed from a hipGraph on the caller's stream; returns microseconds per kernel.
+namespace {
+__global__ void floor_tiny_kernel(int* p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1;
+}
+__global__ void floor_dirty_kernel(float4* p, int n4) {  // every block dirties 4 KiB
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) p[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+}  // namespace
+
+extern "C" int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, float* us_per_kernel) {
+    KR_CHECK_ARG(n > 0 && blocks > 0 && us_per_kernel, "kr_probe_launch_floor: bad args");
+    int* d = nullptr;
+    float4* buf = nullptr;
+    KR_CHECK_HIP(hipMalloc(&d, 4));
+    KR_CHECK_HIP(hipMalloc(&buf, (size_t)blocks * 256 * 16));
+    KR_CHECK_HIP(hipMemsetAsync(d, 0, 4, kr_hs(s)));
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    KR_CHECK_HIP(hipStreamSynchronize(kr_hs(s)));
+    KR_CHECK_HIP(hipStreamBeginCapture(kr_hs(s), hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < n; ++i) {
+        const bool use_dirty = dirty == 2 ? (i & 1) : dirty != 0;  // dirty == 2: alternate the two kernels
+        if (use_dirty)
+            floor_dirty_kernel<<<blocks, 256, 0, kr_hs(s)>>>(buf, blocks * 256);
+        else
+            floor_tiny_kernel<<<blocks, 256, 0, kr_hs(s)>>>(d);
+    }
+    KR_CHECK_HIP(hipStreamEndCapture(kr_hs(s), &g));
+    KR_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    KR_CHECK_HIP(hipEventCreate(&e0));
+    KR_CHECK_HIP(hipEventCreate(&e1));
+    KR_CHECK_HIP(hipGraphLaunch(ge, kr_hs(s)));
+    KR_CHECK_HIP(hipStreamSynchronize(kr_hs(s)));
+    KR_CHECK_HIP(hipEventRecord(e0, kr_hs(s)));
+    for (int i = 0; i < 10; ++i) KR_CHECK_HIP(hipGraphLaunch(ge, kr_hs(s)));
+    KR_CHECK_HIP(hipEventRecord(e1, kr_hs(s)));
+    KR_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    KR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_kernel = ms * 1e3f / (10.0f * n);
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d);
+    hipFree(buf);
+    return KR_OK;
+}

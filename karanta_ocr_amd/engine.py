@@ -236,24 +236,20 @@ class Engine:
         self.d_act = z(B, t.intermediate_size)
         self.d_logits = z(B, t.vocab_size, dtype=torch.float32)
         self.d_ws = z(B * t.num_heads * self.n_split * (t.head_dim + 2), dtype=torch.float32)
-        self.d_attn_cnt = z(B * t.num_kv_heads, dtype=torch.int32)
-        # split-K plan of the narrow decode linears + their slab workspace / arrival counters
-        nck = t.hidden_size // 64
-        self.ks_qkv = self._ksplit(t.qkv_dim // 32, nck)
-        self.ks_o = self._ksplit(t.hidden_size // 16, t.q_dim // 64)
-        self.ks_down = self._ksplit(t.hidden_size // 16, t.intermediate_size // 64)
-        slab = max(t.qkv_dim // 32 * self.ks_qkv * 2, t.hidden_size // 16 * max(self.ks_o, self.ks_down)) * 256
-        self.d_lin_ws = z(slab, dtype=torch.float32)
-        self.d_lin_cnt = z(max(t.qkv_dim // 32, t.hidden_size // 16), dtype=torch.int32)
+        # waves per workgroup of the narrow decode linears: enough waves that every wave still
+        # streams >= 2 K-chunks, no cross-workgroup reduction (each fence/atomic hop costs microseconds)
+        self.wv_qkv = self._waves(t.hidden_size // 64)
+        self.wv_o = self._waves(t.q_dim // 64)
+        self.wv_down = self._waves(t.intermediate_size // 64)
         self.n_amax = (t.vocab_size // 16 + 1) // 2
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
         self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
-        self.d_cs = z(B, t.head_dim, dtype=torch.float32)
+        self.d_plen = z(B, dtype=torch.int32)
+        self.d_cs = None  # [B][max_new][128] rotary table of the decode positions, built per request
         self.d_ctx = z(B, dtype=torch.int32)
         self.d_delta = z(B, dtype=torch.int32)
         self.d_tok = z(B, dtype=torch.int32)
         self.d_fin = z(B, dtype=torch.int32)
-        self.d_step = z(1, dtype=torch.int32)
         self.max_new = 0
         self.d_hist = None
         self.d_eos = torch.tensor(list(self.cfg.eos_token_ids), dtype=torch.int32, device=dev)
@@ -261,12 +257,9 @@ class Engine:
         self.d_last = z(B, dtype=torch.int32)
         torch.cuda.synchronize(dev)
 
-    def _ksplit(self, groups: int, nchunks: int, target: int = 384) -> int:
-        """K-split of a decode linear: enough workgroups to cover the 256 CUs (~target), at least two
-        64-wide K chunks per wave, and an x slice of at most 64 KiB of LDS."""
-        ks = max(1, min(int(round(target / groups)), nchunks // 8))
-        ks = max(ks, -(-self.B * nchunks * 128 // 65536))
-        return min(ks, nchunks)
+    @staticmethod
+    def _waves(nchunks: int) -> int:
+        return 16 if nchunks >= 64 else 8 if nchunks >= 16 else 4
 
     def load_weights(self, weights: Dict[str, np.ndarray]):
         self.w.load(weights)
@@ -277,23 +270,18 @@ class Engine:
         self.L.kr_gemm_bf16(ptr(A), A.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
                             ptr(C_), C_.stride(0), M, N, K, epi, 1 if packed else 0, self.s)
 
-    def _dec(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, ksplit=1, kc=0, vc=0):
-        """kr_linear_decode on packed weights."""
+    def _dec(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=4, kc=0, vc=0,
+             attn_partials=None):
+        """kr_linear_decode on packed weights (no cross-workgroup split on the engine's path)."""
         t = self.cfg.text
         N, K = W.shape
         o = out if out is not None else out_f32
-        self.L.kr_linear_decode(mode, ptr(x), x.stride(0), ptr(W), ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res),
-                                res.stride(0) if res is not None else 0, ptr(out), ptr(out_f32),
-                                o.stride(0) if o is not None else 0, M, N, K, ksplit, ptr(self.d_lin_ws),
-                                ptr(self.d_lin_cnt), ptr(self.d_cs), ptr(self.d_ctx), ptr(self.d_q), kc, vc,
-                                t.num_heads, t.num_kv_heads, self.s_max, ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
-
-    def _gemv(self, x, W, out, M, bias=None, res=None, epi=EPI_NONE, norm_w=None, out_f32=None):
-        N, K = W.shape
-        o = out if out is not None else out_f32
-        self.L.kr_gemv_bf16(ptr(x), x.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
-                            ptr(out), ptr(out_f32), o.stride(0), M, N, K, epi, ptr(norm_w),
-                            self.cfg.text.rms_norm_eps, self.s)
+        self.L.kr_linear_decode(mode, ptr(x), x.stride(0) if x is not None else 0, ptr(W), ptr(bias), ptr(norm_w),
+                                t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out), ptr(out_f32),
+                                o.stride(0) if o is not None else 0, M, N, K, waves, 1, 0, 0,
+                                ptr(attn_partials), self.n_split, ptr(self.d_cs), self.max_new, ptr(self.d_plen),
+                                ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max,
+                                ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _h2d(self, dst: torch.Tensor, arr: np.ndarray):
         src = torch.from_numpy(np.ascontiguousarray(arr))
@@ -405,16 +393,27 @@ class Engine:
         plan = POS.prefill_attn_plan(lens, list(range(B)), t.num_kv_heads, self.s_max)
         last_rows = (np.cumsum(lens) - 1).astype(np.int32)
         ctx0 = np.zeros(self.B, np.int32)
-        ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_argmax_embed adds 1 -> number of cached tokens
+        ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_sample_greedy adds 1 -> number of cached tokens
         with torch.cuda.stream(self.stream):
             self._h2d(self.p_src, src)
             self._h2d(self.p_cos, cos)
             self._h2d(self.p_sin, sin)
             self._h2d(self.d_delta, deltas)
             self._h2d(self.d_ctx, ctx0)
+            plen = np.zeros(self.B, np.int32)
+            plen[:B] = lens
+            self._h2d(self.d_plen, plen)
+            # rotary table of every decode position of every sequence: pos = P + k + delta (all three
+            # M-RoPE axes equal for generated text, TF:1124-1136), cos/sin rounded to bf16 (TF:169)
+            kk = np.arange(self.max_new, dtype=np.int64)
+            cs = np.zeros((self.B, self.max_new, t.head_dim), np.float32)
+            for b in range(B):
+                p1 = lens[b] + kk + int(deltas[b])
+                c_, s_ = POS.mrope_tables(np.stack([p1, p1, p1]), t.head_dim, t.rope_theta, t.mrope_section)
+                cs[b, :, : t.head_dim // 2], cs[b, :, t.head_dim // 2:] = c_[:, : t.head_dim // 2], s_[:, : t.head_dim // 2]
+            self._h2d(self.d_cs, cs)
             self._h2d(self.d_last, last_rows)
             self.d_fin.zero_()
-            self.d_step.zero_()
             t_ = lambda a: torch.from_numpy(a).to(dev)
             blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
             qblk, qlen = t_(plan.qblk), t_(plan.qblk_len)
@@ -450,10 +449,9 @@ class Engine:
         self._dec(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
                   out_f32=self.d_logits if self._want_logits else None)
         L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
-                           ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_step), ptr(self.d_ctx),
+                           ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_plen), ptr(self.d_ctx),
                            ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
-                           1 if self._ignore_eos else 0, ptr(self.d_x), ptr(self.d_delta), ptr(self.d_invfreq),
-                           ptr(self.d_cs), t.head_dim, B, s)
+                           1 if self._ignore_eos else 0, ptr(self.d_x), B, s)
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
@@ -467,17 +465,18 @@ class Engine:
             # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base
             kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])
             self._dec(DEC_ROPE_KV, self.d_x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
-                      ksplit=self.ks_qkv, kc=kc, vc=vc)
-            L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o), ptr(self.d_ws),
-                                   ptr(self.d_attn_cnt), B, H, KVH, hd, self.s_max, self.n_split, hd ** -0.5, s)
-            self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, ksplit=self.ks_o)
+                      waves=self.wv_qkv, kc=kc, vc=vc)
+            L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
+                                   self.s_max, self.n_split, hd ** -0.5, s)
+            self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o,
+                      attn_partials=self.d_ws)
             if self._prof_on:
                 e0, e1 = self._prof_event_pair()
                 L.kr_event_record(e0, s)
             self._dec(DEC_SILU, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
             if self._prof_on:
                 L.kr_event_record(e1, s)
-            self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, ksplit=self.ks_down)
+            self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_down)
         self._lm_head_and_sample(B)
 
     # ------------------------------------------------------------------ live kernel timing (bench.py roofline)
@@ -547,6 +546,7 @@ class Engine:
         if self.d_hist is None or self.max_new < max_new_tokens:
             self.max_new = max_new_tokens
             self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
+            self.d_cs = torch.zeros(self.B, max_new_tokens, self.cfg.text.head_dim, dtype=torch.float32, device=self.device)
             # history pointer is baked into captured graphs
             for g in self._graphs.values():
                 self.L.kr_graph_destroy(g)

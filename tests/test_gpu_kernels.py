@@ -533,7 +533,14 @@ def test_decode_prep_and_attention(L, H, KVH, ctxs):
 
 
 # ----------------------------------------------------------------------------- fused decode step kernels
-def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False, extra=None):
+def dec_call(L, mode, x, ldx, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_w=0, res=0, ldr=0, waves=4, ksplit=1, ws=0,
+             cnt=0, attn=0, attn_split=1, cs=0, cs_stride=0, plen=0, ctx=0, q_out=0, kc=0, vc=0, heads=0, kv_heads=0,
+             s_max=64, av=0, ai=0):
+    L.kr_linear_decode(mode, x, ldx, W, bias, norm_w, 1e-6, res, ldr, out, out_f32, ldc, M, N, K, waves, ksplit, ws, cnt,
+                       attn, attn_split, cs, cs_stride, plen, ctx, q_out, kc, vc, heads, kv_heads, s_max, av, ai, 0)
+
+
+def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False, waves=4):
     M, K = x.shape
     N = W.shape[0]
     nc = N // 2 if mode == DEC_SILU else N
@@ -545,45 +552,56 @@ def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False
     groups = N // 16
     ws = torch.zeros(groups * max(ksplit, 1) * 2 * 256, dtype=torch.float32, device=DEV)
     cnt = torch.zeros(groups, dtype=torch.int32, device=DEV)
-    L.kr_linear_decode(mode, ptr(xd), K, ptr(Wd), ptr(bd), ptr(nd), 1e-6, ptr(rd), nc if res is not None else 0,
-                       0 if f32 else ptr(out), ptr(out) if f32 else 0, nc, M, N, K, ksplit, ptr(ws), ptr(cnt),
-                       0, 0, 0, 0, 0, 0, 0, 64, 0, 0, 0)
+    dec_call(L, mode, ptr(xd), K, ptr(Wd), M, N, K, out=0 if f32 else ptr(out), out_f32=ptr(out) if f32 else 0, ldc=nc,
+             bias=ptr(bd), norm_w=ptr(nd), res=ptr(rd), ldr=nc if res is not None else 0, waves=waves, ksplit=ksplit,
+             ws=ptr(ws), cnt=ptr(cnt))
     res_ = host(out)
     assert not cnt.cpu().numpy().any(), "arrival counters must be left at zero"
     return res_
 
 
 @pytest.mark.parametrize("M", [1, 8, 16])
-@pytest.mark.parametrize("N,K,ksplit", [(16, 64, 1), (48, 256, 1), (48, 256, 4), (1536, 1536, 3), (96, 8960, 4), (96, 8960, 7),
-                                        (16 * 2 * 1024 + 16, 128, 1)])
-def test_linear_decode_plain_exact_on_integers(L, M, N, K, ksplit):
+@pytest.mark.parametrize("N,K,ksplit,waves", [(16, 64, 1, 4), (48, 256, 1, 8), (48, 256, 4, 4), (1536, 1536, 3, 4),
+                                              (1536, 1536, 1, 8), (96, 8960, 4, 4), (96, 8960, 1, 16), (96, 8960, 7, 8),
+                                              (16 * 2 * 1024 + 16, 128, 1, 4)])
+def test_linear_decode_plain_exact_on_integers(L, M, N, K, ksplit, waves):
     rng = np.random.default_rng(M + N + K + ksplit)
     x, W = ints(rng, M, K), ints(rng, N, K)
     if K > 256:
         keep = rng.choice(K, 200, replace=False)
         mask = np.zeros(K, bool); mask[keep] = True
         W[:, ~mask] = 0
-    np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit), ref_linear(x, W))
+    np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, waves=waves), ref_linear(x, W))
 
 
-def test_linear_decode_k_order(L):
-    N, K = 32, 512
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_linear_decode_k_order(L, waves):
+    N, K = 32, 2048
     W = ((np.arange(N)[:, None] * 3 + np.arange(K)[None, :]) % 13).astype(np.float32)
-    for k0 in (0, 7, 8, 15, 16, 63, 64, 130, 511):
+    for k0 in (0, 7, 8, 15, 16, 63, 64, 130, 511, 1999, 2047):
         x = np.zeros((2, K), np.float32); x[0, k0] = 1; x[1, (k0 + 1) % K] = 2
-        np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, ksplit=2), ref_linear(x, W))
+        np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, waves=waves), ref_linear(x, W))
 
 
-@pytest.mark.parametrize("ksplit", [1, 3])
-def test_linear_decode_bias_residual_norm(L, ksplit):
+def test_linear_decode_wide_k_reads_x_from_global(L):
+    """M*K too large for the LDS stage (xmode 0): down_proj of the 7B model at batch 16."""
+    rng = np.random.default_rng(49)
+    M, N, K = 16, 64, 18944
+    x, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    res = rnd(rng, M, N)
+    assert_close_bf16(run_dec(L, DEC_PLAIN, x, W, res=res, waves=16), ref_linear(x, W, res=res), what="dec wide K")
+
+
+@pytest.mark.parametrize("ksplit,waves", [(1, 4), (3, 4), (1, 8)])
+def test_linear_decode_bias_residual_norm(L, ksplit, waves):
     rng = np.random.default_rng(50 + ksplit)
     M, N, K = 8, 512, 1536
     x, W = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
     bias, res, nw = rnd(rng, N, scale=0.1), rnd(rng, M, N), bf16_round(1 + 0.1 * rnd(rng, K))
     xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
-    assert_close_bf16(run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, bias=bias, res=res, norm_w=nw),
+    assert_close_bf16(run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, bias=bias, res=res, norm_w=nw, waves=waves),
                       ref_linear(xn, W, bias, res), what="dec plain norm+bias+res")
-    got32 = run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, f32=True)
+    got32 = run_dec(L, DEC_PLAIN, x, W, ksplit=ksplit, f32=True, waves=waves)
     np.testing.assert_allclose(got32, ref_linear(x, W), atol=3e-3, rtol=1e-4)
 
 
@@ -604,39 +622,43 @@ def test_linear_decode_in_place_residual_splitk(L):
     a, W, X = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, M, N)
     ad, Wd, Xd = dev_bf16(a), dev_bf16(pack_w16x64(W)), dev_bf16(X)
     ws = torch.zeros(16 * 4 * 256, dtype=torch.float32, device=DEV); cnt = torch.zeros(16, dtype=torch.int32, device=DEV)
-    for _ in range(2):  # second call reuses the (reset) counters
+    for ksplit, waves in ((4, 4), (4, 4), (1, 16)):  # the repeated call reuses the (reset) counters
         Xd = dev_bf16(X)
-        L.kr_linear_decode(DEC_PLAIN, ptr(ad), K, ptr(Wd), 0, 0, 0.0, ptr(Xd), N, ptr(Xd), 0, N, M, N, K, 4, ptr(ws), ptr(cnt),
-                           0, 0, 0, 0, 0, 0, 0, 64, 0, 0, 0)
-        assert_close_bf16(host(Xd), ref_linear(a, W, res=X), what="dec in-place split-K")
+        dec_call(L, DEC_PLAIN, ptr(ad), K, ptr(Wd), M, N, K, out=ptr(Xd), ldc=N, res=ptr(Xd), ldr=N, waves=waves,
+                 ksplit=ksplit, ws=ptr(ws), cnt=ptr(cnt))
+        assert_close_bf16(host(Xd), ref_linear(a, W, res=X), what="dec in-place")
 
 
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (3, 1)])
-@pytest.mark.parametrize("ksplit", [1, 2])
-def test_linear_decode_rope_kv(L, H, KVH, ksplit):
+@pytest.mark.parametrize("ksplit,waves", [(1, 4), (2, 4), (1, 8)])
+def test_linear_decode_rope_kv(L, H, KVH, ksplit, waves):
     """Fused RMSNorm + qkv projection + bias + M-RoPE + q / K-cache / V^T-cache writes."""
     rng = np.random.default_rng(70 + H + ksplit)
-    hd, B, s_max, K = 128, 5, 256, 256
+    hd, B, s_max, K, T = 128, 5, 256, 1024, 7
     N = (H + 2 * KVH) * hd
-    ctxs = np.asarray([0, 5, 63, 64, 200], np.int32)
+    plen = np.asarray([0, 3, 60, 64, 198], np.int32)
+    step = np.asarray([0, 2, 3, 0, 6], np.int32)       # index of the decode position of each row
+    ctxs = plen + step
     x, W = rnd(rng, B, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
     bias, nw = rnd(rng, N, scale=0.1), bf16_round(1 + 0.1 * rnd(rng, K))
-    ang = rng.uniform(0, 6.28, size=(B, 64)).astype(np.float32)
-    cs = np.concatenate([bf16_round(np.cos(ang)), bf16_round(np.sin(ang))], -1).astype(np.float32)
+    ang = rng.uniform(0, 6.28, size=(B, T, 64)).astype(np.float32)
+    cs = np.concatenate([bf16_round(np.cos(ang)), bf16_round(np.sin(ang))], -1).astype(np.float32)  # [B,T,128]
     kc = rnd(rng, B, KVH, s_max, hd); vt = rnd(rng, B, KVH, s_max // 64, hd, 64)
     kc_d, vt_d = dev_bf16(kc), dev_bf16(vt)
     q_d = torch.zeros(B, H, hd, dtype=torch.bfloat16, device=DEV)
     xd, Wd, bd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(bias), dev_bf16(nw)
-    cs_d, ctx_d = torch.from_numpy(cs).to(DEV), torch.from_numpy(ctxs).to(DEV)
+    cs_d, ctx_d, pl_d = torch.from_numpy(cs).to(DEV), torch.from_numpy(ctxs).to(DEV), torch.from_numpy(plen).to(DEV)
     ws = torch.zeros((N // 32) * ksplit * 2 * 256, dtype=torch.float32, device=DEV)
     cnt = torch.zeros(N // 32, dtype=torch.int32, device=DEV)
-    L.kr_linear_decode(DEC_ROPE_KV, ptr(xd), K, ptr(Wd), ptr(bd), ptr(nd), 1e-6, 0, 0, 0, 0, 0, B, N, K, ksplit, ptr(ws),
-                       ptr(cnt), ptr(cs_d), ptr(ctx_d), ptr(q_d), ptr(kc_d), ptr(vt_d), H, KVH, s_max, 0, 0, 0)
+    dec_call(L, DEC_ROPE_KV, ptr(xd), K, ptr(Wd), B, N, K, bias=ptr(bd), norm_w=ptr(nd), waves=waves, ksplit=ksplit,
+             ws=ptr(ws), cnt=ptr(cnt), cs=ptr(cs_d), cs_stride=T, plen=ptr(pl_d), ctx=ptr(ctx_d), q_out=ptr(q_d),
+             kc=ptr(kc_d), vc=ptr(vt_d), heads=H, kv_heads=KVH, s_max=s_max)
     xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
     qkv = bf16_round(ref_linear(xn, W, bias))
     q = qkv[:, :H * hd].reshape(B, H, hd); k = qkv[:, H * hd:(H + KVH) * hd].reshape(B, KVH, hd)
     v = qkv[:, (H + KVH) * hd:].reshape(B, KVH, hd)
-    cos, sin = np.concatenate([cs[:, :64]] * 2, -1), np.concatenate([cs[:, 64:]] * 2, -1)
+    csb = cs[np.arange(B), step]
+    cos, sin = np.concatenate([csb[:, :64]] * 2, -1), np.concatenate([csb[:, 64:]] * 2, -1)
     qr = q * cos[:, None] + O.rotate_half(q) * sin[:, None]
     kr = k * cos[:, None] + O.rotate_half(k) * sin[:, None]
     assert_close_bf16(host(q_d), qr, abs_=3e-2, what="fused q")
@@ -657,7 +679,7 @@ def test_linear_decode_rope_kv(L, H, KVH, ksplit):
 def test_linear_decode_argmax_and_sample(L):
     """lm_head partial argmax + kr_sample_greedy: ties -> lowest index; logits optional; bookkeeping."""
     rng = np.random.default_rng(80)
-    B, V, d, hd = 3, 16 * 2 * 40 + 16, 256, 128     # odd tile count: last workgroup has one tile
+    B, V, d = 3, 16 * 2 * 40 + 16, 256     # odd tile count: last workgroup has one tile
     x, W = ints(rng, B, d), ints(rng, V, d)
     W[:, 200:] = 0
     nw = np.ones(d, np.float32)
@@ -666,30 +688,73 @@ def test_linear_decode_argmax_and_sample(L):
     n_part = (V // 16 + 1) // 2
     av = torch.zeros(B, n_part, dtype=torch.float32, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
     lg = torch.zeros(B, V, dtype=torch.float32, device=DEV)
-    L.kr_linear_decode(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, ptr(lg), V, B, V, d, 1, 0, 0,
-                       0, 0, 0, 0, 0, 0, 0, 64, ptr(av), ptr(ai), 0)
+    dec_call(L, DEC_ARGMAX, ptr(xd), d, ptr(Wd), B, V, d, out_f32=ptr(lg), ldc=V, norm_w=ptr(nd), av=ptr(av), ai=ptr(ai))
     got = host(lg)
     np.testing.assert_allclose(got, logits_ref, atol=2e-2, rtol=1e-2)
     table = rnd(rng, V, d); td = dev_bf16(table)
-    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.full((4, 4), -1, dtype=torch.int32, device=DEV)
-    step = torch.zeros(1, dtype=torch.int32, device=DEV); ctx = torch.tensor([10, 20, 30], dtype=torch.int32, device=DEV)
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.full((6, 4), -1, dtype=torch.int32, device=DEV)
+    plen = torch.tensor([10, 19, 27], dtype=torch.int32, device=DEV)
+    ctx = torch.tensor([10, 20, 30], dtype=torch.int32, device=DEV)      # -> generated-token index 1, 2, 4
     fin = torch.zeros(B, dtype=torch.int32, device=DEV); eos = torch.tensor([-5], dtype=torch.int32, device=DEV)
     xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
-    delta = torch.tensor([-3, 0, 7], dtype=torch.int32, device=DEV)
-    inv = POS.rope_inv_freq(hd, 1e6); inv_d = torch.from_numpy(inv).to(DEV)
-    cs = torch.zeros(B, hd, dtype=torch.float32, device=DEV)
-    L.kr_sample_greedy(ptr(av), ptr(ai), n_part, ptr(td), d, ptr(tok), ptr(hist), 4, ptr(step), ptr(ctx), ptr(fin), ptr(eos), 1,
-                       0, 0, ptr(xn), ptr(delta), ptr(inv_d), ptr(cs), hd, B, 0)
+    L.kr_sample_greedy(ptr(av), ptr(ai), n_part, ptr(td), d, ptr(tok), ptr(hist), 4, ptr(plen), ptr(ctx), ptr(fin), ptr(eos),
+                       1, 0, 0, ptr(xn), B, 0)
     torch.cuda.synchronize()
     want = got.argmax(1)           # numpy argmax = lowest index among ties (integer logits tie often)
     np.testing.assert_array_equal(tok.cpu().numpy(), want)
-    np.testing.assert_array_equal(hist.cpu().numpy()[0, :3], want)
-    assert ctx.cpu().tolist() == [11, 21, 31] and int(step.item()) == 1
+    h = hist.cpu().numpy()
+    assert h[1, 0] == want[0] and h[2, 1] == want[1] and h[4, 2] == want[2] and (h == -1).sum() == 24 - 3
+    assert ctx.cpu().tolist() == [11, 21, 31]
     np.testing.assert_array_equal(host(xn), table[want])
-    for b, p in enumerate([11 - 3, 21, 31 + 7]):
-        ang = np.float32(p) * inv
-        np.testing.assert_allclose(cs.cpu().numpy()[b, :64], bf16_round(np.cos(ang).astype(np.float32)), atol=8e-3)
-        np.testing.assert_allclose(cs.cpu().numpy()[b, 64:], bf16_round(np.sin(ang).astype(np.float32)), atol=8e-3)
+
+
+def test_sample_greedy_eos_and_pad(L):
+    B, d, n_part = 3, 64, 5
+    rng = np.random.default_rng(81)
+    table = rnd(rng, 512, d); td = dev_bf16(table)
+    av = torch.full((B, n_part), -1.0, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
+    av[0, 2] = 3; ai[0, 2] = 11; av[1, 4] = 2; ai[1, 4] = 497; av[2, 0] = 1; ai[2, 0] = 300
+    av[2, 3] = 1; ai[2, 3] = 299   # tie on value -> lower index 299
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.full((4, B), -1, dtype=torch.int32, device=DEV)
+    plen = torch.tensor([10, 20, 30], dtype=torch.int32, device=DEV); ctx = torch.tensor([9, 19, 29], dtype=torch.int32, device=DEV)
+    fin = torch.zeros(B, dtype=torch.int32, device=DEV); eos = torch.tensor([497, 496], dtype=torch.int32, device=DEV)
+    xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):
+        L.kr_sample_greedy(ptr(av), ptr(ai), n_part, ptr(td), d, ptr(tok), ptr(hist), B, ptr(plen), ptr(ctx), ptr(fin),
+                           ptr(eos), 2, 496, 0, ptr(xn), B, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hist.cpu().numpy()[:2], [[11, 497, 299], [11, 496, 299]])   # pad after EOS
+    np.testing.assert_array_equal(fin.cpu().numpy(), [0, 1, 0])
+    np.testing.assert_array_equal(ctx.cpu().numpy(), [11, 21, 31])
+    np.testing.assert_array_equal(host(xn), table[[11, 496, 299]])
+
+
+@pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4)])
+@pytest.mark.parametrize("n_split", [1, 4, 8])
+def test_attn_partials_merged_by_o_proj_prologue(L, H, KVH, n_split):
+    """Engine path: attention leaves split partials (out == NULL); the o_proj decode linear merges
+    them in its prologue, multiplies by W_o and adds the residual."""
+    rng = np.random.default_rng(H * 10 + n_split + 1)
+    hd, s_max, d = 128, 1024, 256
+    ctxs = [0, 70, 130, 1023]
+    B = len(ctxs)
+    kc = np.zeros((B, KVH, s_max, hd), np.float32); vc = np.zeros((B, KVH, s_max, hd), np.float32)
+    for b, c in enumerate(ctxs):
+        kc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
+        vc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
+    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    q = rnd(rng, B, H, hd)
+    Wo, X = rnd(rng, d, H * hd, scale=(H * hd) ** -0.5), rnd(rng, B, d)
+    kc_d, vt_d, q_d, Wd, Xd = dev_bf16(kc), dev_bf16(vt), dev_bf16(q), dev_bf16(pack_w16x64(Wo)), dev_bf16(X)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(B * H * n_split * (hd + 2), dtype=torch.float32, device=DEV)
+    L.kr_attn_decode_fused(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), 0, ptr(ws), 0, B, H, KVH, hd, s_max, n_split,
+                           hd ** -0.5, 0)
+    dec_call(L, DEC_PLAIN, 0, 0, ptr(Wd), B, d, H * hd, out=ptr(Xd), ldc=d, res=ptr(Xd), ldr=d, waves=8, attn=ptr(ws),
+             attn_split=n_split)
+    attn = np.concatenate([np_attention(q[b][:, None], kc[b, :, :c + 1], vc[b, :, :c + 1], hd ** -0.5, False)
+                           for b, c in enumerate(ctxs)])
+    assert_close_bf16(host(Xd), ref_linear(bf16_round(attn), Wo, res=X), rel=2 ** -6, abs_=3e-2, what="o_proj with merge")
 
 
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4)])
