@@ -94,7 +94,7 @@ int kr_rmsnorm(const kr_bf16* x, int64_t ldx, const kr_bf16* w, kr_bf16* y,
  * bias / residual may be NULL.  With KR_EPI_SILU_MUL, W holds gate/up rows interleaved in groups
  * of 16 (g0..g15,u0..u15,g16..), N counts both, C is [M, N/2] and N % 32 == 0.
  * lda / ldc / ldr are row strides in elements.  w_packed != 0: W is stored in the decode layout
- * [N/16][K/64][16][64] (see kr_linear_decode) instead of row-major — one copy of the decoder
+ * [N/16][K/32][4][16][8] (see kr_linear_decode) instead of row-major — one copy of the decoder
  * weights serves prefill and decode.  Used for every ViT Linear, the merger, and every decoder
  * Linear at prefill. */
 int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
@@ -206,9 +206,10 @@ int kr_argmax_embed(const float* logits, int64_t ld_logits, int vocab,
 int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, int batch, kr_stream s);
 
 /* ------------------------------------------------------------------ fused decode step (5 launches per layer + 2)
- * Decode linears over PACKED weights: W[N][K] stored as [N/16][K/64][16][64] bf16 tiles, so the
- * matrix is read from HBM as one linear stream (each wave-instruction pair = one contiguous 2 KiB
- * block).  y[M<=16, N] = epi(x W^T).  K is split over the `waves` (4, 8 or 16) waves of a
+ * Decode linears over PACKED weights: W[N][K] stored as [N/16][K/32][4][16][8] bf16 (element
+ * (n, k) at ((((n/16)*(K/32) + k/32)*4 + (k%32)/8)*16 + n%16)*8 + k%8): one (16 x 32) block is an
+ * MFMA fragment set in lane order, so the matrix is read from HBM as one linear stream, 1 KiB of
+ * contiguous memory per wave-level load.  y[M<=16, N] = epi(x W^T).  K is split over the `waves` (4, 8 or 16) waves of a
  * workgroup; ksplit > 1 additionally splits K over workgroups with a deterministic in-launch
  * reduction (ws: f32 [N/16][ksplit][256] slabs, counters: int32 [N/16], zero-initialised, left
  * zero).  Prologues: Qwen2VLRMSNorm on x (norm_w, K <= 4096), or x = merge of the decode

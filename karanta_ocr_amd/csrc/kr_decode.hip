@@ -1,8 +1,9 @@
 // Decode-step kernels (one new token per live sequence): 5 launches per decoder layer + 2 per step.
 //
 //   dec_linear_kernel   y[M<=16, N] = epi(x W^T): the weight matrix is read from HBM exactly once, as
-//                       one linear stream — weights are stored PACKED in [N/16][K/64][16][64] tiles so
-//                       every wave-instruction pair fetches one contiguous 2 KiB block; K is split over
+//                       one linear stream — weights are stored PACKED as [N/16][K/32][4][16][8]: one
+//                       (16 x 32) block is an MFMA fragment set in lane order, so every wave-level load
+//                       is 1 KiB of contiguous memory (8 full 128-byte lines); K is split over
 //                       the 4 / 8 / 16 waves of a workgroup (narrow layers get more waves per workgroup
 //                       instead of a cross-workgroup split: every fence / atomic hop between workgroups
 //                       costs microseconds, measured, and a decode step is a chain of 142 launches).
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tt = tile[t] < ntiles ? tile[t] : ntiles - 1;
-        wp[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + fr * 64 + fg * 16;
+        wp[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + lane * 8;  // block (tile, k/32) = 512 elements, lane-linear
     }
     bf16x8 wbuf[U][NT][2];
 #pragma unroll
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)c * 1024);
-                wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 8);
+                wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 512);
             }
         }
     }
@@ -174,8 +175,9 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
         __syncthreads();
     }
 
-    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 32;
-    const kr_bf16* xg = a.x + (int64_t)(fr < M ? fr : 0) * a.ldx + fg * 16;
+    // x fragment of k-step (c, h): row fr, k = 64c + 32h + 8fg .. +7
+    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 16;
+    const kr_bf16* xg = a.x + (int64_t)(fr < M ? fr : 0) * a.ldx + fg * 8;
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -187,10 +189,10 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
                 bf16x8 x0, x1;
                 if (xlds) {
                     x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
-                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 16);
+                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 64);
                 } else {
                     x0 = ld8(xg + c * 64);
-                    x1 = ld8(xg + c * 64 + 8);
+                    x1 = ld8(xg + c * 64 + 32);
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
-                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 8);
+                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 512);
                     }
                 }
             }
@@ -382,10 +384,12 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
     const int nb = (ctx + 63) >> 6;
 
     const int g = fr < group ? fr : 0;
-    const kr_bf16* qp = q + ((int64_t)b * heads + kvh * group + g) * HD + fg * 32;
+    // MFMA k-step i pairs K[key][32i + 8fg + j] with Q[g][32i + 8fg + j]: per load instruction the
+    // four lane groups cover 64 contiguous bytes of each of 16 key rows
+    const kr_bf16* qp = q + ((int64_t)b * heads + kvh * group + g) * HD + fg * 8;
     bf16x8 qf[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qf[i] = ld8(qp + i * 8);
+    for (int i = 0; i < 4; ++i) qf[i] = ld8(qp + i * 32);
     const int64_t kv_base = (int64_t)b * kv_heads + kvh;
     const kr_bf16* kc = kcache + kv_base * s_max * HD;
     const kr_bf16* vc = vtcache + kv_base * (int64_t)(s_max >> 6) * (HD * 64);
@@ -402,9 +406,9 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
             bf16x8 kf[2][4];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 32;
+                const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 8;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) kf[kt][i] = ld8_nt(kp + i * 8);
+                for (int i = 0; i < 4; ++i) kf[kt][i] = ld8_nt(kp + i * 32);
             }
             bf16x8 vf[DT];
             const kr_bf16* vp = vc + (int64_t)blk * (HD * 64) + hf * 32 + fg * 8;

@@ -26,8 +26,9 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((
 
 // Stage one [128][64] tile (rows row0.., k k0..) of a row-major [rows_total][ld] matrix.
 // Each wave-instruction writes 1 KiB contiguous LDS (= 8 tile rows).
-// PACKED: the matrix is stored as [rows/16][ld/64][16][64] tiles (the decode layout): the same
-// 1 KiB-per-wave-instruction pattern, read from fully contiguous 2 KiB blocks.
+// PACKED: the matrix is stored in the decode layout [rows/16][ld/32][4][16][8] (one MFMA fragment
+// block = 1 KiB, see kr_decode.hip): chunk c (8 k) of row r lives at block (r/16, k/32), group
+// (k%32)/8, row r%16 — a wave-instruction still fetches eight 128-byte segments.
 template <bool PACKED>
 __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_total,
                                            int k0, char* lds_tile, int tid, int wave) {
@@ -38,7 +39,7 @@ __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_
         const int c = cp ^ ((r >> 1) & 7);  // which global chunk lands at this LDS position
         int64_t gr = row0 + r;
         gr = gr < rows_total ? gr : rows_total - 1;
-        const kr_bf16* src = PACKED ? g + ((gr >> 4) * (ld >> 6) + (k0 >> 6)) * 1024 + (gr & 15) * 64 + c * 8
+        const kr_bf16* src = PACKED ? g + ((((gr >> 4) * (ld >> 5) + (k0 >> 5) + (c >> 2)) * 4 + (c & 3)) * 16 + (gr & 15)) * 8
                                     : g + gr * ld + k0 + c * 8;
         char* dst = lds_tile + (p * 256 + wave * 64) * 16;  // wave-uniform; hardware adds lane*16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

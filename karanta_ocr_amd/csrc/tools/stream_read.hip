@@ -1,0 +1,88 @@
+// Micro-benchmark: read-only HBM streaming rate for the access shapes the decode linears use.
+// Build: hipcc -O3 --offload-arch=gfx950 stream_read.hip -o /tmp/stream_read
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// every wave streams a contiguous slice; U 16-byte loads per lane in flight
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) rd_vgpr(const u32x4* __restrict__ p, size_t n16_per_wave, unsigned* sink) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u32x4* q = p + wave * n16_per_wave + lane;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = 0; i < n16_per_wave; i += 64 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(q + i + u * 64) : q[i + u * 64];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
+// LDS-DMA: one wave-instruction = 1 KiB straight into LDS, no VGPR destination
+template <int U>
+__global__ void __launch_bounds__(256) rd_lds(const u32x4* __restrict__ p, size_t n16_per_wave, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const u32x4* q = p + wave * n16_per_wave + lane;
+    char* base = smem + wv * (U * 1024);
+    for (size_t i = 0; i < n16_per_wave; i += 64 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q + i + u * 64),
+                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (((unsigned*)smem)[threadIdx.x] == 0x12345678u) sink[0] = 1;
+}
+
+template <typename F>
+void timeit(const char* name, F launch, size_t bytes, hipStream_t s) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    launch(); CK(hipStreamSynchronize(s));
+    float best = 1e9;
+    for (int it = 0; it < 5; ++it) {
+        CK(hipEventRecord(e0, s)); launch(); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+    }
+    printf("%-44s %8.3f ms  %6.2f TB/s\n", name, best, bytes / best / 1e9);
+}
+
+int main() {
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const size_t bytes = (size_t)2 << 30;
+    u32x4* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 1, bytes));
+    unsigned* sink; CK(hipMalloc(&sink, 4));
+    for (int blocks_per_cu : {1, 2, 4, 8}) {
+        const int blocks = 256 * blocks_per_cu, waves = blocks * 4;
+        const size_t n16 = bytes / 16 / waves / (64 * 16) * (64 * 16);
+        const size_t tot = n16 * 16 * waves;
+        char name[128];
+        snprintf(name, sizeof name, "vgpr U=4        %d blk/CU", blocks_per_cu);
+        timeit(name, [&] { rd_vgpr<4, false><<<blocks, 256, 0, s>>>(p, n16, sink); }, tot, s);
+        snprintf(name, sizeof name, "vgpr U=16       %d blk/CU", blocks_per_cu);
+        timeit(name, [&] { rd_vgpr<16, false><<<blocks, 256, 0, s>>>(p, n16, sink); }, tot, s);
+        snprintf(name, sizeof name, "vgpr U=16 nt    %d blk/CU", blocks_per_cu);
+        timeit(name, [&] { rd_vgpr<16, true><<<blocks, 256, 0, s>>>(p, n16, sink); }, tot, s);
+        snprintf(name, sizeof name, "lds-dma U=8     %d blk/CU", blocks_per_cu);
+        timeit(name, [&] { rd_lds<8><<<blocks, 256, 4 * 8 * 1024, s>>>(p, n16, sink); }, tot, s);
+        snprintf(name, sizeof name, "lds-dma U=16    %d blk/CU", blocks_per_cu);
+        timeit(name, [&] { rd_lds<16><<<blocks, 256, 4 * 16 * 1024, s>>>(p, n16, sink); }, tot, s);
+    }
+    // few CUs only: per-CU ceiling
+    for (int blocks : {32, 96}) {
+        const int waves = blocks * 16;
+        const size_t n16 = ((size_t)256 << 20) / 16 / waves / (64 * 16) * (64 * 16);
+        const size_t tot = n16 * 16 * waves;
+        char name[128];
+        snprintf(name, sizeof name, "vgpr U=16 nt  %d blocks x 16 waves", blocks);
+        timeit(name, [&] { rd_vgpr<16, true><<<blocks, 1024, 0, s>>>(p, n16, sink); }, tot, s);
+    }
+    return 0;
+}

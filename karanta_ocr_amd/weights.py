@@ -174,16 +174,20 @@ def as_f32(w: np.ndarray) -> np.ndarray:
 
 
 def pack_w16x64(w: np.ndarray) -> np.ndarray:
-    """Row-major ``[N, K]`` -> the decode layout ``[N/16][K/64][16][64]`` (flattened to ``[N, K]``
-    shape for bookkeeping): each (16-row, 64-column) tile is one contiguous 2 KiB block, tiles of
-    one 16-row group follow each other along K.  kr_linear_decode streams it linearly; kr_gemm_bf16
-    reads it with ``w_packed=1``."""
+    """Row-major ``[N, K]`` -> the decode layout ``[N/16][K/32][4][16][8]`` (flattened back to an
+    ``[N, K]``-shaped array for bookkeeping).
+
+    One (16-row, 32-column) block is exactly one ``v_mfma_f32_16x16x32_bf16`` A/B fragment set in
+    lane order: lane ``l = 16*g + r`` holds row ``r``, columns ``8g .. 8g+7``.  So a wave fetches a
+    block with ONE 16-byte-per-lane load covering 1 KiB of contiguous memory (8 full 128-byte
+    lines), and a 16-row group is one linear stream along K.  kr_linear_decode streams it;
+    kr_gemm_bf16 reads the same copy with ``w_packed=1``."""
     n, k = w.shape
     if n % 16 or k % 64:
         raise ValueError(f"pack_w16x64: shape {w.shape} is not a multiple of (16, 64)")
-    return np.ascontiguousarray(w.reshape(n // 16, 16, k // 64, 64).transpose(0, 2, 1, 3)).reshape(n, k)
+    return np.ascontiguousarray(w.reshape(n // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)).reshape(n, k)
 
 
 def unpack_w16x64(p: np.ndarray) -> np.ndarray:
     n, k = p.shape
-    return np.ascontiguousarray(p.reshape(n // 16, k // 64, 16, 64).transpose(0, 2, 1, 3)).reshape(n, k)
+    return np.ascontiguousarray(p.reshape(n // 16, k // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4)).reshape(n, k)

@@ -181,8 +181,13 @@ def test_pack_w16x64_layout():
 
     w = np.arange(32 * 128, dtype=np.float32).reshape(32, 128)
     p = pack_w16x64(w).reshape(-1)
-    # tile (row group 1, k chunk 1) starts at ((1*2)+1)*1024; its row 3, column 5 is w[16+3, 64+5]
-    assert p[3 * 1024 + 3 * 64 + 5] == w[19, 69]
+    # element (n, k) lives at ((((n/16)*(K/32) + k/32)*4 + (k%32)/8)*16 + n%16)*8 + k%8
+    for n, k in ((0, 0), (19, 69), (31, 127), (5, 40)):
+        off = ((((n // 16) * 4 + k // 32) * 4 + (k % 32) // 8) * 16 + n % 16) * 8 + k % 8
+        assert p[off] == w[n, k]
+    # lane l = 16g + r of a wave reads 8 consecutive elements at 8l of a block: row r, columns 8g..8g+7
+    blk = p[:512].reshape(64, 8)
+    np.testing.assert_array_equal(blk[16 * 2 + 3], w[3, 16:24])
     np.testing.assert_array_equal(unpack_w16x64(pack_w16x64(w)), w)
     with pytest.raises(ValueError):
         pack_w16x64(np.zeros((8, 64), np.float32))
