@@ -166,7 +166,7 @@ def main():
 
     s_max = (max(P) + T_out + 63) // 64 * 64
     eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(len(p) for p in pvs),
-                 max_prompt_tokens=sum(P), decode_splits=8)
+                 max_prompt_tokens=sum(P), decode_splits=4)
     pix_dev = torch.from_numpy(np.concatenate(pvs, 0)).to(dev)
 
     # ---------------- weights: rank 0 materialises them, the others receive the arena over RCCL
@@ -252,7 +252,7 @@ def main():
                                 "frac_of_hbm_peak": round(t_step_roof / decode_step_s, 4) if decode_step_s > 0 else None,
                                 "pages_per_s_roof_per_gpu": round(B / (T_out * t_step_roof), 3)},
             "roofline": {
-                "kernel": "gemv_kernel<2,SILU_MUL> (decode gate/up projection + fused RMSNorm + SiLU*mul)",
+                "kernel": "dec_linear_kernel<2, SILU, 4> (decode gate/up projection + fused RMSNorm + SiLU*mul)",
                 "bound": "hbm",
                 "achieved": round(prof["bytes_per_launch"] / (prof["avg_us"] * 1e-6) / 1e9, 1) if prof["avg_us"] else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

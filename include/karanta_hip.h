@@ -213,7 +213,7 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
  * workgroup; ksplit > 1 additionally splits K over workgroups with a deterministic in-launch
  * reduction (ws: f32 [N/16][ksplit][256] slabs, counters: int32 [N/16], zero-initialised, left
  * zero).  Prologues: Qwen2VLRMSNorm on x (norm_w, K <= 4096), or x = merge of the decode
- * attention partials (attn_partials [M][K/128][attn_split][130] f32 as kr_attn_decode_fused
+ * attention partials (attn_partials [M][K/128][attn_split][hd+4] f32 as kr_attn_decode_fused
  * leaves them with out == NULL; x itself may then be NULL).
  * mode 0 PLAIN   : +bias, +residual, bf16 `out` or fp32 `out_f32` [M, ldc]      (o_proj, down_proj)
  *      1 SILU    : silu(gate)*up, rows interleaved in 16-row groups, out [M, N/2] (gate/up)
@@ -238,7 +238,7 @@ int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_p
                      float* amax_val, int32_t* amax_idx, kr_stream s);
 
 /* Decode attention (q_len 1, GQA, MFMA, split over n_split key ranges), kcache / vtcache = the
- * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+2] partials (o, m, l).
+ * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+4] partials (o[hd], m, l, 2 pad: 16-byte aligned records).
  * out != NULL: the splits are merged in-launch by the last-arriving workgroup (counters: int32
  * [batch*kv_heads], zero-initialised, left zero) and written as bf16 [batch, heads*hd].
  * out == NULL: only the partials are produced; the consumer merges them (kr_linear_decode). */

@@ -36,7 +36,7 @@ struct DecLinArgs {
     kr_bf16* out; float* out_f32; int64_t ldc;
     int M, N, K, ksplit;
     float* ws; int* counters;          // split-K slabs [groups][ksplit][NT][256] f32, arrival counters [groups]
-    // x = merge of attention partials [M][heads][n_split][130] f32 (xmode 3)
+    // x = merge of attention partials [M][heads][n_split][132] f32 (o[128], m, l, 2 pad) (xmode 3)
     const float* attn_ws; int attn_split;
     int xmode;                         // 0: x straight from global, 1: LDS stage, 2: LDS stage + RMSNorm, 3: attention merge
     // ROPE_KV
@@ -144,14 +144,15 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
         // the decode attention, done here instead of in a kernel of its own (K = heads * 128).
         const int ns = a.attn_split, nbh = M * (K >> 7);
         float* wts = red;  // [nbh][ns] scratch, consumed before `red` is used for the K reduction
-        for (int bh = tid; bh < nbh; bh += NTHR) {
-            const float* w = a.attn_ws + (int64_t)bh * ns * 130;
+        for (int i = tid; i < nbh * ns; i += NTHR) {
+            const int bh = i / ns;
+            const float* w = a.attn_ws + (int64_t)bh * ns * 132;
             float mm = -1e30f;
-            for (int p = 0; p < ns; ++p) mm = fmaxf(mm, w[p * 130 + 128]);
+            for (int p = 0; p < ns; ++p) mm = fmaxf(mm, w[p * 132 + 128]);
             float ll = 0.f;
-            for (int p = 0; p < ns; ++p) ll += w[p * 130 + 129] * __builtin_amdgcn_exp2f(w[p * 130 + 128] - mm);
-            const float inv = ll > 0.f ? 1.0f / ll : 0.f;
-            for (int p = 0; p < ns; ++p) wts[bh * ns + p] = __builtin_amdgcn_exp2f(w[p * 130 + 128] - mm) * inv;
+            for (int p = 0; p < ns; ++p) ll += w[p * 132 + 129] * __builtin_amdgcn_exp2f(w[p * 132 + 128] - mm);
+            const int p = i - bh * ns;
+            wts[i] = ll > 0.f ? __builtin_amdgcn_exp2f(w[p * 132 + 128] - mm) / ll : 0.f;
         }
         __syncthreads();
         const int cpr = K >> 3;
@@ -159,17 +160,24 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
             const int b = i / cpr, c = i - b * cpr;  // chunk c of row b: head c>>4, d = (c&15)*8
             if (c < cb0 * 8 || c >= cb1 * 8) continue;
             const int bh = b * (K >> 7) + (c >> 4);
-            const float* w = a.attn_ws + (int64_t)bh * ns * 130 + (c & 15) * 8;
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* w = a.attn_ws + (int64_t)bh * ns * 132 + (c & 15) * 8;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
             for (int p = 0; p < ns; ++p) {
                 const float wp_ = wts[bh * ns + p];
-                const float* o = w + p * 130;  // 130-float records: 8-byte aligned only
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(w + p * 132);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(w + p * 132 + 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += o[j] * wp_;
+                for (int j = 0; j < 4; ++j) {
+                    a0[j] += o0[j] * wp_;
+                    a1[j] += o1[j] * wp_;
+                }
             }
             bf16x8 ov;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = f2bf(acc[j]);
+            for (int j = 0; j < 4; ++j) {
+                ov[j] = f2bf(a0[j]);
+                ov[4 + j] = f2bf(a1[j]);
+            }
             *reinterpret_cast<bf16x8*>(smem + b * xrow + (c - cb0 * 8) * 16) = ov;
         }
         __syncthreads();
@@ -366,20 +374,21 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 // =====================================================================================
 // grid = (n_split, kv_heads, batch); 4 waves; wave `part` = split*4 + wave walks 64-key blocks
 // part, part + 4*n_split, ...   Layouts as in kr_attention.hip (K rows, V^T 64-key blocks).
-__global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
-                                                           const kr_bf16* __restrict__ vtcache,
-                                                           const int32_t* __restrict__ ctx_len, kr_bf16* __restrict__ out,
-                                                           float* __restrict__ ws, int* __restrict__ counters, int heads,
-                                                           int kv_heads, int s_max, float scale_log2e) {
-    constexpr int HD = 128, DT = HD / 16;
-    __shared__ __attribute__((aligned(16))) float o_s[4][16][HD];
-    __shared__ float m_s[4][16], l_s[4][16];
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
+                                                                  const kr_bf16* __restrict__ vtcache,
+                                                                  const int32_t* __restrict__ ctx_len, kr_bf16* __restrict__ out,
+                                                                  float* __restrict__ ws, int* __restrict__ counters, int heads,
+                                                                  int kv_heads, int s_max, float scale_log2e) {
+    constexpr int HD = 128, DT = HD / 16, REC = HD + 4, NTHR = WAVES * 64;
+    __shared__ __attribute__((aligned(16))) float o_s[WAVES][16][HD];
+    __shared__ float m_s[WAVES][16], l_s[WAVES][16];
     __shared__ int last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int split = blockIdx.x, n_split = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
     const int group = heads / kv_heads;
-    const int n_part = n_split * 4, part = split * 4 + wave;
+    const int n_part = n_split * WAVES, part = split * WAVES + wave;
     const int ctx = ctx_len[b] + 1;
     const int nb = (ctx + 63) >> 6;
 
@@ -457,7 +466,7 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    // ---- merge the 4 waves through LDS
+    // ---- merge the waves through LDS
     if (fr < group) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(&o_s[wave][fr][dt * 16 + fg * 4]) = o[dt];
@@ -468,14 +477,14 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
     }
     __syncthreads();
     const int bh0 = b * heads + kvh * group;
-    for (int e = tid; e < group * HD; e += 256) {
+    for (int e = tid; e < group * HD; e += NTHR) {
         const int gg = e >> 7, d = e & 127;
         float mm = m_s[0][gg];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) mm = fmaxf(mm, m_s[w][gg]);
+        for (int w = 1; w < WAVES; ++w) mm = fmaxf(mm, m_s[w][gg]);
         float acc = 0.f, ll = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const float sc = __builtin_amdgcn_exp2f(m_s[w][gg] - mm);
             acc += o_s[w][gg][d] * sc;
             ll += l_s[w][gg] * sc;
@@ -483,7 +492,7 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
         if (n_split == 1 && out) {
             out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
         } else {
-            float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * (HD + 2);
+            float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * REC;
             w[d] = acc;
             if (d == 0) {
                 w[HD] = mm;
@@ -508,16 +517,16 @@ __global__ void __launch_bounds__(256) attn_decode2_kernel(const kr_bf16* __rest
     }
     __syncthreads();
     if (!last_s) return;
-    for (int e = tid; e < group * HD; e += 256) {
+    for (int e = tid; e < group * HD; e += NTHR) {
         const int gg = e >> 7, d = e & 127;
-        const float* w = ws + (int64_t)(bh0 + gg) * n_split * (HD + 2);
+        const float* w = ws + (int64_t)(bh0 + gg) * n_split * REC;
         float mm = -1e30f;
-        for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * (HD + 2) + HD]);
+        for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * REC + HD]);
         float acc = 0.f, ll = 0.f;
         for (int p = 0; p < n_split; ++p) {
-            const float sc = __builtin_amdgcn_exp2f(w[p * (HD + 2) + HD] - mm);
-            acc += w[p * (HD + 2) + d] * sc;
-            ll += w[p * (HD + 2) + HD + 1] * sc;
+            const float sc = __builtin_amdgcn_exp2f(w[p * REC + HD] - mm);
+            acc += w[p * REC + d] * sc;
+            ll += w[p * REC + HD + 1] * sc;
         }
         out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
     }
@@ -671,8 +680,13 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_fused: GQA group must be <= 16");
     KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
     KR_CHECK_ARG(!out || n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
-    attn_decode2_kernel<<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
-        q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
+    // few splits: 8 waves per workgroup keep the same number of waves streaming the cache
+    if (n_split <= 4)
+        attn_decode2_kernel<8><<<dim3(n_split, kv_heads, batch), 512, 0, kr_hs(s)>>>(
+            q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
+    else
+        attn_decode2_kernel<4><<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
+            q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

@@ -168,7 +168,7 @@ class GenerateResult:
 
 class Engine:
     def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
-                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 8):
+                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 4):
         if not torch.cuda.is_available():
             raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
         self.L = lib()
@@ -235,7 +235,7 @@ class Engine:
         self.d_o = z(B, t.q_dim)
         self.d_act = z(B, t.intermediate_size)
         self.d_logits = z(B, t.vocab_size, dtype=torch.float32)
-        self.d_ws = z(B * t.num_heads * self.n_split * (t.head_dim + 2), dtype=torch.float32)
+        self.d_ws = z(B * t.num_heads * self.n_split * (t.head_dim + 4), dtype=torch.float32)
         # waves per workgroup of the narrow decode linears: enough waves that every wave still
         # streams >= 2 K-chunks, no cross-workgroup reduction (each fence/atomic hop costs microseconds)
         self.wv_qkv = self._waves(t.hidden_size // 64)

@@ -747,7 +747,7 @@ def test_attn_partials_merged_by_o_proj_prologue(L, H, KVH, n_split):
     Wo, X = rnd(rng, d, H * hd, scale=(H * hd) ** -0.5), rnd(rng, B, d)
     kc_d, vt_d, q_d, Wd, Xd = dev_bf16(kc), dev_bf16(vt), dev_bf16(q), dev_bf16(pack_w16x64(Wo)), dev_bf16(X)
     ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
-    ws = torch.zeros(B * H * n_split * (hd + 2), dtype=torch.float32, device=DEV)
+    ws = torch.zeros(B * H * n_split * (hd + 4), dtype=torch.float32, device=DEV)
     L.kr_attn_decode_fused(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), 0, ptr(ws), 0, B, H, KVH, hd, s_max, n_split,
                            hd ** -0.5, 0)
     dec_call(L, DEC_PLAIN, 0, 0, ptr(Wd), B, d, H * hd, out=ptr(Xd), ldc=d, res=ptr(Xd), ldr=d, waves=8, attn=ptr(ws),
@@ -772,7 +772,7 @@ def test_attn_decode_fused(L, H, KVH, n_split):
     q = rnd(rng, B, H, hd)
     kc_d, vt_d, q_d = dev_bf16(kc), dev_bf16(vt), dev_bf16(q)
     ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
-    ws = torch.zeros(B * H * n_split * (hd + 2), dtype=torch.float32, device=DEV)
+    ws = torch.zeros(B * H * n_split * (hd + 4), dtype=torch.float32, device=DEV)
     cnt = torch.zeros(B * KVH, dtype=torch.int32, device=DEV)
     o_d = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
     for _ in range(2):
