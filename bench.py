@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--decode-splits", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -166,7 +167,7 @@ def main():
 
     s_max = (max(P) + T_out + 63) // 64 * 64
     eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(len(p) for p in pvs),
-                 max_prompt_tokens=sum(P), decode_splits=4)
+                 max_prompt_tokens=sum(P), decode_splits=args.decode_splits)
     pix_dev = torch.from_numpy(np.concatenate(pvs, 0)).to(dev)
 
     # ---------------- weights: rank 0 materialises them, the others receive the arena over RCCL
@@ -179,22 +180,8 @@ def main():
     else:
         eng.w.allocate()
     if world > 1:
-        import ctypes as C
-        L = lib()
-        uid = (C.c_uint8 * 128)()
-        if rank == 0:
-            L.kr_comm_unique_id(uid)
-        obj = [bytes(uid)]
-        dist.broadcast_object_list(obj, src=0)
-        uid = (C.c_uint8 * 128).from_buffer_copy(obj[0])
-        comm = C.c_void_p()
-        L.kr_comm_init(C.byref(comm), world, rank, uid)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        L.kr_bcast_weights(comm, ptr(eng.w.arena), eng.w.nbytes, 0, eng.s)
-        eng.stream.synchronize()
-        bcast_s = time.perf_counter() - t0
+        from karanta_ocr_amd.dp import broadcast_weights
+        bcast_s = broadcast_weights(eng.w.arena, rank, world, stream=eng.s)
         log(f"RCCL weight broadcast: {eng.w.nbytes/1e9:.2f} GB in {bcast_s*1e3:.0f} ms")
 
     def one_step(profile_every=0):

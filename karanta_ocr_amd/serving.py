@@ -1,0 +1,312 @@
+"""OpenAI-chat-completions surface of the MI355X engine — the boundary the reference talks to.
+
+The reference never calls a model in-process: ``process_page`` POSTs ``build_page_query``'s dict to
+``{server}/chat/completions`` (/root/reference/karanta/pipeline.py:115-171, :317-344) and the bulk
+workers go through ``VLLMClient.generate`` (/root/reference/bulk_processing/workers/vllm_client.py:
+155-227).  This module turns exactly that request dict into engine work and the engine's tokens
+back into exactly the response JSON those callers parse:
+
+    choices[0].message.content, choices[0].finish_reason in {"stop","length"},
+    usage.{prompt_tokens, completion_tokens, total_tokens}, model
+
+Status codes follow what ``process_page`` distinguishes (pipeline.py:321-332): 200, 400 (bad
+request: caller skips the attempt), 500 (internal error: caller retries).
+
+Not built yet: continuous batching, sampling with temperature > 0
+(requests are served greedy — the reference's ``build_page_query`` default of 0.0, pipeline.py:170),
+``guided_regex`` / ``response_format`` constrained decoding, logprobs.
+"""
+from __future__ import annotations
+
+import json
+import queue
+import threading
+import time
+import uuid
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import image_processing as IP
+from .config import ModelConfig
+
+DEFAULT_SYSTEM = "You are a helpful assistant."
+
+
+# ----------------------------------------------------------------------------- tokenizers
+class ByteTokenizer:
+    """Tokenizer of last resort (tests, random-init models): UTF-8 bytes as ids 0..255.
+    Special tokens keep the model's own ids.  Real checkpoints use :class:`HFTokenizer`."""
+
+    def __init__(self, cfg: ModelConfig, im_start: Optional[int] = None, im_end: Optional[int] = None):
+        self.cfg = cfg
+        self.im_start = im_start if im_start is not None else min(cfg.text.vocab_size - 1, 151644)
+        self.im_end = im_end if im_end is not None else cfg.eos_token_ids[0]
+        self.newline = 10
+
+    def encode(self, text: str) -> List[int]:
+        return list(text.encode("utf-8"))
+
+    def decode(self, ids: Sequence[int]) -> str:
+        special = set(self.cfg.eos_token_ids) | {self.im_start, self.cfg.pad_token_id}
+        return bytes(int(i) for i in ids if 0 <= int(i) < 256 and int(i) not in special).decode("utf-8", "replace")
+
+
+class HFTokenizer:
+    """``tokenizer.json`` of a real Qwen2-VL checkpoint through the `tokenizers` library."""
+
+    def __init__(self, path: str, cfg: ModelConfig):
+        from tokenizers import Tokenizer
+
+        self.tk = Tokenizer.from_file(path)
+        self.cfg = cfg
+        self.im_start = self.tk.token_to_id("<|im_start|>")
+        self.im_end = self.tk.token_to_id("<|im_end|>")
+        self.newline = self.tk.encode("\n", add_special_tokens=False).ids[0]
+
+    def encode(self, text: str) -> List[int]:
+        return self.tk.encode(text, add_special_tokens=False).ids
+
+    def decode(self, ids: Sequence[int]) -> str:
+        return self.tk.decode([int(i) for i in ids], skip_special_tokens=True)
+
+
+# ----------------------------------------------------------------------------- request parsing
+class BadRequest(ValueError):
+    """Maps to HTTP 400 (the reference skips the attempt, pipeline.py:321-324)."""
+
+
+@dataclass
+class ParsedRequest:
+    input_ids: np.ndarray
+    pixel_values: Optional[np.ndarray]
+    grids: List[Tuple[int, int, int]]
+    max_tokens: int
+    model: str
+
+
+class ChatFrontend:
+    """messages -> Qwen2-VL chat-template token ids + image patches.
+
+    Template (Qwen2-VL): ``<|im_start|>system\\n{sys}<|im_end|>\\n<|im_start|>user\\n{content}<|im_end|>\\n
+    <|im_start|>assistant\\n``; an ``image_url`` part becomes ``<|vision_start|><|image_pad|>*T<|vision_end|>``
+    in place, parts in message order (the reference puts the text first, the image second:
+    /root/reference/karanta/data/utils.py:283-297)."""
+
+    def __init__(self, cfg: ModelConfig, tokenizer, min_pixels: int = IP.MIN_PIXELS,
+                 max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT, max_model_len: int = 16384):
+        self.cfg, self.tok = cfg, tokenizer
+        self.min_pixels, self.max_pixels = min_pixels, max_pixels
+        self.max_model_len = max_model_len  # reference --max_model_len default (pipeline.py:1225-1230)
+
+    def _turn(self, role: str, body: List[int]) -> List[int]:
+        t = self.tok
+        return [t.im_start] + t.encode(role) + [t.newline] + body + [t.im_end, t.newline]
+
+    def parse(self, req: Dict[str, Any]) -> ParsedRequest:
+        if not isinstance(req, dict) or not isinstance(req.get("messages"), list) or not req["messages"]:
+            raise BadRequest("`messages` must be a non-empty list")
+        mt = req.get("max_tokens", req.get("max_completion_tokens"))
+        max_tokens = 100 if mt is None else int(mt)
+        if max_tokens < 1:
+            raise BadRequest("max_tokens must be >= 1")
+        ids: List[int] = []
+        pvs, grids = [], []
+        if req["messages"][0].get("role") != "system":
+            ids += self._turn("system", self.tok.encode(DEFAULT_SYSTEM))
+        for msg in req["messages"]:
+            role, content = msg.get("role"), msg.get("content")
+            if role not in ("system", "user", "assistant"):
+                raise BadRequest(f"unsupported role {role!r}")
+            body: List[int] = []
+            parts = [{"type": "text", "text": content}] if isinstance(content, str) else content
+            if not isinstance(parts, list):
+                raise BadRequest("message content must be a string or a list of parts")
+            for part in parts:
+                kind = part.get("type")
+                if kind == "text":
+                    body += self.tok.encode(part.get("text", ""))
+                elif kind in ("image_url", "image"):
+                    url = part["image_url"]["url"] if kind == "image_url" else part["image"]
+                    try:
+                        img = IP.decode_data_url(url)
+                    except Exception as e:  # undecodable image -> 400, like vLLM
+                        raise BadRequest(f"cannot decode image: {e}") from e
+                    pv, grid = IP.image_to_patches(img, self.min_pixels, self.max_pixels)
+                    pvs.append(pv)
+                    grids.append(grid)
+                    n_tok = grid[0] * grid[1] * grid[2] // (self.cfg.vision.spatial_merge_size ** 2)
+                    body += [self.cfg.vision_start_token_id] + [self.cfg.image_token_id] * n_tok + [self.cfg.vision_end_token_id]
+                else:
+                    raise BadRequest(f"unsupported content part {kind!r}")
+            ids += self._turn(role, body)
+        ids += [self.tok.im_start] + self.tok.encode("assistant") + [self.tok.newline]
+        if len(ids) + max_tokens > self.max_model_len:
+            raise BadRequest(f"prompt ({len(ids)} tokens) + max_tokens ({max_tokens}) exceeds max_model_len {self.max_model_len}")
+        return ParsedRequest(np.asarray(ids, np.int64), np.concatenate(pvs, 0) if pvs else None, grids, max_tokens,
+                             str(req.get("model", "karantaocr")))
+
+
+# ----------------------------------------------------------------------------- in-process server
+class LocalServer:
+    """Static-batching scheduler in front of one engine (one GPU).  Thread-safe: callers block in
+    :meth:`chat_completions` while a worker thread groups whatever is waiting (up to the engine's
+    max batch) into one ``generate`` call."""
+
+    def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
+                 batch_wait_s: float = 0.005, log=print):
+        self.engine, self.frontend, self.name = engine, frontend, served_model_name
+        self.batch_wait_s, self.log = batch_wait_s, log
+        self._q: "queue.Queue" = queue.Queue()
+        self._running = 0
+        self._stop = False
+        self.pages_done = 0
+        self.latencies: List[float] = []
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        # the reference watches the server's output for one of these lines (pipeline.py:790-800)
+        self.log("Starting vLLM API server (karanta MI355X engine)")
+
+    # -- public surface -------------------------------------------------------
+    def health(self) -> Tuple[int, dict]:
+        return 200, {"status": "ok", "engine": "karanta-mi355x", "running": self._running, "waiting": self._q.qsize()}
+
+    def models(self) -> Tuple[int, dict]:
+        return 200, {"object": "list", "data": [{"id": self.name, "object": "model", "owned_by": "karanta"}]}
+
+    def chat_completions(self, req: Dict[str, Any]) -> Tuple[int, dict]:
+        t0 = time.time()
+        try:
+            parsed = self.frontend.parse(req)
+        except BadRequest as e:
+            return 400, {"error": {"message": str(e), "type": "BadRequestError", "code": 400}}
+        except Exception as e:  # malformed beyond recognition
+            return 400, {"error": {"message": f"malformed request: {e}", "type": "BadRequestError", "code": 400}}
+        slot: Dict[str, Any] = {"req": parsed, "done": threading.Event()}
+        self._q.put(slot)
+        slot["done"].wait()
+        if "error" in slot:
+            return 500, {"error": {"message": slot["error"], "type": "InternalServerError", "code": 500}}
+        toks, reason = slot["tokens"], slot["reason"]
+        text = self.frontend.tok.decode(toks)
+        self.latencies.append(time.time() - t0)
+        n_in, n_out = int(len(parsed.input_ids)), int(len(toks))
+        return 200, {
+            "id": "chatcmpl-" + uuid.uuid4().hex, "object": "chat.completion", "created": int(time.time()),
+            "model": req.get("model", self.name),
+            "choices": [{"index": 0, "message": {"role": "assistant", "content": text}, "finish_reason": reason}],
+            "usage": {"prompt_tokens": n_in, "completion_tokens": n_out, "total_tokens": n_in + n_out},
+        }
+
+    def close(self):
+        self._stop = True
+        self._q.put(None)
+        self._thread.join(timeout=5)
+
+    # -- scheduler --------------------------------------------------------------
+    def _loop(self):
+        from .engine import PageRequest
+
+        while not self._stop:
+            first = self._q.get()
+            if first is None:
+                break
+            batch = [first]
+            deadline = time.time() + self.batch_wait_s
+            while len(batch) < self.engine.B:
+                try:
+                    nxt = self._q.get(timeout=max(0.0, deadline - time.time()))
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    self._stop = True
+                    break
+                batch.append(nxt)
+            self._running = len(batch)
+            # same shape as vLLM's periodic stats line that the reference scrapes (pipeline.py:782-800)
+            self.log(f"Running: {self._running} reqs, Waiting: {self._q.qsize()} reqs")
+            try:
+                pages = [PageRequest(s["req"].input_ids, s["req"].pixel_values, s["req"].grids) for s in batch]
+                res = self.engine.generate(pages, max(s["req"].max_tokens for s in batch))
+                for s, toks, reason in zip(batch, res.tokens, res.finish_reasons):
+                    mt = s["req"].max_tokens
+                    if len(toks) > mt:
+                        toks, reason = toks[:mt], "length"
+                    eos = set(int(e) for e in self.engine.cfg.eos_token_ids)
+                    if reason == "stop" and len(toks) and int(toks[-1]) in eos:
+                        toks = toks[:-1]  # the EOS token is not part of the message content
+                    s["tokens"], s["reason"] = toks, reason
+            except Exception as e:  # engine failure -> 500 for every request of the batch
+                for s in batch:
+                    s["error"] = f"{type(e).__name__}: {e}"
+            self.pages_done += len(batch)
+            self._running = 0
+            for s in batch:
+                s["done"].set()
+
+
+# registry used by the in-process VLLMClient (clients.py): port -> LocalServer
+_LOCAL_SERVERS: Dict[Tuple[str, int], LocalServer] = {}
+
+
+def register_local_server(port: int, server: LocalServer, host: str = "localhost") -> None:
+    _LOCAL_SERVERS[(host, int(port))] = server
+
+
+def unregister_local_server(port: int, host: str = "localhost") -> None:
+    _LOCAL_SERVERS.pop((host, int(port)), None)
+
+
+def local_server(host: str, port: int) -> Optional[LocalServer]:
+    return _LOCAL_SERVERS.get((host, int(port))) or (_LOCAL_SERVERS.get(("localhost", int(port))) if host in ("127.0.0.1", "localhost") else None)
+
+
+# ----------------------------------------------------------------------------- HTTP shim
+def serve_http(server: LocalServer, port: int, host: str = "127.0.0.1"):
+    """OpenAI-compatible HTTP front (``POST /v1/chat/completions``, ``GET /v1/models``, ``GET /health``)
+    so the unmodified reference (``karanta.pipeline --server http://host:port/v1``, the Celery workers'
+    ``VLLMClient``) can point at this engine.  Returns the running ``ThreadingHTTPServer``."""
+    from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
+
+    class Handler(BaseHTTPRequestHandler):
+        protocol_version = "HTTP/1.1"
+
+        def log_message(self, *a):  # --disable-log-requests
+            pass
+
+        def _send(self, status: int, body: dict):
+            data = json.dumps(body).encode()
+            self.send_response(status)
+            self.send_header("Content-Type", "application/json")
+            self.send_header("Content-Length", str(len(data)))
+            self.send_header("Connection", "close")
+            self.end_headers()
+            self.wfile.write(data)
+            self.close_connection = True
+
+        def do_GET(self):
+            path = self.path.split("?")[0].rstrip("/")
+            if path == "/health":
+                self._send(*server.health())
+            elif path in ("/v1/models", "/models"):
+                self._send(*server.models())
+            else:
+                self._send(404, {"error": {"message": "not found", "code": 404}})
+
+        def do_POST(self):
+            path = self.path.split("?")[0].rstrip("/")
+            if path not in ("/v1/chat/completions", "/chat/completions"):
+                return self._send(404, {"error": {"message": "not found", "code": 404}})
+            try:
+                n = int(self.headers.get("Content-Length", "0"))
+                req = json.loads(self.rfile.read(n))
+            except Exception as e:
+                return self._send(400, {"error": {"message": f"invalid JSON: {e}", "type": "BadRequestError", "code": 400}})
+            self._send(*server.chat_completions(req))
+
+    httpd = ThreadingHTTPServer((host, port), Handler)
+    httpd.daemon_threads = True
+    threading.Thread(target=httpd.serve_forever, daemon=True).start()
+    server.log("The server is fired up and ready to roll!")
+    return httpd

@@ -1,0 +1,195 @@
+"""Drop-in surfaces with a fake engine (no GPU): chat-template front end, in-process server,
+VLLMClient-shaped client (result schema + error behaviour of the reference), raw HTTP/1.1 round
+trip in the style of the reference's hand-rolled `apost` (karanta/pipeline.py:178-272)."""
+import asyncio
+import json
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from karanta_ocr_amd import image_processing as IP
+from karanta_ocr_amd import serving as S
+from karanta_ocr_amd.clients import (VLLMClient, VLLMClientError, VLLMClientManager, get_vllm_client_for_worker)
+from karanta_ocr_amd.config import CONFIGS
+
+CFG = CONFIGS["tiny"]
+
+
+class FakeEngine:
+    """Emits b"OK<eos>" for every page, or echoes the prompt length; records what it was given."""
+    B = 4
+    cfg = CFG
+
+    def __init__(self, fail=False):
+        self.calls, self.fail = [], fail
+
+    def generate(self, pages, max_new_tokens, **kw):
+        if self.fail:
+            raise RuntimeError("boom")
+        self.calls.append((len(pages), max_new_tokens, [len(p.input_ids) for p in pages]))
+        toks, reasons = [], []
+        for p in pages:
+            full = np.asarray(list(b"OK") + [CFG.eos_token_ids[0]], np.int64)
+            if max_new_tokens < 3:
+                toks.append(full[:max_new_tokens]); reasons.append("length")
+            else:
+                toks.append(full); reasons.append("stop")
+        return SimpleNamespace(tokens=toks, finish_reasons=reasons, prompt_tokens=[len(p.input_ids) for p in pages])
+
+
+def vision_message(text="read this", h=56, w=84):
+    url = IP.encode_png_data_url(IP.synthetic_page(1, h, w))
+    # shape built by the reference's create_vision_message (karanta/data/utils.py:283-297)
+    return [{"role": "user", "content": [{"type": "text", "text": text}, {"type": "image_url", "image_url": {"url": url}}]}]
+
+
+@pytest.fixture
+def server():
+    logs = []
+    srv = S.LocalServer(FakeEngine(), S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=logs.append)
+    srv.logs = logs
+    yield srv
+    srv.close()
+
+
+def test_chat_template_and_image_placeholders():
+    fe = S.ChatFrontend(CFG, S.ByteTokenizer(CFG))
+    p = fe.parse({"messages": vision_message("hi"), "max_tokens": 7})
+    ids = p.input_ids.tolist()
+    assert p.max_tokens == 7 and p.grids == [(1, 4, 6)] and p.pixel_values.shape == (24, 1176)
+    assert ids.count(CFG.image_token_id) == 6                      # 4*6 patches / 4
+    i = ids.index(CFG.vision_start_token_id)
+    assert ids[i + 7] == CFG.vision_end_token_id
+    assert bytes(ids[i - 2:i]) == b"hi"                            # text first, image second
+    tk = fe.tok
+    assert ids[0] == tk.im_start and bytes(ids[1:7]) == b"system"  # default system turn
+    assert ids[-11:] == [tk.im_start] + list(b"assistant") + [tk.newline]
+
+
+@pytest.mark.parametrize("req", [{}, {"messages": []}, {"messages": [{"role": "tool", "content": "x"}]},
+                                 {"messages": [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "data:image/png;base64,AAAA"}}]}]},
+                                 {"messages": [{"role": "user", "content": "x"}], "max_tokens": 0},
+                                 {"messages": [{"role": "user", "content": "x" * 200}], "max_tokens": 16384}])
+def test_bad_requests_are_400(server, req):
+    status, body = server.chat_completions(req)
+    assert status == 400 and "error" in body
+
+
+def test_completion_schema_and_log_protocol(server):
+    status, body = server.chat_completions({"model": "karantaocr", "messages": vision_message(), "max_tokens": 16, "temperature": 0.0})
+    assert status == 200
+    assert body["choices"][0]["message"]["content"] == "OK"
+    assert body["choices"][0]["finish_reason"] == "stop"
+    u = body["usage"]
+    assert u["total_tokens"] == u["prompt_tokens"] + u["completion_tokens"] and u["prompt_tokens"] > 6
+    assert body["model"] == "karantaocr"
+    # lines the reference scrapes from the server's output (karanta/pipeline.py:782-800)
+    assert any("Starting vLLM API server" in l for l in server.logs)
+    import re
+    assert any(re.search(r"Running: (\d+)", l) and re.search(r"(?:Waiting|Pending):\s*(\d+)", l) for l in server.logs)
+
+
+def test_max_tokens_truncation_is_length(server):
+    status, body = server.chat_completions({"messages": [{"role": "user", "content": "x"}], "max_tokens": 1})
+    assert status == 200 and body["choices"][0]["finish_reason"] == "length" and body["usage"]["completion_tokens"] == 1
+
+
+def test_engine_failure_is_500():
+    srv = S.LocalServer(FakeEngine(fail=True), S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None)
+    status, body = srv.chat_completions({"messages": [{"role": "user", "content": "x"}]})
+    srv.close()
+    assert status == 500 and "boom" in body["error"]["message"]
+
+
+def test_concurrent_requests_are_batched(server):
+    import threading
+    out = []
+    ts = [threading.Thread(target=lambda: out.append(server.chat_completions({"messages": [{"role": "user", "content": "x"}]})[0]))
+          for _ in range(6)]
+    server.batch_wait_s = 0.2
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert out == [200] * 6
+    assert max(c[0] for c in server.engine.calls) > 1 and sum(c[0] for c in server.engine.calls) == 6
+    assert all(c[0] <= FakeEngine.B for c in server.engine.calls)
+
+
+def test_vllm_client_in_process(server):
+    S.register_local_server(8765, server)
+    try:
+        c = VLLMClient(port=8765)
+        assert c.health_check(force=True)
+        assert c.get_server_info()["models"] == ["karantaocr"]
+        r = c.generate(vision_message(), max_tokens=6000, temperature=0.1, response_format={"type": "json_schema"})
+        # result schema of the reference's _process_response (vllm_client.py:240-261)
+        assert set(r) == {"text", "finish_reason", "model", "usage", "metadata"}
+        assert r["text"] == "OK" and r["finish_reason"] == "stop" and r["model"] == "karantaocr"
+        assert set(r["usage"]) == {"prompt_tokens", "completion_tokens", "total_tokens"}
+        md = r["metadata"]
+        assert md["server_url"] == "http://localhost:8765/v1" and "messages" not in md["generation_params"]
+        assert md["generation_params"]["max_tokens"] == 6000 and md["generation_time"] >= 0
+        b = c.batch_generate([vision_message(), "plain text"], max_tokens=5)
+        assert [x["metadata"]["batch_index"] for x in b] == [0, 1] and b[1]["text"] == "OK"
+    finally:
+        S.unregister_local_server(8765)
+
+
+def test_vllm_client_errors():
+    c = VLLMClient(port=1, max_retries=1, retry_delay=0.01, health_check_timeout=0.2)   # nothing listens on port 1
+    with pytest.raises(VLLMClientError, match="is not healthy"):
+        c.generate([{"role": "user", "content": "x"}])
+    srv = S.LocalServer(FakeEngine(fail=True), S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None)
+    S.register_local_server(8766, srv)
+    try:
+        c = VLLMClient(port=8766, max_retries=2, retry_delay=0.001)
+        with pytest.raises(VLLMClientError, match=r"Generation failed after 3 attempts"):
+            c.generate([{"role": "user", "content": "x"}])
+    finally:
+        S.unregister_local_server(8766); srv.close()
+
+
+def test_worker_name_routing():
+    m = VLLMClientManager({8006: "gpu-node-1"})
+    c = m.get_client_from_worker_name("worker_port_8006_1@hostname")
+    assert c.port == 8006 and c.host == "gpu-node-1" and m.get_client(8006) is c
+    with pytest.raises(VLLMClientError, match="Invalid worker name format"):
+        m.get_client_from_worker_name("worker_8006@h")
+    assert get_vllm_client_for_worker("worker_port_9001_0@h").port == 9001
+
+
+async def raw_post(url_host, url_port, path, payload):
+    """HTTP/1.1 POST with `Connection: close`, content-length body — what the reference's apost sends."""
+    reader, writer = await asyncio.open_connection(url_host, url_port)
+    body = json.dumps(payload)
+    writer.write((f"POST {path} HTTP/1.1\r\nHost: {url_host}\r\nContent-Type: application/json\r\n"
+                  f"Content-Length: {len(body)}\r\nConnection: close\r\n\r\n{body}").encode())
+    await writer.drain()
+    status = int((await reader.readline()).split()[1])
+    headers = {}
+    while True:
+        line = await reader.readline()
+        if line in (b"\r\n", b"\n", b""):
+            break
+        k, _, v = line.decode().partition(":")
+        headers[k.strip().lower()] = v.strip()
+    data = await reader.readexactly(int(headers["content-length"]))
+    writer.close()
+    return status, json.loads(data)
+
+
+def test_http_shim_round_trip(server):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    httpd = S.serve_http(server, port)
+    try:
+        status, body = asyncio.run(raw_post("127.0.0.1", port, "/v1/chat/completions",
+                                            {"model": "karantaocr", "messages": vision_message(), "max_tokens": 4000, "temperature": 0.0}))
+        assert status == 200 and body["choices"][0]["finish_reason"] == "stop" and body["usage"]["total_tokens"] <= 16384
+        status, body = asyncio.run(raw_post("127.0.0.1", port, "/v1/chat/completions", {"messages": []}))
+        assert status == 400
+        c = VLLMClient(port=port, host="127.0.0.1")            # the same client over real HTTP
+        assert c.health_check(force=True) and c.get_server_info()["models"] == ["karantaocr"]
+        assert c.generate(vision_message(), max_tokens=8)["text"] == "OK"
+        assert any("ready to roll" in l for l in server.logs)
+    finally:
+        httpd.shutdown()
