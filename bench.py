@@ -111,6 +111,19 @@ def cpu_baseline(cfg, pv_page: np.ndarray, grid, ids: np.ndarray, t_out: int) ->
     }
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed PMC pass (None if absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            ks = json.load(f)["kernels"]
+        for name, v in ks.items():
+            if "dec_linear_kernel<2, 1" in name:   # <NT=2, EPI=SILU, ...>
+                return v["hbm_read_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,9 +257,10 @@ def main():
                 "achieved": round(prof["bytes_per_launch"] / (prof["avg_us"] * 1e-6) / 1e9, 1) if prof["avg_us"] else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(prof["bytes_per_launch"] / (prof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof["avg_us"] else None,
-                "traffic": None,
+                "traffic": pmc_traffic(), "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)",
                 "bytes_per_launch": prof["bytes_per_launch"], "avg_us": round(prof["avg_us"], 3),
                 "min_us": round(prof["min_us"], 3), "launches_timed": prof["launches"],
+                "event_bracket_us": round(prof["bracket_us"], 3), "null_bracket_us": round(prof["null_bracket_us"], 3),
             },
         }
         if bcast_s is not None:

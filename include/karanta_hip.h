@@ -273,6 +273,8 @@ int kr_selftest_mfma(kr_stream s);
 /* Diagnostic: microseconds per kernel of a dependent chain of `n` tiny kernels (`blocks` x 256
  * threads; dirty != 0: each block also writes 4 KiB) replayed from a hipGraph on stream `s`. */
 int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, float* us_per_kernel);
+/* Launches an empty kernel (1 wave): calibrates the cost of a HIP-event bracket around one launch. */
+int kr_launch_null(kr_stream s);
 
 #ifdef __cplusplus
 }

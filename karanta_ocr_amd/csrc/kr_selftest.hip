@@ -123,3 +123,12 @@ extern "C" int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, 
     hipFree(buf);
     return KR_OK;
 }
+
+// A kernel that does nothing: bench.py brackets it with the same two HIP events it puts around the
+// roofline kernel, to calibrate the bracket's own cost (event packets + dispatch latency) live.
+namespace { __global__ void null_kernel() {} }
+extern "C" int kr_launch_null(kr_stream s) {
+    null_kernel<<<1, 64, 0, kr_hs(s)>>>();
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}

@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) average duration of the decode kernels."""
-import collections, csv, glob, sys
+import collections, csv, glob, re, sys
 import numpy as np
 
 f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof*/*/*_kernel_trace.csv"))[-1]
@@ -7,7 +7,8 @@ rows = list(csv.DictReader(open(f)))
 g = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    key = (n.split("(")[0][-52:], r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"], r["VGPR_Count"], r["LDS_Block_Size"])
+    m = re.search(r"(\w+<[^>]*>|\w+)\(", n.replace("(anonymous namespace)::", ""))
+    key = ((m.group(1) if m else n)[-52:], r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"], r["VGPR_Count"], r["LDS_Block_Size"])
     g[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in g.values())
 for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1])):

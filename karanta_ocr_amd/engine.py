@@ -471,11 +471,14 @@ class Engine:
             self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o,
                       attn_partials=self.d_ws)
             if self._prof_on:
-                e0, e1 = self._prof_event_pair()
+                # [e0] null kernel [e1] gate/up [e2]: the first bracket calibrates the second one
+                (e0, e1), (e2, _) = self._prof_event_pair(), self._prof_event_pair()
                 L.kr_event_record(e0, s)
+                L.kr_launch_null(s)
+                L.kr_event_record(e1, s)
             self._dec(DEC_SILU, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
             if self._prof_on:
-                L.kr_event_record(e1, s)
+                L.kr_event_record(e2, s)
             self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_down)
         self._lm_head_and_sample(B)
 
@@ -493,20 +496,27 @@ class Engine:
     def kernel_profile(self, reset: bool = True) -> Dict[str, float]:
         """Durations of the decode gate/up projection (`dec_linear_kernel<2, SILU>`, the kernel that moves
         half of the decoder's bytes) measured with HIP events on the launch stream during the profiled
-        eager steps.  Returns {launches, avg_us, min_us, bytes_per_launch}."""
+        eager steps.  Each sample is a HIP-event bracket around the one launch, minus the same bracket
+        around an empty kernel recorded right before it (the bracket's own cost: two event packets and a
+        dispatch).  Returns {launches, avg_us, min_us, bracket_us, null_bracket_us, bytes_per_launch}."""
         self.stream.synchronize()
         ms = C.c_float()
-        vals = []
-        for e0, e1 in self._prof_events[: self._prof_next]:
+        vals, nulls = [], []
+        ev = self._prof_events[: self._prof_next]
+        for (e0, e1), (e2, _) in zip(ev[0::2], ev[1::2]):
             self.L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+            nulls.append(ms.value * 1e3)
+            self.L.kr_event_elapsed_ms(e1, e2, C.byref(ms))
             vals.append(ms.value * 1e3)
         if reset:
             self._prof_next = 0
         t = self.cfg.text
         B = self._last_batch
         nbytes = 2 * (2 * t.intermediate_size * t.hidden_size + t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
-        return {"launches": len(vals), "avg_us": float(np.mean(vals)) if vals else 0.0,
-                "min_us": float(np.min(vals)) if vals else 0.0, "bytes_per_launch": nbytes}
+        raw = float(np.mean(vals)) if vals else 0.0
+        null = float(np.mean(nulls)) if nulls else 0.0
+        return {"launches": len(vals), "bracket_us": raw, "null_bracket_us": null, "avg_us": max(raw - null, 0.0),
+                "min_us": float(np.min(vals) - null) if vals else 0.0, "bytes_per_launch": nbytes}
 
     def _graph_for(self, B: int) -> int:
         key = (B, self._ignore_eos)
