@@ -117,7 +117,7 @@ def pmc_traffic():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             ks = json.load(f)["kernels"]
         for name, v in ks.items():
-            if "dec_linear_kernel<2, 1" in name:   # <NT=2, EPI=SILU, ...>
+            if "dec_linear_kernel<1, 4" in name:   # <NT=1, EPI=SILU8, ...>
                 return v["hbm_read_bytes_per_launch"]
     except Exception:
         pass
@@ -252,7 +252,7 @@ def main():
                                 "frac_of_hbm_peak": round(t_step_roof / decode_step_s, 4) if decode_step_s > 0 else None,
                                 "pages_per_s_roof_per_gpu": round(B / (T_out * t_step_roof), 3)},
             "roofline": {
-                "kernel": "dec_linear_kernel<2, SILU, 4> (decode gate/up projection + fused RMSNorm + SiLU*mul)",
+                "kernel": "dec_linear_kernel<1, 4, 4> = <NT 1, SILU8, 4 waves> (decode gate/up projection + fused RMSNorm + SiLU*mul)",
                 "bound": "hbm",
                 "achieved": round(prof["bytes_per_launch"] / (prof["avg_us"] * 1e-6) / 1e9, 1) if prof["avg_us"] else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

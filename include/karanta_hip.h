@@ -47,6 +47,7 @@ typedef uint16_t kr_bf16;
 #define KR_EPI_QUICK_GELU 1 /* x*sigmoid(1.702x): ViT fc1, TF:293-301 */
 #define KR_EPI_GELU_ERF 2   /* exact GELU: PatchMerger, TF:277-290 */
 #define KR_EPI_SILU_MUL 3   /* silu(gate)*up with gate/up rows interleaved in 16-row groups: Qwen2MLP, TF:453-466 */
+#define KR_EPI_SILU_MUL8 4  /* same, interleaved in 8-row groups (g0..g7,u0..u7,g8..): one 16-row MFMA tile = 8 features */
 
 /* ------------------------------------------------------------------ library / device */
 int kr_version(void);
@@ -229,6 +230,7 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
 #define KR_DEC_SILU 1
 #define KR_DEC_ROPE_KV 2
 #define KR_DEC_ARGMAX 3
+#define KR_DEC_SILU8 4      /* SILU with 8-row interleave: one tile per workgroup -> 2x the workgroups of KR_DEC_SILU */
 int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                      const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                      kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
@@ -246,6 +248,11 @@ int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16*
                          const int32_t* ctx_len, kr_bf16* out, float* workspace, int32_t* counters,
                          int batch, int heads, int kv_heads, int hd, int s_max, int n_split,
                          float scale, kr_stream s);
+
+/* Merge of the partials kr_attn_decode_fused leaves with out == NULL into bf16 out [batch, heads*hd]
+ * (one small launch; the alternative to merging inside the consumer's prologue). */
+int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split,
+                         kr_stream s);
 
 /* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out[b] and
  * history[(ctx_len[b] + 1 - prompt_len[b]) * hist_stride + b] (= this sequence's generated-token

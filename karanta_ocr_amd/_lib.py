@@ -57,6 +57,7 @@ SIGNATURES = {
     "kr_linear_decode": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p,
                          c_p, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
+    "kr_attn_decode_merge": [c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
     "kr_comm_unique_id": [c_p],
     "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],
@@ -68,8 +69,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"kr_last_error": C.c_char_p}
 
-EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SILU_MUL = 0, 1, 2, 3
-DEC_PLAIN, DEC_SILU, DEC_ROPE_KV, DEC_ARGMAX = 0, 1, 2, 3
+EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SILU_MUL, EPI_SILU_MUL8 = 0, 1, 2, 3, 4
+DEC_PLAIN, DEC_SILU, DEC_ROPE_KV, DEC_ARGMAX, DEC_SILU8 = 0, 1, 2, 3, 4
 
 
 class _Lib:

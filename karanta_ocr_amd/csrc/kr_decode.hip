@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int DEPI_PLAIN = 0, DEPI_SILU = 1, DEPI_ROPE_KV = 2, DEPI_ARGMAX = 3;
+constexpr int DEPI_PLAIN = 0, DEPI_SILU = 1, DEPI_ROPE_KV = 2, DEPI_ARGMAX = 3, DEPI_SILU8 = 4;
 
 struct DecLinArgs {
     const kr_bf16* x; int64_t ldx;
@@ -292,6 +292,19 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
         }
         return;
     }
+    if (EPI == DEPI_SILU8) {
+        // one 16-row tile = 8 features: gate rows in lane groups 0,1, their up rows in groups 2,3 (lane ^ 32)
+        float u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(sum[0][j], 32, 64);
+        if (b < M && fg < 2 && tile[0] < ntiles) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(sum[0][j]) * u[j]);
+            *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + tile[0] * 8 + fg * 4) = o;
+        }
+        return;
+    }
     if (b >= M) return;
     if (EPI == DEPI_SILU) {
         if (tile[0] >= ntiles) return;
@@ -532,6 +545,23 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
     }
 }
 
+// Merge of the split-KV partials as a launch of its own: one 128-thread workgroup per (sequence, head).
+// (Cheaper end-to-end than replicating the merge in every o_proj workgroup's prologue: measured.)
+__global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict__ ws, kr_bf16* __restrict__ out, int n_split) {
+    constexpr int HD = 128, REC = HD + 4;
+    const int bh = blockIdx.x, d = threadIdx.x;
+    const float* w = ws + (int64_t)bh * n_split * REC;
+    float mm = -1e30f;
+    for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * REC + HD]);
+    float acc = 0.f, ll = 0.f;
+    for (int p = 0; p < n_split; ++p) {
+        const float sc = __builtin_amdgcn_exp2f(w[p * REC + HD] - mm);
+        acc += w[p * REC + d] * sc;
+        ll += w[p * REC + HD + 1] * sc;
+    }
+    out[(int64_t)bh * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+}
+
 // =====================================================================================
 // greedy sampling from the lm_head partials + per-step bookkeeping
 // =====================================================================================
@@ -657,6 +687,9 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
         case DEPI_SILU:
             KR_CHECK_ARG(out && N % 32 == 0 && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode: SILU output");
             return launch_dec_w<2, DEPI_SILU>(a, ntiles / 2, waves, s);
+        case DEPI_SILU8:
+            KR_CHECK_ARG(out && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode: SILU8 output");
+            return launch_dec_w<1, DEPI_SILU8>(a, ntiles, waves, s);
         case DEPI_ROPE_KV:
             KR_CHECK_ARG(bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
                          "kr_linear_decode: ROPE_KV pointers");
@@ -687,6 +720,15 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     else
         attn_decode2_kernel<4><<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
             q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split,
+                                    kr_stream s) {
+    KR_CHECK_ARG(workspace && out && batch > 0 && heads > 0 && n_split > 0, "kr_attn_decode_merge: bad args");
+    KR_CHECK_ARG(hd == 128, "kr_attn_decode_merge: hd=%d (only 128)", hd);
+    attn_merge_kernel<<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

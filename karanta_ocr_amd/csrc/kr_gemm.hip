@@ -106,8 +106,24 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int64_t m = m0 + wr * 64 + mt * 16 + fr;
-        if (m >= M) continue;
-        if (EPI == KR_EPI_SILU_MUL) {
+        if (EPI != KR_EPI_SILU_MUL8 && m >= M) continue;  // (SILU_MUL8 shuffles across lanes: no early exit)
+        if (EPI == KR_EPI_SILU_MUL8) {
+            // gate/up interleaved in groups of 8 rows: a 16-row tile holds gate rows in lane groups 0,1
+            // and the matching up rows in lane groups 2,3 (lane ^ 32)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(acc[nt][mt][j], 32, 64);
+                const int n = n0 + wc * 64 + nt * 16;
+                if (fg < 2 && n < N && m < M) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[nt][mt][j]) * u[j]);
+                    *reinterpret_cast<bf16x4*>(C + m * ldc + (n >> 1) + fg * 4) = o;
+                }
+            }
+        } else if (EPI == KR_EPI_SILU_MUL) {
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 const int n = n0 + wc * 64 + pr * 32 + fg * 4;  // gate row index in W'
@@ -206,6 +222,9 @@ extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, con
             KR_CHECK_ARG(N % 32 == 0 && ldc >= N / 2 && !bias && !residual,
                          "kr_gemm_bf16: SILU_MUL needs N%%32==0, no bias/residual");
             return launch_gemm<KR_EPI_SILU_MUL>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
+        case KR_EPI_SILU_MUL8:
+            KR_CHECK_ARG(ldc >= N / 2 && !bias && !residual, "kr_gemm_bf16: SILU_MUL8 takes no bias/residual");
+            return launch_gemm<KR_EPI_SILU_MUL8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         default:
             kr_set_error("kr_gemm_bf16: unknown epilogue %d", epilogue);
             return KR_ERR_ARG;

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -21,7 +22,7 @@ import numpy as np
 import torch
 
 from . import positions as POS
-from ._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL,
+from ._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8,
                    KarantaHipError, lib, ptr)
 from .config import ModelConfig
 from .weights import pack_w16x64, to_bf16_bits
@@ -45,7 +46,7 @@ class DeviceWeights:
 
     * ViT Linears keep their [out, in] row-major layout (K contiguous = MFMA fragment order);
     * decoder q/k/v are fused into one [q+2kv, d] matrix, gate/up into one [2*ff, d] matrix with
-      rows interleaved in groups of 16 (KR_EPI_SILU_MUL);
+      rows interleaved in groups of 8 (KR_EPI_SILU_MUL8: one 16-row MFMA tile = 8 gate rows + their 8 up rows);
     * every decoder Linear and the lm_head are stored PACKED as [N/16][K/64][16][64] tiles
       (weights.pack_w16x64): decode streams them linearly from HBM, prefill reads the same copy
       through kr_gemm_bf16(w_packed=1).  A tied lm_head gets its own packed copy (the embedding
@@ -127,8 +128,8 @@ class DeviceWeights:
             self._put("vit.merger." + b, _bits(w[V + a]))
         self._put("llm.embed", _bits(w[Lm + "embed_tokens.weight"]))
         ff = t.intermediate_size
-        if ff % 16:
-            raise KarantaHipError(f"intermediate_size {ff} must be a multiple of 16")
+        if ff % 8:
+            raise KarantaHipError(f"intermediate_size {ff} must be a multiple of 8")
         for i in range(t.num_layers):
             s, d = f"{Lm}layers.{i}.", f"llm.{i}."
             self._put(d + "ln1.w", _bits(w[s + "input_layernorm.weight"]))
@@ -136,8 +137,8 @@ class DeviceWeights:
             self._put(d + "qkv.w", pack_w16x64(np.concatenate([_bits(w[s + f"self_attn.{n}_proj.weight"]) for n in "qkv"], 0)))
             self._put(d + "qkv.b", np.concatenate([_bits(w[s + f"self_attn.{n}_proj.bias"]) for n in "qkv"], 0))
             self._put(d + "o.w", pack_w16x64(_bits(w[s + "self_attn.o_proj.weight"])))
-            g = _bits(w[s + "mlp.gate_proj.weight"]).reshape(ff // 16, 16, -1)
-            u = _bits(w[s + "mlp.up_proj.weight"]).reshape(ff // 16, 16, -1)
+            g = _bits(w[s + "mlp.gate_proj.weight"]).reshape(ff // 8, 8, -1)   # 8-row interleave: KR_EPI_SILU_MUL8
+            u = _bits(w[s + "mlp.up_proj.weight"]).reshape(ff // 8, 8, -1)
             self._put(d + "gate_up.w", pack_w16x64(np.stack([g, u], 1).reshape(2 * ff, -1)))
             self._put(d + "down.w", pack_w16x64(_bits(w[s + "mlp.down_proj.weight"])))
         self._put("llm.norm.w", _bits(w[Lm + "norm.weight"]))
@@ -184,6 +185,7 @@ class Engine:
         self.max_patches = max_patches
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
+        self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
             raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
@@ -435,7 +437,7 @@ class Engine:
                                  hd ** -0.5, 1, s)
                 self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x, packed=True)
                 L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln2.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
-                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL, packed=True)
+                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL8, packed=True)
                 self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x, packed=True)
             # last position of every sequence -> final norm (fused) -> lm_head -> greedy token
             L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)
@@ -468,15 +470,19 @@ class Engine:
                       waves=self.wv_qkv, kc=kc, vc=vc)
             L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
                                    self.s_max, self.n_split, hd ** -0.5, s)
-            self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o,
-                      attn_partials=self.d_ws)
+            if self.merge_in_o_proj:
+                self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o,
+                          attn_partials=self.d_ws)
+            else:
+                L.kr_attn_decode_merge(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
+                self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o)
             if self._prof_on:
-                # [e0] null kernel [e1] gate/up [e2]: the first bracket calibrates the second one
+                # [e0][e1] gate/up [e2]: the empty bracket e0..e1 measures what two back-to-back event
+                # packets cost by themselves; it is subtracted from the bracket around the launch
                 (e0, e1), (e2, _) = self._prof_event_pair(), self._prof_event_pair()
                 L.kr_event_record(e0, s)
-                L.kr_launch_null(s)
                 L.kr_event_record(e1, s)
-            self._dec(DEC_SILU, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+            self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
             if self._prof_on:
                 L.kr_event_record(e2, s)
             self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_down)
@@ -496,9 +502,8 @@ class Engine:
     def kernel_profile(self, reset: bool = True) -> Dict[str, float]:
         """Durations of the decode gate/up projection (`dec_linear_kernel<2, SILU>`, the kernel that moves
         half of the decoder's bytes) measured with HIP events on the launch stream during the profiled
-        eager steps.  Each sample is a HIP-event bracket around the one launch, minus the same bracket
-        around an empty kernel recorded right before it (the bracket's own cost: two event packets and a
-        dispatch).  Returns {launches, avg_us, min_us, bracket_us, null_bracket_us, bytes_per_launch}."""
+        eager steps.  Each sample is a HIP-event bracket around the one launch, minus an empty bracket
+        (two events, nothing between) recorded right before it — the event packets' own cost.  Returns {launches, avg_us, min_us, bracket_us, null_bracket_us, bytes_per_launch}."""
         self.stream.synchronize()
         ms = C.c_float()
         vals, nulls = [], []

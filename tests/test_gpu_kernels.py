@@ -11,8 +11,8 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from karanta_ocr_amd import positions as POS  # noqa: E402
-from karanta_ocr_amd._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU, EPI_GELU_ERF, EPI_NONE,  # noqa: E402
-                                  EPI_QUICK_GELU, EPI_SILU_MUL, KarantaHipError, lib, ptr)
+from karanta_ocr_amd._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU, DEC_SILU8, EPI_GELU_ERF, EPI_NONE,  # noqa: E402
+                                  EPI_QUICK_GELU, EPI_SILU_MUL, EPI_SILU_MUL8, KarantaHipError, lib, ptr)
 from karanta_ocr_amd.weights import bf16_round, pack_w16x64  # noqa: E402
 from oracle import qwen2vl_oracle as O  # noqa: E402
 
@@ -163,9 +163,10 @@ def test_argmax_embed_state_machine(L):
 # ----------------------------------------------------------------------------- GEMM
 def ref_linear(A, W, bias=None, res=None, epi=EPI_NONE):
     acc = A.astype(np.float64) @ W.astype(np.float64).T
-    if epi == EPI_SILU_MUL:
+    if epi in (EPI_SILU_MUL, EPI_SILU_MUL8):
         n = W.shape[0]
-        g = acc.reshape(A.shape[0], n // 32, 2, 16)
+        grp = 16 if epi == EPI_SILU_MUL else 8
+        g = acc.reshape(A.shape[0], n // (2 * grp), 2, grp)
         gate, up = g[:, :, 0].reshape(A.shape[0], -1), g[:, :, 1].reshape(A.shape[0], -1)
         return (gate / (1 + np.exp(-gate)) * up).astype(np.float32)
     if bias is not None:
@@ -184,7 +185,7 @@ def run_gemm(L, A, W, bias=None, res=None, epi=EPI_NONE, lda_pad=0, packed=False
     N = W.shape[0]
     Ad = dev_bf16(np.concatenate([A, np.zeros((M, lda_pad), np.float32)], 1)) if lda_pad else dev_bf16(A)
     Wd = dev_bf16(pack_w16x64(W) if packed else W)
-    nc = N // 2 if epi == EPI_SILU_MUL else N
+    nc = N // 2 if epi in (EPI_SILU_MUL, EPI_SILU_MUL8) else N
     Cd = torch.full((M, nc), 9.0, dtype=torch.bfloat16, device=DEV)
     bd = dev_bf16(bias) if bias is not None else None
     rd = dev_bf16(res) if res is not None else None
@@ -245,6 +246,16 @@ def test_gemm_packed_silu(L):
     M, ff, K = 150, 512, 256
     A, Wp = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5)
     assert_close_bf16(run_gemm(L, A, Wp, epi=EPI_SILU_MUL, packed=True), ref_linear(A, Wp, epi=EPI_SILU_MUL), what="packed silu")
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_silu_mul8(L, packed):
+    rng = np.random.default_rng(23)
+    M, ff, K = 150, 520, 256          # 2*ff = 1040 = 65 tiles: ragged last N tile
+    A, Wp = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5)
+    got = run_gemm(L, A, Wp, epi=EPI_SILU_MUL8, packed=packed)
+    assert got.shape == (M, ff)
+    assert_close_bf16(got, ref_linear(A, Wp, epi=EPI_SILU_MUL8), what="gemm silu8")
 
 
 def test_gemm_in_place_residual(L):
@@ -543,7 +554,7 @@ def dec_call(L, mode, x, ldx, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_
 def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False, waves=4):
     M, K = x.shape
     N = W.shape[0]
-    nc = N // 2 if mode == DEC_SILU else N
+    nc = N // 2 if mode in (DEC_SILU, DEC_SILU8) else N
     xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
     out = torch.full((M, nc), 9.0, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
     bd = dev_bf16(bias) if bias is not None else None
@@ -614,6 +625,17 @@ def test_linear_decode_silu_norm(L, M, K):
     got = run_dec(L, DEC_SILU, x, Wp, norm_w=nw)
     assert got.shape == (M, ff)
     assert_close_bf16(got, ref_linear(xn, Wp, epi=EPI_SILU_MUL), what="dec silu")
+
+
+@pytest.mark.parametrize("M,K,waves", [(8, 1536, 4), (16, 3584, 8), (3, 256, 4)])
+def test_linear_decode_silu8_norm(L, M, K, waves):
+    rng = np.random.default_rng(62 + M)
+    ff = 1016                          # 127 tiles of 8 features
+    x, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    got = run_dec(L, DEC_SILU8, x, Wp, norm_w=nw, waves=waves)
+    assert got.shape == (M, ff)
+    assert_close_bf16(got, ref_linear(xn, Wp, epi=EPI_SILU_MUL8), what="dec silu8")
 
 
 def test_linear_decode_in_place_residual_splitk(L):

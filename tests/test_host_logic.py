@@ -160,9 +160,9 @@ def test_weight_arena_packing_on_cpu():
     t = cfg.text
     gu = unpack_w16x64(dw.view("llm.1.gate_up.w").float().numpy())
     g, u = w["model.language_model.layers.1.mlp.gate_proj.weight"], w["model.language_model.layers.1.mlp.up_proj.weight"]
-    np.testing.assert_array_equal(gu[0:16], g[0:16])
-    np.testing.assert_array_equal(gu[16:32], u[0:16])
-    np.testing.assert_array_equal(gu[32:48], g[16:32])
+    np.testing.assert_array_equal(gu[0:8], g[0:8])
+    np.testing.assert_array_equal(gu[8:16], u[0:8])
+    np.testing.assert_array_equal(gu[16:24], g[8:16])
     qkv = unpack_w16x64(dw.view("llm.0.qkv.w").float().numpy())
     np.testing.assert_array_equal(qkv[: t.q_dim], w["model.language_model.layers.0.self_attn.q_proj.weight"])
     np.testing.assert_array_equal(qkv[t.q_dim + t.kv_dim:], w["model.language_model.layers.0.self_attn.v_proj.weight"])
