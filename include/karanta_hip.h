@@ -211,7 +211,10 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
  * (n, k) at ((((n/16)*(K/32) + k/32)*4 + (k%32)/8)*16 + n%16)*8 + k%8): one (16 x 32) block is an
  * MFMA fragment set in lane order, so the matrix is read from HBM as one linear stream, 1 KiB of
  * contiguous memory per wave-level load.  y[M<=16, N] = epi(x W^T).  K is split over the `waves` (4, 8 or 16) waves of a
- * workgroup; ksplit > 1 additionally splits K over workgroups with a deterministic in-launch
+ * workgroup.  max_blocks > 0 (and ksplit == 1): at most that many PERSISTENT workgroups walk the
+ * 16-row tile groups (the prologue runs once per workgroup, the next group's weights are put in
+ * flight before the current group's reduction); 0 = one workgroup per tile group.
+ * ksplit > 1 additionally splits K over workgroups with a deterministic in-launch
  * reduction (ws: f32 [N/16][ksplit][256] slabs, counters: int32 [N/16], zero-initialised, left
  * zero).  Prologues: Qwen2VLRMSNorm on x (norm_w, K <= 4096), or x = merge of the decode
  * attention partials (attn_partials [M][K/128][attn_split][hd+4] f32 as kr_attn_decode_fused
@@ -233,7 +236,7 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
 #define KR_DEC_SILU8 4      /* SILU with 8-row interleave: one tile per workgroup -> 2x the workgroups of KR_DEC_SILU */
 int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                      const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
-                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
+                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int max_blocks, int ksplit,
                      float* ws, int32_t* counters, const float* attn_partials, int attn_split,
                      const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                      kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,

@@ -35,6 +35,7 @@ struct DecLinArgs {
     const kr_bf16* residual; int64_t ldr;
     kr_bf16* out; float* out_f32; int64_t ldc;
     int M, N, K, ksplit;
+    int groups;                        // work items (tile groups); a workgroup walks g, g + gridDim.x, ... (ksplit == 1)
     float* ws; int* counters;          // split-K slabs [groups][ksplit][NT][256] f32, arrival counters [groups]
     // x = merge of attention partials [M][heads][n_split][132] f32 (o[128], m, l, 2 pad) (xmode 3)
     const float* attn_ws; int attn_split;
@@ -56,23 +57,15 @@ __device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
 template <int NT, int EPI, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int U = 8 / NT;  // chunks (64 k) in flight per wave: 16 x 16-byte loads outstanding
+    // chunks (64 k) in flight per wave: 16 x 16-byte loads outstanding (8 with 16 waves: 128-VGPR budget)
+    constexpr int U = (WAVES == 16 ? 4 : 8) / NT;
     constexpr int NTHR = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int g = blockIdx.x, ks = blockIdx.y;
+    const int ks = blockIdx.y;
     const int M = a.M, K = a.K;
     const int nchunks = K >> 6, ntiles = a.N >> 4;
-
-    int tile[NT];
-    if (EPI == DEPI_ROPE_KV) {  // tiles t and t+4: the two rotary halves of 16 head channels
-        tile[0] = (g >> 2) * 8 + (g & 3);
-        tile[NT - 1] = tile[0] + 4;
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) tile[t] = g * NT + t;
-    }
     // K range of this workgroup, then of this wave (contiguous => one linear HBM stream per wave)
     const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
@@ -80,24 +73,39 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     const int per = (nblk + WAVES - 1) / WAVES;
     const int c0 = min(cb0 + wave * per, cb1), c1 = min(c0 + per, cb1);
 
+    // Work item g = NT weight tiles.  With ksplit == 1 the workgroup is persistent over
+    // g = blockIdx.x, blockIdx.x + gridDim.x, ...: the x prologue (RMSNorm) runs once per workgroup,
+    // and the next item's first weight chunks are put in flight before the current item's reduction.
+    int tile[NT];
     const kr_bf16* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int tt = tile[t] < ntiles ? tile[t] : ntiles - 1;
-        wp[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + lane * 8;  // block (tile, k/32) = 512 elements, lane-linear
-    }
     bf16x8 wbuf[U][NT][2];
+    auto set_item = [&](int g) {
+        if (EPI == DEPI_ROPE_KV) {  // tiles t and t+4: the two rotary halves of 16 head channels
+            tile[0] = (g >> 2) * 8 + (g & 3);
+            tile[NT - 1] = tile[0] + 4;
+        } else {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int c = c0 + u;
-        if (c < c1) {
+            for (int t = 0; t < NT; ++t) tile[t] = g * NT + t;
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)c * 1024);
-                wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 512);
+        for (int t = 0; t < NT; ++t) {
+            const int tt = tile[t] < ntiles ? tile[t] : ntiles - 1;
+            wp[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + lane * 8;  // block (tile, k/32) = 512 elements, lane-linear
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u;
+            if (c < c1) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)c * 1024);
+                    wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 512);
+                }
             }
         }
-    }
+    };
+    int g = blockIdx.x;
+    set_item(g);
 
     // ---- x slice -> LDS (RMS-normalised, or merged from the attention partials, on the way)
     const bool xlds = a.xmode != 0;
@@ -186,45 +194,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     // x fragment of k-step (c, h): row fr, k = 64c + 32h + 8fg .. +7
     const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 16;
     const kr_bf16* xg = a.x + (int64_t)(fr < M ? fr : 0) * a.ldx + fg * 8;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cc = c0; cc < c1; cc += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = cc + u;
-            if (c < c1) {
-                bf16x8 x0, x1;
-                if (xlds) {
-                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
-                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 64);
-                } else {
-                    x0 = ld8(xg + c * 64);
-                    x1 = ld8(xg + c * 64 + 32);
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][0], x0, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][1], x1, acc[t], 0, 0, 0);
-                }
-                const int cn = c + U;
-                if (cn < c1) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
-                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 512);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- reduce the waves' K slices through LDS; wave 0 owns the rest
-    if (a.xmode == 3) __syncthreads();  // `red` doubled as the merge-weight scratch
-#pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
-    __syncthreads();
-    if (wave != 0) return;
+    // wave 0 of the workgroup: cross-wave sum (+ optional cross-workgroup split-K), then the epilogue
+    auto finish_item = [&](const int g, const int (&tile)[NT], const float* red) {
     f32x4 sum[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -287,8 +258,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
             better(bv, bi, ov, oi);
         }
         if (fg == 0 && b < M) {
-            a.amax_val[(int64_t)b * gridDim.x + g] = bv;
-            a.amax_idx[(int64_t)b * gridDim.x + g] = bi;
+            a.amax_val[(int64_t)b * a.groups + g] = bv;
+            a.amax_idx[(int64_t)b * a.groups + g] = bi;
         }
         return;
     }
@@ -380,6 +351,61 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
             *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
         }
     }
+    };
+    float* const red0 = red;
+    int rbuf = 0;
+    for (;;) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = c0; cc < c1; cc += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cc + u;
+            if (c < c1) {
+                bf16x8 x0, x1;
+                if (xlds) {
+                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
+                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 64);
+                } else {
+                    x0 = ld8(xg + c * 64);
+                    x1 = ld8(xg + c * 64 + 32);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][0], x0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][1], x1, acc[t], 0, 0, 0);
+                }
+                const int cn = c + U;
+                if (cn < c1) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
+                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 512);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- this item is done streaming: put the next item's first chunks in flight, then reduce
+    const int g_cur = g;
+    int tile_cur[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tile_cur[t] = tile[t];
+    const int g_next = g + gridDim.x;
+    const bool more = a.ksplit == 1 && g_next < a.groups;
+    if (more) set_item(g_next);
+    float* red = red0 + rbuf * (WAVES * NT * 256);  // double buffered: wave 0 may still be reading the other half
+    if (a.xmode == 3 && g_cur == (int)blockIdx.x) __syncthreads();  // `red` doubled as the merge-weight scratch
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wave == 0) finish_item(g_cur, tile_cur, red);
+    if (!more) break;
+    g = g_next;
+    rbuf ^= 1;
+    }  // persistent loop
 }
 
 // =====================================================================================
@@ -613,11 +639,12 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
 }
 
 template <int NT, int EPI, int WAVES>
-int launch_dec(const DecLinArgs& a, int groups, kr_stream s) {
+int launch_dec(DecLinArgs& a, int groups, int max_blocks, kr_stream s) {
+    a.groups = groups;
     const int nchunks = a.K >> 6;
     const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const size_t xbytes = a.xmode ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
-    size_t red = (size_t)WAVES * NT * 256 * 4;
+    size_t red = (size_t)2 * WAVES * NT * 256 * 4;  // double buffered
     if (a.xmode == 3) red = red > (size_t)a.M * (a.K >> 7) * a.attn_split * 4 ? red : (size_t)a.M * (a.K >> 7) * a.attn_split * 4;
     const size_t lds = xbytes + red;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode: needs %zu bytes of LDS (M=%d K=%d ksplit=%d)", lds, a.M, a.K, a.ksplit);
@@ -627,17 +654,18 @@ int launch_dec(const DecLinArgs& a, int groups, kr_stream s) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
+    const int grid_x = (a.ksplit == 1 && max_blocks > 0 && groups > max_blocks) ? max_blocks : groups;
+    fn<<<dim3(grid_x, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
 
 template <int NT, int EPI>
-int launch_dec_w(const DecLinArgs& a, int groups, int waves, kr_stream s) {
+int launch_dec_w(DecLinArgs& a, int groups, int waves, int max_blocks, kr_stream s) {
     switch (waves) {
-        case 4: return launch_dec<NT, EPI, 4>(a, groups, s);
-        case 8: return launch_dec<NT, EPI, 8>(a, groups, s);
-        case 16: return launch_dec<NT, EPI, 16>(a, groups, s);
+        case 4: return launch_dec<NT, EPI, 4>(a, groups, max_blocks, s);
+        case 8: return launch_dec<NT, EPI, 8>(a, groups, max_blocks, s);
+        case 16: return launch_dec<NT, EPI, 16>(a, groups, max_blocks, s);
         default: kr_set_error("kr_linear_decode: waves=%d (4, 8 or 16)", waves); return KR_ERR_ARG;
     }
 }
@@ -649,7 +677,7 @@ int launch_dec_w(const DecLinArgs& a, int groups, int waves, kr_stream s) {
 // =====================================================================================
 extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                                 const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr, kr_bf16* out,
-                                float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit, float* ws,
+                                float* out_f32, int64_t ldc, int M, int N, int K, int waves, int max_blocks, int ksplit, float* ws,
                                 int32_t* counters, const float* attn_partials, int attn_split, const float* cs_table,
                                 int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len, kr_bf16* q_out,
                                 kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max, float* amax_val,
@@ -681,24 +709,24 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
         case DEPI_PLAIN: {
             KR_CHECK_ARG((out || out_f32) && ldc >= N && (ldc & 3) == 0, "kr_linear_decode: PLAIN output");
             KR_CHECK_ARG(!residual || (ldr & 3) == 0, "kr_linear_decode: ldr");
-            if (ntiles >= 1024) return launch_dec_w<2, DEPI_PLAIN>(a, (ntiles + 1) / 2, waves, s);
-            return launch_dec_w<1, DEPI_PLAIN>(a, ntiles, waves, s);
+            if (ntiles >= 1024) return launch_dec_w<2, DEPI_PLAIN>(a, (ntiles + 1) / 2, waves, max_blocks, s);
+            return launch_dec_w<1, DEPI_PLAIN>(a, ntiles, waves, max_blocks, s);
         }
         case DEPI_SILU:
             KR_CHECK_ARG(out && N % 32 == 0 && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode: SILU output");
-            return launch_dec_w<2, DEPI_SILU>(a, ntiles / 2, waves, s);
+            return launch_dec_w<2, DEPI_SILU>(a, ntiles / 2, waves, max_blocks, s);
         case DEPI_SILU8:
             KR_CHECK_ARG(out && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode: SILU8 output");
-            return launch_dec_w<1, DEPI_SILU8>(a, ntiles, waves, s);
+            return launch_dec_w<1, DEPI_SILU8>(a, ntiles, waves, max_blocks, s);
         case DEPI_ROPE_KV:
             KR_CHECK_ARG(bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
                          "kr_linear_decode: ROPE_KV pointers");
             KR_CHECK_ARG(N == (heads + 2 * kv_heads) * 128 && s_max % 64 == 0, "kr_linear_decode: ROPE_KV needs head_dim 128");
-            return launch_dec_w<2, DEPI_ROPE_KV>(a, ntiles / 2, waves, s);
+            return launch_dec_w<2, DEPI_ROPE_KV>(a, ntiles / 2, waves, max_blocks, s);
         case DEPI_ARGMAX:
             KR_CHECK_ARG(amax_val && amax_idx && ksplit == 1, "kr_linear_decode: ARGMAX pointers / ksplit");
             KR_CHECK_ARG(!out_f32 || ldc >= N, "kr_linear_decode: ARGMAX logits ldc");
-            return launch_dec_w<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, waves, s);
+            return launch_dec_w<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, waves, max_blocks, s);
         default:
             kr_set_error("kr_linear_decode: unknown mode %d", mode);
             return KR_ERR_ARG;

@@ -185,6 +185,7 @@ class Engine:
         self.max_patches = max_patches
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
+        self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "256"))  # 1 persistent workgroup per CU
         self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
@@ -280,7 +281,7 @@ class Engine:
         o = out if out is not None else out_f32
         self.L.kr_linear_decode(mode, ptr(x), x.stride(0) if x is not None else 0, ptr(W), ptr(bias), ptr(norm_w),
                                 t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out), ptr(out_f32),
-                                o.stride(0) if o is not None else 0, M, N, K, waves, 1, 0, 0,
+                                o.stride(0) if o is not None else 0, M, N, K, waves, self.persist_blocks, 1, 0, 0,
                                 ptr(attn_partials), self.n_split, ptr(self.d_cs), self.max_new, ptr(self.d_plen),
                                 ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max,
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)

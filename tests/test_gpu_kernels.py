@@ -546,12 +546,12 @@ def test_decode_prep_and_attention(L, H, KVH, ctxs):
 # ----------------------------------------------------------------------------- fused decode step kernels
 def dec_call(L, mode, x, ldx, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_w=0, res=0, ldr=0, waves=4, ksplit=1, ws=0,
              cnt=0, attn=0, attn_split=1, cs=0, cs_stride=0, plen=0, ctx=0, q_out=0, kc=0, vc=0, heads=0, kv_heads=0,
-             s_max=64, av=0, ai=0):
-    L.kr_linear_decode(mode, x, ldx, W, bias, norm_w, 1e-6, res, ldr, out, out_f32, ldc, M, N, K, waves, ksplit, ws, cnt,
+             s_max=64, av=0, ai=0, max_blocks=0):
+    L.kr_linear_decode(mode, x, ldx, W, bias, norm_w, 1e-6, res, ldr, out, out_f32, ldc, M, N, K, waves, max_blocks, ksplit, ws, cnt,
                        attn, attn_split, cs, cs_stride, plen, ctx, q_out, kc, vc, heads, kv_heads, s_max, av, ai, 0)
 
 
-def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False, waves=4):
+def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False, waves=4, max_blocks=0):
     M, K = x.shape
     N = W.shape[0]
     nc = N // 2 if mode in (DEC_SILU, DEC_SILU8) else N
@@ -565,7 +565,7 @@ def run_dec(L, mode, x, W, ksplit=1, bias=None, res=None, norm_w=None, f32=False
     cnt = torch.zeros(groups, dtype=torch.int32, device=DEV)
     dec_call(L, mode, ptr(xd), K, ptr(Wd), M, N, K, out=0 if f32 else ptr(out), out_f32=ptr(out) if f32 else 0, ldc=nc,
              bias=ptr(bd), norm_w=ptr(nd), res=ptr(rd), ldr=nc if res is not None else 0, waves=waves, ksplit=ksplit,
-             ws=ptr(ws), cnt=ptr(cnt))
+             ws=ptr(ws), cnt=ptr(cnt), max_blocks=max_blocks)
     res_ = host(out)
     assert not cnt.cpu().numpy().any(), "arrival counters must be left at zero"
     return res_
@@ -636,6 +636,27 @@ def test_linear_decode_silu8_norm(L, M, K, waves):
     got = run_dec(L, DEC_SILU8, x, Wp, norm_w=nw, waves=waves)
     assert got.shape == (M, ff)
     assert_close_bf16(got, ref_linear(xn, Wp, epi=EPI_SILU_MUL8), what="dec silu8")
+
+
+@pytest.mark.parametrize("max_blocks", [1, 3, 7, 64])
+def test_linear_decode_persistent_workgroups(L, max_blocks):
+    """Persistent workgroups walking several tile groups (double-buffered reduction, next-group prefetch)."""
+    rng = np.random.default_rng(90 + max_blocks)
+    M, N, K = 8, 16 * 37, 512
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    W[:, 200:] = 0
+    np.testing.assert_array_equal(run_dec(L, DEC_PLAIN, x, W, max_blocks=max_blocks, waves=8), ref_linear(x, W))
+    # fused norm + SiLU (8-row interleave) + persistent
+    ff = 8 * 45
+    x2, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x2, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(run_dec(L, DEC_SILU8, x2, Wp, norm_w=nw, max_blocks=max_blocks), ref_linear(xn, Wp, epi=EPI_SILU_MUL8),
+                      what="persistent silu8")
+    # residual in place + bias, persistent
+    bias, res = rnd(rng, N, scale=0.1), rnd(rng, M, N)
+    assert_close_bf16(run_dec(L, DEC_PLAIN, x2, rnd(np.random.default_rng(5), N, K, scale=K ** -0.5), bias=bias, res=res,
+                              max_blocks=max_blocks),
+                      ref_linear(x2, rnd(np.random.default_rng(5), N, K, scale=K ** -0.5), bias, res), what="persistent plain")
 
 
 def test_linear_decode_in_place_residual_splitk(L):
@@ -710,7 +731,8 @@ def test_linear_decode_argmax_and_sample(L):
     n_part = (V // 16 + 1) // 2
     av = torch.zeros(B, n_part, dtype=torch.float32, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
     lg = torch.zeros(B, V, dtype=torch.float32, device=DEV)
-    dec_call(L, DEC_ARGMAX, ptr(xd), d, ptr(Wd), B, V, d, out_f32=ptr(lg), ldc=V, norm_w=ptr(nd), av=ptr(av), ai=ptr(ai))
+    dec_call(L, DEC_ARGMAX, ptr(xd), d, ptr(Wd), B, V, d, out_f32=ptr(lg), ldc=V, norm_w=ptr(nd), av=ptr(av), ai=ptr(ai),
+             max_blocks=6)
     got = host(lg)
     np.testing.assert_allclose(got, logits_ref, atol=2e-2, rtol=1e-2)
     table = rnd(rng, V, d); td = dev_bf16(table)
