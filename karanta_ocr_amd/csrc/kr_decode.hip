@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     const int g_next = g + gridDim.x;
     const bool more = a.ksplit == 1 && g_next < a.groups;
     if (more) set_item(g_next);
-    float* red = red0 + rbuf * (WAVES * NT * 256);  // double buffered: wave 0 may still be reading the other half
+    // double buffered when persistent: wave 0 may still be reading the other half
+    float* red = red0 + rbuf * (WAVES * NT * 256);
     if (a.xmode == 3 && g_cur == (int)blockIdx.x) __syncthreads();  // `red` doubled as the merge-weight scratch
 #pragma unroll
     for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     if (wave == 0) finish_item(g_cur, tile_cur, red);
     if (!more) break;
     g = g_next;
-    rbuf ^= 1;
+    rbuf ^= 1;  // (only reached when the grid is smaller than the item count: the host sized `red` for two halves)
     }  // persistent loop
 }
 
@@ -643,8 +644,13 @@ int launch_dec(DecLinArgs& a, int groups, int max_blocks, kr_stream s) {
     a.groups = groups;
     const int nchunks = a.K >> 6;
     const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
-    const size_t xbytes = a.xmode ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
-    size_t red = (size_t)2 * WAVES * NT * 256 * 4;  // double buffered
+    const int grid_x = (a.ksplit == 1 && max_blocks > 0 && groups > max_blocks) ? max_blocks : groups;
+    size_t red = (size_t)(grid_x < groups ? 2 : 1) * WAVES * NT * 256 * 4;  // double buffered when persistent
+    // x goes through LDS whenever it fits next to the reduction buffer (wide-K layers at large M read
+    // their x fragments from L2 instead: twice the vector-memory instructions, measurably slower)
+    size_t xbytes = ((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127;
+    if (a.xmode == 1 && xbytes + red > 160 * 1024) a.xmode = 0;
+    if (a.xmode == 0) xbytes = 0;
     if (a.xmode == 3) red = red > (size_t)a.M * (a.K >> 7) * a.attn_split * 4 ? red : (size_t)a.M * (a.K >> 7) * a.attn_split * 4;
     const size_t lds = xbytes + red;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode: needs %zu bytes of LDS (M=%d K=%d ksplit=%d)", lds, a.M, a.K, a.ksplit);
@@ -654,7 +660,6 @@ int launch_dec(DecLinArgs& a, int groups, int max_blocks, kr_stream s) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    const int grid_x = (a.ksplit == 1 && max_blocks > 0 && groups > max_blocks) ? max_blocks : groups;
     fn<<<dim3(grid_x, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
@@ -698,9 +703,7 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
     a.M = M; a.N = N; a.K = K; a.ksplit = ksplit; a.ws = ws; a.counters = counters;
     a.attn_ws = attn_partials; a.attn_split = attn_split;
     // x staged in LDS unless the row slice is too large (wide-K layers read x fragments from L2)
-    const int cpb = ((K >> 6) + ksplit - 1) / ksplit;
-    const bool fits = (size_t)M * (cpb * 128 + 16) <= 96 * 1024;
-    a.xmode = attn_partials ? 3 : norm_w ? 2 : fits ? 1 : 0;
+    a.xmode = attn_partials ? 3 : norm_w ? 2 : 1;  // 1 falls back to 0 (x from L2) in launch_dec when LDS is short
     a.cs_table = cs_table; a.cs_stride = cs_stride; a.prompt_len = prompt_len; a.ctx_len = ctx_len;
     a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
     a.heads = heads; a.kv_heads = kv_heads; a.s_max = s_max; a.amax_val = amax_val; a.amax_idx = amax_idx;

@@ -23,6 +23,25 @@ __global__ void __launch_bounds__(256) rd_vgpr(const u32x4* __restrict__ p, size
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
 
+// half-duplicate lanes: lanes (fg, fr >= 8) read the address of (fg, fr - 8): 512 useful bytes per
+// wave-level load (the access shape of an 8-row MFMA weight tile)
+template <int U>
+__global__ void __launch_bounds__(256) rd_half(const u32x4* __restrict__ p, size_t n16_per_wave, unsigned* sink) {
+    const int lane = threadIdx.x & 63;
+    const int l2 = ((lane >> 4) << 3) | (lane & 7);  // 0..31
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u32x4* q = p + wave * n16_per_wave + l2;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = 0; i < n16_per_wave; i += 32 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(q + i + u * 32);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
 // LDS-DMA: one wave-instruction = 1 KiB straight into LDS, no VGPR destination
 template <int U>
 __global__ void __launch_bounds__(256) rd_lds(const u32x4* __restrict__ p, size_t n16_per_wave, unsigned* sink) {
@@ -74,6 +93,22 @@ int main() {
         timeit(name, [&] { rd_lds<8><<<blocks, 256, 4 * 8 * 1024, s>>>(p, n16, sink); }, tot, s);
         snprintf(name, sizeof name, "lds-dma U=16    %d blk/CU", blocks_per_cu);
         timeit(name, [&] { rd_lds<16><<<blocks, 256, 4 * 16 * 1024, s>>>(p, n16, sink); }, tot, s);
+    }
+    for (int blocks : {96, 192, 256, 512}) {
+        const int waves = blocks * 4;
+        const size_t n16 = ((size_t)1 << 30) / 16 / waves / (64 * 16) * (64 * 16);
+        const size_t tot = n16 * 16 * waves;
+        char name[128];
+        snprintf(name, sizeof name, "vgpr U=16 nt full-line   %d blocks x4w", blocks);
+        timeit(name, [&] { rd_vgpr<16, true><<<blocks, 256, 0, s>>>(p, n16, sink); }, tot, s);
+        snprintf(name, sizeof name, "vgpr U=16 nt half-dup    %d blocks x4w", blocks);
+        timeit(name, [&] { rd_half<16><<<blocks, 256, 0, s>>>(p, n16, sink); }, tot, s);
+        const int waves16 = blocks * 16;
+        const size_t n16b = ((size_t)1 << 30) / 16 / waves16 / (64 * 16) * (64 * 16);
+        snprintf(name, sizeof name, "vgpr U=8 nt full-line    %d blocks x16w", blocks);
+        timeit(name, [&] { rd_vgpr<8, true><<<blocks, 1024, 0, s>>>(p, n16b, sink); }, n16b * 16 * waves16, s);
+        snprintf(name, sizeof name, "vgpr U=8 nt half-dup     %d blocks x16w", blocks);
+        timeit(name, [&] { rd_half<8><<<blocks, 1024, 0, s>>>(p, n16b, sink); }, n16b * 16 * waves16, s);
     }
     // few CUs only: per-CU ceiling
     for (int blocks : {32, 96}) {

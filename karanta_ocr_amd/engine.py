@@ -185,7 +185,7 @@ class Engine:
         self.max_patches = max_patches
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
-        self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "256"))  # 1 persistent workgroup per CU
+        self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
