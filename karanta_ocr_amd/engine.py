@@ -186,6 +186,7 @@ class Engine:
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
+        self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
         self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
@@ -244,6 +245,11 @@ class Engine:
         self.wv_qkv = self._waves(t.hidden_size // 64)
         self.wv_o = self._waves(t.q_dim // 64)
         self.wv_down = self._waves(t.intermediate_size // 64)
+        self.wv_wide = 4
+        for name in ("qkv", "o", "down", "wide"):  # tuning overrides (sweeps): KARANTA_WV_DOWN=8 ...
+            v_ = os.environ.get("KARANTA_WV_" + name.upper())
+            if v_:
+                setattr(self, "wv_" + name, int(v_))
         self.n_amax = (t.vocab_size // 16 + 1) // 2
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
         self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
@@ -450,7 +456,7 @@ class Engine:
         bookkeeping and the next step's rotary table (TF:839, :1320-1323; generate(do_sample=False))."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         self._dec(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
-                  out_f32=self.d_logits if self._want_logits else None)
+                  out_f32=self.d_logits if self._want_logits else None, waves=self.wv_wide)
         L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
                            ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_plen), ptr(self.d_ctx),
                            ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
@@ -483,10 +489,13 @@ class Engine:
                 (e0, e1), (e2, _) = self._prof_event_pair(), self._prof_event_pair()
                 L.kr_event_record(e0, s)
                 L.kr_event_record(e1, s)
-            self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+            self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                      waves=self.wv_wide)
             if self._prof_on:
                 L.kr_event_record(e2, s)
             self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_down)
+            for _ in range(self._extra_nulls):  # diagnostic: price of one more (empty) launch in the chain
+                L.kr_launch_null(s)
         self._lm_head_and_sample(B)
 
     # ------------------------------------------------------------------ live kernel timing (bench.py roofline)
