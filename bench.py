@@ -152,7 +152,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # control plane (barriers, the RCCL unique id, max-over-ranks timing) over gloo on CPU tensors; the
+        # data plane — the one-time weight broadcast — is RCCL through the C-ABI (kr_bcast_weights)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from karanta_ocr_amd import image_processing as IP
     from karanta_ocr_amd._lib import lib, ptr
@@ -203,13 +205,13 @@ def main():
         try:
             bcast_s = broadcast_weights(eng.w.arena, rank, world, stream=eng.s)   # kr_comm_* / kr_bcast_weights (RCCL)
             bcast_path = "kr_bcast_weights"
-        except Exception as e:  # library-level RCCL failure: use torch.distributed's RCCL backend instead
-            print(f"[bench] rank {rank}: kr_bcast_weights failed ({e}); falling back to torch.distributed.broadcast",
+        except Exception as e:  # library-level RCCL failure: the weights are seeded, regenerate them locally
+            print(f"[bench] rank {rank}: kr_bcast_weights failed ({e}); regenerating the seeded weights locally",
                   file=sys.stderr, flush=True)
             t0 = time.perf_counter()
-            dist.broadcast(eng.w.arena, src=0)
-            torch.cuda.synchronize()
-            bcast_s, bcast_path = time.perf_counter() - t0, "torch.distributed.broadcast"
+            if rank != 0:
+                eng.load_weights(random_weights(cfg, 0, as_bits=True))
+            bcast_s, bcast_path = time.perf_counter() - t0, "FAILED: regenerated locally"
         digs = [None] * world
         dist.all_gather_object(digs, digest())
         if digs[rank] != digs[0]:  # never observed; keeps the run valid (weights are seeded, so identical by construction)
@@ -234,7 +236,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))  # CPU tensor -> gloo: the control plane never touches RCCL
 
     barrier()
     t_begin = time.perf_counter()
@@ -248,7 +250,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     prof = eng.kernel_profile()
@@ -302,7 +304,7 @@ def main():
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
 
 

@@ -69,12 +69,21 @@ def broadcast_weights(weights_arena, rank: int, world: int, stream: int = 0, roo
     if rank == root:
         L.kr_comm_unique_id(uid)
     obj = [bytes(uid)]
-    dist.broadcast_object_list(obj, src=root)
+    dist.broadcast_object_list(obj, src=root, device=torch.device("cpu"))
     uid = (C.c_uint8 * 128).from_buffer_copy(obj[0])
     comm = C.c_void_p()
-    L.kr_comm_init(C.byref(comm), world, rank, uid)
+    err = None
+    try:
+        L.kr_comm_init(C.byref(comm), world, rank, uid)
+    except Exception as e:  # keep every rank on the same sequence of host collectives
+        err = e
+    ok = torch.tensor([0.0 if err else 1.0])
     torch.cuda.synchronize()
-    dist.barrier()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # CPU tensor: gloo; doubles as the pre-broadcast barrier
+    if ok.item() < 1.0:
+        if comm.value:
+            L.kr_comm_destroy(comm)
+        raise RuntimeError(f"kr_comm_init failed on at least one rank ({err})")
     t0 = time.perf_counter()
     L.kr_bcast_weights(comm, ptr(weights_arena), weights_arena.numel(), root, stream)
     torch.cuda.synchronize()
