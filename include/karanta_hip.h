@@ -227,8 +227,8 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
  *                  [M][cs_stride][128] fp32 (cos[0..64), sin[0..64)), entry ctx_len[b] -
  *                  prompt_len[b] = index of the decode position.  head_dim 128 only.
  *                  (TF:469-556, :180-222)
- *      3 ARGMAX  : lm_head: per-tile (max, lowest index) partials amax_val/amax_idx
- *                  [M][N/16]; fp32 logits also written when out_f32 != NULL   (TF:1320-1323) */
+ *      3 ARGMAX  : lm_head: per-workgroup (max, lowest index) partials amax_val/amax_idx
+ *                  [M][ceil(N/32)]; fp32 logits also written when out_f32 != NULL   (TF:1320-1323) */
 #define KR_DEC_PLAIN 0
 #define KR_DEC_SILU 1
 #define KR_DEC_ROPE_KV 2

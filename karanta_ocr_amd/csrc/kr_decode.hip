@@ -54,14 +54,11 @@ __device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
 }
 
-// UC > 0 ("ring" mode, persistent workgroups): every wave owns exactly UC K-chunks of an item and the
-// register ring has UC slots — the slot freed by chunk j of item i is refilled at once with chunk j of
-// item i+1, so UC chunks stay in flight across item boundaries (no HBM-latency bubble per item).
-template <int NT, int EPI, int WAVES, int UC>
+template <int NT, int EPI, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // chunks (64 k) in flight per wave: 16 x 16-byte loads outstanding (8 with 16 waves: 128-VGPR budget)
-    constexpr int U = UC ? UC : (WAVES == 16 ? 4 : 8) / NT;
+    constexpr int U = (WAVES == 16 ? 4 : 8) / NT;
     constexpr int NTHR = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,24 +79,19 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     int tile[NT];
     const kr_bf16* wp[NT];
     bf16x8 wbuf[U][NT][2];
-    const kr_bf16* wp_next[NT];
-    auto item_tiles = [&](int g, int (&tl)[NT], const kr_bf16* (&ptr_)[NT]) {
+    auto set_item = [&](int g) {
         if (EPI == DEPI_ROPE_KV) {  // tiles t and t+4: the two rotary halves of 16 head channels
-            tl[0] = (g >> 2) * 8 + (g & 3);
-            tl[NT - 1] = tl[0] + 4;
+            tile[0] = (g >> 2) * 8 + (g & 3);
+            tile[NT - 1] = tile[0] + 4;
         } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) tl[t] = g * NT + t;
+            for (int t = 0; t < NT; ++t) tile[t] = g * NT + t;
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int tt = tl[t] < ntiles ? tl[t] : ntiles - 1;
-            ptr_[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + lane * 8;  // block (tile, k/32) = 512 elements, lane-linear
+            const int tt = tile[t] < ntiles ? tile[t] : ntiles - 1;
+            wp[t] = a.wp + ((int64_t)tt * nchunks) * 1024 + lane * 8;  // block (tile, k/32) = 512 elements, lane-linear
         }
-    };
-    auto set_item = [&](int g, bool prefetch) {
-        item_tiles(g, tile, wp);
-        if (!prefetch) return;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = c0 + u;
@@ -113,7 +105,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
         }
     };
     int g = blockIdx.x;
-    set_item(g, true);
+    set_item(g);
 
     // ---- x slice -> LDS (RMS-normalised, or merged from the attention partials, on the way)
     const bool xlds = a.xmode != 0;
@@ -363,12 +355,6 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     float* const red0 = red;
     int rbuf = 0;
     for (;;) {
-    const int g_next = g + gridDim.x;
-    const bool more = a.ksplit == 1 && g_next < a.groups;
-    if (UC && more) {
-        int tl[NT];
-        item_tiles(g_next, tl, wp_next);
-    }
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -397,12 +383,6 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
                         wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
                         wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 512);
                     }
-                } else if (UC && more) {  // ring mode: the same chunk of the next item takes the freed slot
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        wbuf[u][t][0] = ld8_nt(wp_next[t] + (int64_t)c * 1024);
-                        wbuf[u][t][1] = ld8_nt(wp_next[t] + (int64_t)c * 1024 + 512);
-                    }
                 }
             }
         }
@@ -413,7 +393,9 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
     int tile_cur[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) tile_cur[t] = tile[t];
-    if (more) set_item(g_next, UC == 0);  // ring mode already has the next item's chunks in flight
+    const int g_next = g + gridDim.x;
+    const bool more = a.ksplit == 1 && g_next < a.groups;
+    if (more) set_item(g_next);
     // double buffered when persistent: wave 0 may still be reading the other half
     float* red = red0 + rbuf * (WAVES * NT * 256);
     if (a.xmode == 3 && g_cur == (int)blockIdx.x) __syncthreads();  // `red` doubled as the merge-weight scratch
@@ -657,19 +639,6 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
     for (int c = tid; c < (d >> 3); c += 256) st8(x_next + (int64_t)b * d + c * 8, ld8(table + (int64_t)tok * d + c * 8));
 }
 
-template <int NT, int EPI, int WAVES, int UC>
-int launch_dec_uc(DecLinArgs& a, int groups, int grid_x, size_t lds, kr_stream s) {
-    auto fn = &dec_linear_kernel<NT, EPI, WAVES, UC>;
-    static bool attr = false;
-    if (!attr) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    fn<<<dim3(grid_x, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
-    KR_CHECK_LAUNCH();
-    return KR_OK;
-}
-
 template <int NT, int EPI, int WAVES>
 int launch_dec(DecLinArgs& a, int groups, int max_blocks, kr_stream s) {
     a.groups = groups;
@@ -685,17 +654,15 @@ int launch_dec(DecLinArgs& a, int groups, int max_blocks, kr_stream s) {
     if (a.xmode == 3) red = red > (size_t)a.M * (a.K >> 7) * a.attn_split * 4 ? red : (size_t)a.M * (a.K >> 7) * a.attn_split * 4;
     const size_t lds = xbytes + red;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode: needs %zu bytes of LDS (M=%d K=%d ksplit=%d)", lds, a.M, a.K, a.ksplit);
-    // ring mode for the persistent wide layers (one tile per item) when every wave owns exactly UC chunks
-    if (NT == 1 && WAVES <= 8 && (EPI == DEPI_SILU8 || EPI == DEPI_ARGMAX || EPI == DEPI_PLAIN) && grid_x < groups &&
-        nchunks % WAVES == 0) {
-        switch (nchunks / WAVES) {
-            case 3: return launch_dec_uc<NT, EPI, WAVES, 3>(a, groups, grid_x, lds, s);
-            case 6: return launch_dec_uc<NT, EPI, WAVES, 6>(a, groups, grid_x, lds, s);
-            case 7: return launch_dec_uc<NT, EPI, WAVES, 7>(a, groups, grid_x, lds, s);
-            default: break;
-        }
+    auto fn = &dec_linear_kernel<NT, EPI, WAVES>;
+    static bool attr = false;
+    if (!attr) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
     }
-    return launch_dec_uc<NT, EPI, WAVES, 0>(a, groups, grid_x, lds, s);
+    fn<<<dim3(grid_x, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
 }
 
 template <int NT, int EPI>
@@ -762,7 +729,7 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
         case DEPI_ARGMAX:
             KR_CHECK_ARG(amax_val && amax_idx && ksplit == 1, "kr_linear_decode: ARGMAX pointers / ksplit");
             KR_CHECK_ARG(!out_f32 || ldc >= N, "kr_linear_decode: ARGMAX logits ldc");
-            return launch_dec_w<1, DEPI_ARGMAX>(a, ntiles, waves, max_blocks, s);
+            return launch_dec_w<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, waves, max_blocks, s);
         default:
             kr_set_error("kr_linear_decode: unknown mode %d", mode);
             return KR_ERR_ARG;

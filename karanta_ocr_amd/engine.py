@@ -250,7 +250,7 @@ class Engine:
             v_ = os.environ.get("KARANTA_WV_" + name.upper())
             if v_:
                 setattr(self, "wv_" + name, int(v_))
-        self.n_amax = t.vocab_size // 16  # one (max, index) partial per 16-row lm_head tile
+        self.n_amax = (t.vocab_size // 16 + 1) // 2
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
         self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
         self.d_plen = z(B, dtype=torch.int32)

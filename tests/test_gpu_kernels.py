@@ -728,7 +728,7 @@ def test_linear_decode_argmax_and_sample(L):
     nw = np.ones(d, np.float32)
     logits_ref = ref_linear(bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16"))), W)
     xd, Wd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw)
-    n_part = V // 16
+    n_part = (V // 16 + 1) // 2
     av = torch.zeros(B, n_part, dtype=torch.float32, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
     lg = torch.zeros(B, V, dtype=torch.float32, device=DEV)
     dec_call(L, DEC_ARGMAX, ptr(xd), d, ptr(Wd), B, V, d, out_f32=ptr(lg), ldc=V, norm_w=ptr(nd), av=ptr(av), ai=ptr(ai),
