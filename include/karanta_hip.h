@@ -242,6 +242,16 @@ int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_p
                      kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
                      float* amax_val, int32_t* amax_idx, kr_stream s);
 
+/* Wide decode linears (gate/up, lm_head): one WAVE per 16-row weight tile over the full K — no cross-wave
+ * reduction and no barrier after the prologue; an 8-deep register ring streams on across tile boundaries
+ * (K % 512 == 0, K <= 4096).  `blocks` workgroups of `waves` (<= 8) waves; wave (b, w) walks tiles
+ * b + blocks*(w + waves*i).  Modes PLAIN / SILU8 / ARGMAX as kr_linear_decode; ARGMAX partials are per
+ * tile: amax_val / amax_idx [M][N/16]. */
+int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
+                          const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                          kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
+                          float* amax_val, int32_t* amax_idx, kr_stream s);
+
 /* Decode attention (q_len 1, GQA, MFMA, split over n_split key ranges), kcache / vtcache = the
  * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+4] partials (o[hd], m, l, 2 pad: 16-byte aligned records).
  * out != NULL: the splits are merged in-launch by the last-arriving workgroup (counters: int32
@@ -285,6 +295,9 @@ int kr_selftest_mfma(kr_stream s);
 int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, float* us_per_kernel);
 /* Launches an empty kernel (1 wave): calibrates the cost of a HIP-event bracket around one launch. */
 int kr_launch_null(kr_stream s);
+/* Reads [ptr, ptr+bytes) with `blocks` workgroups of plain 16-byte loads and discards the data:
+ * a software prefetch into the 256 MiB memory-side Infinity Cache for a later streaming kernel. */
+int kr_prefetch(const void* ptr, size_t bytes, int blocks, kr_stream s);
 
 #ifdef __cplusplus
 }

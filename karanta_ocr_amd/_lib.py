@@ -56,6 +56,7 @@ SIGNATURES = {
     "kr_argmax": [c_p, i64, i32, c_p, i32, c_p],
     "kr_linear_decode": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, i32, c_p, c_p,
                          c_p, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p],
+    "kr_linear_decode_wide": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
     "kr_attn_decode_merge": [c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
@@ -66,6 +67,7 @@ SIGNATURES = {
     "kr_selftest_mfma": [c_p],
     "kr_probe_launch_floor": [c_p, i32, i32, i32, C.POINTER(f32)],
     "kr_launch_null": [c_p],
+    "kr_prefetch": [c_p, C.c_size_t, i32, c_p],
 }
 _RESTYPES = {"kr_last_error": C.c_char_p}
 

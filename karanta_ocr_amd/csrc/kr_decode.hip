@@ -48,6 +48,9 @@ struct DecLinArgs {
     int heads, kv_heads, s_max;
     // ARGMAX
     float* amax_val; int32_t* amax_idx;  // [M][gridDim.x]
+    // wide kernel: launch geometry as kernel arguments (gridDim / blockDim come from the dispatch packet through
+    // a dependent global load, ~1 us on the critical path of a 10 us kernel)
+    int wide_blocks, wide_waves;
 };
 
 __device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
@@ -410,6 +413,246 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 }
 
 // =====================================================================================
+// wide layers (gate/up, lm_head): one WAVE per 16-row tile over the full K
+// =====================================================================================
+// No cross-wave reduction, no barrier after the prologue, and a register ring of U 64-wide K-chunks that keeps
+// streaming across tile boundaries (K/64 is a multiple of U, so ring slots stay static): each wave is an
+// independent linear HBM stream (U = 12 chunks = 24 KB per wave in flight at K = 1536).  Loads return in issue
+// order, hence the order of issue: x rows and the norm weight FIRST (the norm prologue then waits only for them),
+// weights right behind; the RMSNorm / LDS staging of x runs while the weights are in flight.  Measured (M=8, gate/up of the 2B decoder,
+// chain of launches over rotating copies): launch 1.7 us + body 1.1 + stores 0.6 + x staging 1.8 + weight
+// stream 7.5 (= 7.4 TB/s) were purely additive with the weights-first order.
+// Wave (block b, wave w) walks tiles b + gridDim.x * (w + W * i).
+template <int NCH> struct WideCfg { static constexpr int U = 8, RL = 8; };   // generic: K <= 4096, K % 512 == 0
+template <> struct WideCfg<24> { static constexpr int U = 12, RL = 3; };     // K = 1536 (Qwen2-VL-2B)
+template <> struct WideCfg<56> { static constexpr int U = 8, RL = 7; };      // K = 3584 (Qwen2-VL-7B): 2 x rows + norm = 84 VGPRs
+
+// ACTIVE = this wave owns at least one tile.  The two cases are separate instantiations selected by ONE
+// wave-uniform branch at the top of the kernel (each contains the workgroup's single barrier): a branch around
+// the weight loads inside a common body would make the compiler's s_waitcnt bookkeeping assume the shorter
+// path, and the wait for x would become a wait for the weights.
+template <int EPI, int NCH, bool ACTIVE>
+__device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
+    constexpr int U = WideCfg<NCH>::U, RL = WideCfg<NCH>::RL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = a.wide_waves, nblk = a.wide_blocks;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int M = a.M, K = a.K, nchunks = NCH ? NCH : (K >> 6), ntiles = a.N >> 4;
+    const int stride = nblk * W;
+    const int xrow = K * 2 + 16, kc = K >> 3;
+    int t = blockIdx.x + nblk * wave;
+
+    // ---- issue: x rows `wave` and `wave + W` and the norm weight first (branch-free when K is a template
+    // constant: s_waitcnt bookkeeping does not survive divergent control flow) ...
+    constexpr bool FULL = NCH != 0;  // RL * 64 == K / 8 exactly
+    bf16x8 xv[2][RL], nwv[RL];
+    const bool has_norm = a.norm_w != nullptr;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int b = wave + r * W;
+        const kr_bf16* xp = a.x + (int64_t)(b < M ? b : 0) * a.ldx;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            const int c = lane + i * 64;
+            if (FULL || c < kc) xv[r][i] = ld8(xp + c * 8);
+        }
+    }
+    {
+        const kr_bf16* np = has_norm ? a.norm_w : a.x;  // always a valid address; unused without a norm
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            const int c = lane + i * 64;
+            if (FULL || c < kc) nwv[i] = ld8(np + c * 8);
+        }
+    }
+    // ---- ... then the weight ring
+    bf16x8 wbuf[U][2];
+    const kr_bf16* wp = a.wp + ((int64_t)(ACTIVE ? t : 0) * nchunks) * 1024 + lane * 8;
+    if (ACTIVE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wbuf[u][0] = ld8_nt(wp + (int64_t)u * 1024);
+            wbuf[u][1] = ld8_nt(wp + (int64_t)u * 1024 + 512);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // everything above is issued before any of the norm arithmetic below
+    // ---- x -> LDS, RMS-normalised when norm_w is given
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int b = wave + r * W;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            if (FULL || lane + i * 64 < kc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += bf2f(xv[r][i][j]) * bf2f(xv[r][i][j]);
+            }
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)K + a.norm_eps);
+        if (b < M) {
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                const int c = lane + i * 64;
+                if (FULL || c < kc) {
+                    bf16x8 o = xv[r][i];
+                    if (has_norm) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nwv[i][j]) * bfround(bf2f(xv[r][i][j]) * rs));
+                    }
+                    *reinterpret_cast<bf16x8*>(smem + b * xrow + c * 16) = o;
+                }
+            }
+        }
+    }
+    for (int b = wave + 2 * W; b < M; b += W) {  // fewer than M/2 waves: the remaining rows, the slow way
+        bf16x8 v[RL];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            const int c = lane + i * 64;
+            if (c < kc) {
+                v[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += bf2f(v[i][j]) * bf2f(v[i][j]);
+            }
+        }
+        ss = wave_sum(ss);
+        const float rs = a.norm_w ? rsqrtf(ss / (float)K + a.norm_eps) : 1.f;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            const int c = lane + i * 64;
+            if (c < kc) {
+                bf16x8 o = v[i];
+                if (a.norm_w) {
+                    const bf16x8 nw = ld8(a.norm_w + c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[j]) * bfround(bf2f(v[i][j]) * rs));
+                }
+                *reinterpret_cast<bf16x8*>(smem + b * xrow + c * 16) = o;
+            }
+        }
+    }
+    __syncthreads();
+    if (!ACTIVE) return;
+    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 16;
+    const int b = fr;
+
+    for (; t < ntiles; t += stride) {
+        const int tn = t + stride;
+        const bool more = tn < ntiles;
+        const kr_bf16* wpn = a.wp + ((int64_t)(more ? tn : t) * nchunks) * 1024 + lane * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < nchunks; cc += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = cc + u;
+                // keep the scheduler from hoisting every chunk's LDS reads to the top (their registers would
+                // not fit next to a whole-tile ring)
+                if ((u & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + c * 128);
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + 64);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][0], x0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][1], x1, acc, 0, 0, 0);
+                const int cn = c + U;
+                if (cn < nchunks) {
+                    wbuf[u][0] = ld8_nt(wp + (int64_t)cn * 1024);
+                    wbuf[u][1] = ld8_nt(wp + (int64_t)cn * 1024 + 512);
+                } else if (more) {  // the ring runs on into the next tile
+                    wbuf[u][0] = ld8_nt(wpn + (int64_t)(cn - nchunks) * 1024);
+                    wbuf[u][1] = ld8_nt(wpn + (int64_t)(cn - nchunks) * 1024 + 512);
+                }
+            }
+        }
+        wp = wpn;
+        // ---- epilogue of this wave's tile: lane = (row b, features 4*fg .. 4*fg+3)
+        if (EPI == DEPI_SILU8) {
+            float u4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u4[j] = __shfl_xor(acc[j], 32, 64);
+            if (b < M && fg < 2) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[j]) * u4[j]);
+                *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
+            }
+        } else if (EPI == DEPI_ARGMAX) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            const int n = t * 16 + fg * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) better(bv, bi, acc[j], n + j);
+            if (a.out_f32 && b < M) *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = acc;
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                better(bv, bi, ov, oi);
+            }
+            if (fg == 0 && b < M) {
+                a.amax_val[(int64_t)b * ntiles + t] = bv;
+                a.amax_idx[(int64_t)b * ntiles + t] = bi;
+            }
+        } else if (b < M) {  // PLAIN
+            const int n = t * 16 + fg * 4;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[j];
+            if (a.bias) {
+                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
+            }
+            if (a.residual) {
+                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
+            }
+            if (a.out_f32) {
+                *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+                *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI, int NCH>
+__global__ void __launch_bounds__(512) dec_wide_kernel(const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.x + a.wide_blocks * wave < (a.N >> 4)) dec_wide_body<EPI, NCH, true>(a, smem);
+    else dec_wide_body<EPI, NCH, false>(a, smem);
+}
+
+template <int EPI, int NCH>
+int launch_wide_n(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+    const size_t lds = (size_t)a.M * (a.K * 2 + 16);
+    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_wide: x needs %zu bytes of LDS", lds);
+    auto fn = &dec_wide_kernel<EPI, NCH>;
+    static bool attr = false;
+    if (!attr) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+template <int EPI>
+int launch_wide(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+    switch (a.K >> 6) {
+        case 24: return launch_wide_n<EPI, 24>(a, blocks, waves, s);
+        case 56: return launch_wide_n<EPI, 56>(a, blocks, waves, s);
+        default: return launch_wide_n<EPI, 0>(a, blocks, waves, s);
+    }
+}
+
+// =====================================================================================
 // decode attention with in-launch merge
 // =====================================================================================
 // grid = (n_split, kv_heads, batch); 4 waves; wave `part` = split*4 + wave walks 64-key blocks
@@ -732,6 +975,37 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
             return launch_dec_w<2, DEPI_ARGMAX>(a, (ntiles + 1) / 2, waves, max_blocks, s);
         default:
             kr_set_error("kr_linear_decode: unknown mode %d", mode);
+            return KR_ERR_ARG;
+    }
+}
+
+extern "C" int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
+                                     const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
+                                     float* amax_val, int32_t* amax_idx, kr_stream s) {
+    KR_CHECK_ARG(x && w_packed, "kr_linear_decode_wide: null pointer");
+    KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode_wide: M=%d must be in 1..16", M);
+    KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 512 == 0 && K <= 4096,
+                 "kr_linear_decode_wide: N=%d K=%d (N%%16, K%%512, K<=4096)", N, K);
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_wide: ldx");
+    KR_CHECK_ARG(blocks > 0 && waves >= 1 && waves <= 8, "kr_linear_decode_wide: blocks=%d waves=%d", blocks, waves);
+    DecLinArgs a{};
+    a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.ksplit = 1; a.amax_val = amax_val; a.amax_idx = amax_idx;
+    a.wide_blocks = blocks; a.wide_waves = waves;
+    switch (mode) {
+        case DEPI_PLAIN:
+            KR_CHECK_ARG((out || out_f32) && ldc >= N && (ldc & 3) == 0 && (!residual || (ldr & 3) == 0), "kr_linear_decode_wide: PLAIN output");
+            return launch_wide<DEPI_PLAIN>(a, blocks, waves, s);
+        case DEPI_SILU8:
+            KR_CHECK_ARG(out && ldc >= N / 2 && (ldc & 3) == 0, "kr_linear_decode_wide: SILU8 output");
+            return launch_wide<DEPI_SILU8>(a, blocks, waves, s);
+        case DEPI_ARGMAX:
+            KR_CHECK_ARG(amax_val && amax_idx && (!out_f32 || ldc >= N), "kr_linear_decode_wide: ARGMAX pointers");
+            return launch_wide<DEPI_ARGMAX>(a, blocks, waves, s);
+        default:
+            kr_set_error("kr_linear_decode_wide: mode %d not supported (PLAIN, SILU8, ARGMAX)", mode);
             return KR_ERR_ARG;
     }
 }

@@ -187,6 +187,7 @@ class Engine:
         self.n_split = decode_splits
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
+        self._prefetch_mode = int(os.environ.get("KARANTA_PREFETCH", "0"))
         self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
@@ -250,7 +251,11 @@ class Engine:
             v_ = os.environ.get("KARANTA_WV_" + name.upper())
             if v_:
                 setattr(self, "wv_" + name, int(v_))
-        self.n_amax = (t.vocab_size // 16 + 1) // 2
+        # gate/up and lm_head: one wave per 16-row tile (kr_linear_decode_wide) when K allows it
+        self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
+        self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
+        self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
+        self.n_amax = t.vocab_size // 16 if self.wide_mode else (t.vocab_size // 16 + 1) // 2
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
         self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
         self.d_plen = z(B, dtype=torch.int32)
@@ -291,6 +296,19 @@ class Engine:
                                 ptr(attn_partials), self.n_split, ptr(self.d_cs), self.max_new, ptr(self.d_plen),
                                 ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max,
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
+
+    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None):
+        """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
+        N, K = W.shape
+        tiles = N // 16
+        # no idle waves: W = tiles per CU (at most 8), then just enough workgroups for one tile per wave
+        # (gate/up of the 2B decoder: 1120 tiles = 224 workgroups x 5 waves); beyond that the waves loop
+        waves = self.wide_waves or min(8, -(-tiles // self.wide_blocks))
+        blocks = min(self.wide_blocks, -(-tiles // waves))
+        o = out if out is not None else out_f32
+        self.L.kr_linear_decode_wide(mode, ptr(x), x.stride(0), ptr(W), 0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0,
+                                     ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0, M, N, K, blocks, waves,
+                                     ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _h2d(self, dst: torch.Tensor, arr: np.ndarray):
         src = torch.from_numpy(np.ascontiguousarray(arr))
@@ -455,8 +473,12 @@ class Engine:
         """final RMSNorm (fused) -> lm_head with per-workgroup argmax partials -> greedy token,
         bookkeeping and the next step's rotary table (TF:839, :1320-1323; generate(do_sample=False))."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
-        self._dec(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
-                  out_f32=self.d_logits if self._want_logits else None, waves=self.wv_wide)
+        if self.wide_mode:
+            self._dec_wide(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
+                           out_f32=self.d_logits if self._want_logits else None)
+        else:
+            self._dec(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
+                      out_f32=self.d_logits if self._want_logits else None, waves=self.wv_wide)
         L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
                            ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_plen), ptr(self.d_ctx),
                            ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
@@ -473,6 +495,10 @@ class Engine:
             p = f"llm.{i}."
             # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base
             kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])
+            if self._prefetch_mode == 1:  # diagnostic: serial prefetch of this layer's weights into the Infinity Cache
+                a0 = w.layout[p + "ln1.w"][0]
+                a1 = w.layout[p + "down.w"][0] + 2 * int(np.prod(w.layout[p + "down.w"][1]))
+                L.kr_prefetch(w.arena.data_ptr() + a0, a1 - a0, 512, s)
             self._dec(DEC_ROPE_KV, self.d_x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                       waves=self.wv_qkv, kc=kc, vc=vc)
             L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
@@ -489,8 +515,11 @@ class Engine:
                 (e0, e1), (e2, _) = self._prof_event_pair(), self._prof_event_pair()
                 L.kr_event_record(e0, s)
                 L.kr_event_record(e1, s)
-            self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
-                      waves=self.wv_wide)
+            if self.wide_mode:
+                self._dec_wide(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+            else:
+                self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                          waves=self.wv_wide)
             if self._prof_on:
                 L.kr_event_record(e2, s)
             self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_down)

@@ -752,6 +752,85 @@ def test_linear_decode_argmax_and_sample(L):
     np.testing.assert_array_equal(host(xn), table[want])
 
 
+def run_wide(L, mode, x, W, blocks, waves, bias=None, res=None, norm_w=None, f32=False):
+    M, K = x.shape
+    N = W.shape[0]
+    nc = N // 2 if mode == DEC_SILU8 else N
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    out = torch.full((M, nc), 9.0, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    bd = dev_bf16(bias) if bias is not None else None
+    rd = dev_bf16(res) if res is not None else None
+    nd = dev_bf16(norm_w) if norm_w is not None else None
+    L.kr_linear_decode_wide(mode, ptr(xd), K, ptr(Wd), ptr(bd), ptr(nd), 1e-6, ptr(rd), nc if res is not None else 0,
+                            0 if f32 else ptr(out), ptr(out) if f32 else 0, nc, M, N, K, blocks, waves, 0, 0, 0)
+    return host(out)
+
+
+@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("N,K,blocks,waves", [(16, 512, 1, 1), (16 * 37, 512, 3, 5), (16 * 37, 1536, 256, 4),
+                                              (16 * 300, 1024, 7, 8), (16 * 41, 3584, 5, 2)])
+def test_linear_wide_plain_exact_on_integers(L, M, N, K, blocks, waves):
+    """One wave per tile, register ring running across tile boundaries: exact on small integers; the zeroed K
+    tail makes a wrong chunk order / wrong next-tile prefetch visible."""
+    rng = np.random.default_rng(M + N + K + blocks)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    W[:, K // 2 + 40:] = 0
+    W[::3, 100:300] = 1
+    np.testing.assert_array_equal(run_wide(L, DEC_PLAIN, x, W, blocks, waves), ref_linear(x, W))
+    np.testing.assert_array_equal(run_wide(L, DEC_PLAIN, x, W, blocks, waves, f32=True), ref_linear(x, W))
+
+
+@pytest.mark.parametrize("M,K,blocks,waves", [(8, 1536, 256, 5), (16, 3584, 9, 8), (3, 512, 2, 3)])
+def test_linear_wide_silu8_norm_bias_residual(L, M, K, blocks, waves):
+    rng = np.random.default_rng(162 + M)
+    ff = 1016
+    x, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    got = run_wide(L, DEC_SILU8, x, Wp, blocks, waves, norm_w=nw)
+    assert got.shape == (M, ff)
+    assert_close_bf16(got, ref_linear(xn, Wp, epi=EPI_SILU_MUL8), what="wide silu8")
+    N = 16 * 23
+    W2, bias, res = rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N, scale=0.1), rnd(rng, M, N)
+    assert_close_bf16(run_wide(L, DEC_PLAIN, x, W2, blocks, waves, bias=bias, res=res), ref_linear(x, W2, bias, res),
+                      what="wide plain")
+
+
+def test_linear_wide_argmax_and_sample(L):
+    rng = np.random.default_rng(81)
+    B, V, d = 3, 16 * 83, 512
+    x, W = ints(rng, B, d), ints(rng, V, d)
+    W[:, 200:] = 0
+    nw = np.ones(d, np.float32)
+    logits_ref = ref_linear(bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16"))), W)
+    xd, Wd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw)
+    n_part = V // 16
+    av = torch.zeros(B, n_part, dtype=torch.float32, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
+    lg = torch.zeros(B, V, dtype=torch.float32, device=DEV)
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, ptr(lg), V, B, V, d, 6, 4,
+                            ptr(av), ptr(ai), 0)
+    got = host(lg)
+    np.testing.assert_allclose(got, logits_ref, atol=2e-2, rtol=1e-2)
+    avh, aih = av.cpu().numpy(), ai.cpu().numpy()
+    for b in range(B):
+        for t in range(n_part):
+            seg = got[b, t * 16:(t + 1) * 16]
+            assert avh[b, t] == seg.max() and aih[b, t] == t * 16 + int(seg.argmax())
+    # without the logits buffer the partials are the same
+    av2 = torch.zeros_like(av); ai2 = torch.zeros_like(ai)
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, 0, 0, B, V, d, 256, 8,
+                            ptr(av2), ptr(ai2), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(av, av2) and torch.equal(ai, ai2)
+
+
+def test_linear_wide_rejects_bad_shapes(L):
+    x = torch.zeros(8, 576, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(KarantaHipError):
+        L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 576, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 8, 16, 576, 1, 4, 0, 0, 0)
+    with pytest.raises(KarantaHipError):
+        L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 512, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 8, 16, 512, 1, 9, 0, 0, 0)
+
+
 def test_sample_greedy_eos_and_pad(L):
     B, d, n_part = 3, 64, 5
     rng = np.random.default_rng(81)
