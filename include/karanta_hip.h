@@ -252,6 +252,22 @@ int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16
                           kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
                           float* amax_val, int32_t* amax_idx, kr_stream s);
 
+/* Narrow decode linears (qkv, o_proj, down_proj): one workgroup per 16-row tile (ROPE_KV: per rotary tile
+ * pair), K split over its `waves` (8 or 16; the norm prologue always runs 8) waves; x / norm weight / epilogue
+ * operands are requested before the weights.  Modes PLAIN and ROPE_KV as kr_linear_decode.
+ *   ksplit > 1 (PLAIN only): K is also split over `ksplit` workgroups and the reduction is DEFERRED: out_f32
+ *     receives f32 slabs [ksplit][M][ldc] (no bias / residual / norm); the consumer adds them.
+ *   part_in (with norm_w): n_part_in (= 2) slabs [n][M][K] f32 are added to x in the prologue,
+ *     x_new = bf16(x + sum of slabs) is RMS-normalised and, by workgroup 0, stored to x_out (ldxo), which
+ *     must not alias x (other workgroups still read x).  K must be 1536 or 3584 for this. */
+int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                            kr_bf16* x_out, int64_t ldxo, const kr_bf16* w_packed, const kr_bf16* bias,
+                            const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                            kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
+                            const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
+                            kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
+                            kr_stream s);
+
 /* Decode attention (q_len 1, GQA, MFMA, split over n_split key ranges), kcache / vtcache = the
  * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+4] partials (o[hd], m, l, 2 pad: 16-byte aligned records).
  * out != NULL: the splits are merged in-launch by the last-arriving workgroup (counters: int32

@@ -51,6 +51,10 @@ struct DecLinArgs {
     // wide kernel: launch geometry as kernel arguments (gridDim / blockDim come from the dispatch packet through
     // a dependent global load, ~1 us on the critical path of a 10 us kernel)
     int wide_blocks, wide_waves;
+    // narrow kernel: deferred split-K.  `part_in` [PKS][M][K] f32 partial sums of the previous down_proj that the
+    // x prologue adds to x (the residual stream); workgroup 0 writes the sum to x_out (a different buffer than x).
+    // PARTIAL epilogue: out_f32 = [ksplit][M][ldc] f32 slabs, no bias / residual.
+    const float* part_in; kr_bf16* x_out; int64_t ldxo;
 };
 
 __device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
@@ -653,6 +657,341 @@ int launch_wide(DecLinArgs& a, int blocks, int waves, kr_stream s) {
 }
 
 // =====================================================================================
+// narrow layers (qkv, o_proj, down_proj): one workgroup per tile (pair), K split over its waves
+// =====================================================================================
+// Same issue discipline as the wide kernel (x and the norm weight before the weights, branch-free, geometry
+// from kernel arguments), plus a split of K over blockIdx.y whose reduction is DEFERRED to the consumer: a
+// cross-workgroup reduction inside the launch costs a release/acquire pair (5-6 us measured, more than the
+// launch it saves), while two f32 slabs added in the next kernel's x prologue cost a few hundred bytes per lane.
+//   down_proj   : EPI PARTIAL, ksplit 2 -> 192 workgroups instead of 96, slabs [2][M][d] f32
+//   next qkv    : NORM prologue with PKS = 2: x_new = bf16(x + slab0 + slab1) (workgroup 0 stores it to x_out,
+//                 the other residual buffer), RMSNorm of x_new, QKV + bias + M-RoPE + KV append as before
+template <int NCH> struct NarrowCfg { static constexpr int RL = 8; };
+template <> struct NarrowCfg<24> { static constexpr int RL = 3; };
+template <> struct NarrowCfg<56> { static constexpr int RL = 7; };
+constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
+
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM>
+__global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int U = (WAVES == 16 ? 6 : 8) / NT;
+    constexpr int RL = NarrowCfg<NCH>::RL;
+    constexpr bool FULL = NCH != 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int g = blockIdx.x, ks = blockIdx.y;
+    const int M = a.M, K = a.K;
+    const int nchunks = NCH ? NCH : (K >> 6), ntiles = a.N >> 4, kc = K >> 3;
+    const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
+    const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
+    const int nblk = cb1 - cb0;
+    const int per = (nblk + WAVES - 1) / WAVES;
+    const int c0 = min(cb0 + wave * per, cb1), c1 = min(c0 + per, cb1);
+    const int xrow = nblk * 128 + 16;
+    float* red = reinterpret_cast<float*>(smem + (NORM ? ((M * xrow + 127) & ~127) : 0));  // [WAVES][NT][64][4]
+
+    int tile[NT];
+    if (EPI == DEPI_ROPE_KV) {
+        tile[0] = (g >> 2) * 8 + (g & 3);
+        tile[NT - 1] = tile[0] + 4;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile[t] = g * NT + t;
+    }
+    const kr_bf16* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = a.wp + ((int64_t)min(tile[t], ntiles - 1) * nchunks) * 1024 + lane * 8;
+    const int rb = fr < M ? fr : 0;  // batch row of this lane's accumulator column
+
+    // ---- 1. the oldest loads of every wave: what the prologue and the epilogue wait for
+    int pos = 0, plen = 0;
+    if (EPI == DEPI_ROPE_KV) {
+        pos = a.ctx_len[rb];
+        plen = a.prompt_len[rb];
+    }
+    bf16x8 xv[NORM ? RL : 1], nwv[NORM ? RL : 1];
+    f32x4 pv[PKS ? PKS : 1][NORM ? RL : 1][2];
+    bf16x8 xf[NORM ? 1 : U][2];
+    const kr_bf16* xg = a.x + (int64_t)rb * a.ldx + fg * 8;
+    if (NORM) {
+        const int b = wave < M ? wave : 0;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            const int c = lane + i * 64;
+            if (FULL || c < kc) {
+                xv[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+#pragma unroll
+                for (int k = 0; k < PKS; ++k) {
+                    const float* pp = a.part_in + ((int64_t)k * M + b) * K + c * 8;
+                    pv[k][i][0] = *reinterpret_cast<const f32x4*>(pp);
+                    pv[k][i][1] = *reinterpret_cast<const f32x4*>(pp + 4);
+                }
+                nwv[i] = ld8(a.norm_w + c * 8);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = min(max(min(c0 + u, c1 - 1), cb0), nchunks - 1);
+            xf[u][0] = ld8(xg + c * 64);
+            xf[u][1] = ld8(xg + c * 64 + 32);
+        }
+    }
+    // ---- 2. the weight ring (clamped, not branched: short waves re-request their last chunk)
+    bf16x8 wbuf[U][NT][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = min(max(min(c0 + u, c1 - 1), cb0), nchunks - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)c * 1024);
+            wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 512);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 3. x (+ deferred partial sums) -> RMSNorm -> LDS
+    if constexpr (NORM) {
+        auto norm_row = [&](const int b, bf16x8 (&xr)[RL], const bf16x8 (&nw)[RL]) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                if (FULL || lane + i * 64 < kc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += bf2f(xr[i][j]) * bf2f(xr[i][j]);
+                }
+            }
+            ss = wave_sum(ss);
+            const float rs = rsqrtf(ss / (float)K + a.norm_eps);
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                const int c = lane + i * 64;
+                if ((FULL || c < kc) && c >= cb0 * 8 && c < cb1 * 8) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[i][j]) * bfround(bf2f(xr[i][j]) * rs));
+                    *reinterpret_cast<bf16x8*>(smem + b * xrow + (c - cb0 * 8) * 16) = o;
+                }
+            }
+        };
+        if (PKS) {
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                if (FULL || lane + i * 64 < kc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = bf2f(xv[i][j]);
+#pragma unroll
+                        for (int k = 0; k < PKS; ++k) v += pv[k][i][j >> 2][j & 3];
+                        xv[i][j] = f2bf(v);
+                    }
+                    if (g == 0 && ks == 0 && wave < M)
+                        *reinterpret_cast<bf16x8*>(a.x_out + (int64_t)wave * a.ldxo + (lane + i * 64) * 8) = xv[i];
+                }
+            }
+        }
+        if (wave < M) norm_row(wave, xv, nwv);
+        for (int b = wave + WAVES; b < M; b += WAVES) {  // more rows than waves: the slow way (loads behind the weights)
+            bf16x8 v[RL];
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                const int c = lane + i * 64;
+                if (FULL || c < kc) {
+                    v[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+                    if (PKS) {
+                        float f[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = bf2f(v[i][j]);
+#pragma unroll
+                        for (int k = 0; k < PKS; ++k) {
+                            const float* pp = a.part_in + ((int64_t)k * M + b) * K + c * 8;
+                            const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                f[j] += p0[j];
+                                f[4 + j] += p1[j];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[i][j] = f2bf(f[j]);
+                        if (g == 0 && ks == 0) *reinterpret_cast<bf16x8*>(a.x_out + (int64_t)b * a.ldxo + c * 8) = v[i];
+                    }
+                }
+            }
+            norm_row(b, v, nwv);
+        }
+        __syncthreads();
+    }
+    // ---- 4. epilogue operands of the rotary modes: in flight during the K loop
+    float csv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x4 bias0 = {}, bias1 = {};
+    if (EPI == DEPI_ROPE_KV) {
+        const int i0 = (tile[0] & 7) * 16 + fg * 4;
+        const float* cs = a.cs_table + ((int64_t)rb * a.cs_stride + (pos - plen)) * 128;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + i0), sv = *reinterpret_cast<const f32x4*>(cs + 64 + i0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            csv[j] = cv[j];
+            csv[4 + j] = sv[j];
+        }
+        bias0 = *reinterpret_cast<const bf16x4*>(a.bias + tile[0] * 16 + fg * 4);
+        bias1 = *reinterpret_cast<const bf16x4*>(a.bias + tile[NT - 1] * 16 + fg * 4);
+    }
+
+    // ---- 5. K loop of this wave
+    const char* xl = smem + rb * xrow + fg * 16;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = c0; cc < c1; cc += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cc + u;
+            if (c < c1) {
+                bf16x8 x0, x1;
+                if (NORM) {
+                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
+                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 64);
+                } else {
+                    x0 = xf[u][0];
+                    x1 = xf[u][1];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][0], x0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][1], x1, acc[t], 0, 0, 0);
+                }
+                const int cn = c + U;
+                if (cn < c1) {
+                    if (!NORM) {
+                        xf[u][0] = ld8(xg + cn * 64);
+                        xf[u][1] = ld8(xg + cn * 64 + 32);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
+                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 512);
+                    }
+                }
+            }
+        }
+    }
+    // ---- 6. cross-wave sum, epilogue by wave 0
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 sum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
+        }
+    }
+    const int b = fr;
+    if (b >= M) return;
+    if (EPI == DEPI_ROPE_KV) {
+        const int hh = tile[0] >> 3;                   // global head index in [q heads | k heads | v heads]
+        const int i0 = (tile[0] & 7) * 16 + fg * 4;    // channel in [0, 64)
+        float lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = bfround(sum[0][j] + bf2f(bias0[j]));       // the projection output is a bf16 tensor
+            hi[j] = bfround(sum[NT - 1][j] + bf2f(bias1[j]));
+        }
+        if (hh < a.heads + a.kv_heads) {
+            bf16x4 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o0[j] = f2bf(lo[j] * csv[j] - hi[j] * csv[4 + j]);
+                o1[j] = f2bf(hi[j] * csv[j] + lo[j] * csv[4 + j]);
+            }
+            kr_bf16* dst = hh < a.heads
+                               ? a.q_out + ((int64_t)b * a.heads + hh) * 128
+                               : a.kcache + (((int64_t)b * a.kv_heads + (hh - a.heads)) * a.s_max + pos) * 128;
+            *reinterpret_cast<bf16x4*>(dst + i0) = o0;
+            *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
+        } else {
+            const int kvh = hh - a.heads - a.kv_heads;
+            kr_bf16* vt = a.vtcache + ((((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * 128) * 64 + (pos & 63);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
+                vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (tile[t] >= ntiles) continue;
+        const int n = tile[t] * 16 + fg * 4;
+        if (EPI == DEPI_PARTIAL) {
+            *reinterpret_cast<f32x4*>(a.out_f32 + ((int64_t)ks * M + b) * a.ldc + n) = sum[t];
+            continue;
+        }
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sum[t][j];
+        if (a.bias) {
+            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
+        }
+        if (a.residual) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
+        }
+        if (a.out_f32) {
+            *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+            *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
+        }
+    }
+}
+
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM>
+int launch_narrow_k(DecLinArgs& a, int groups, kr_stream s) {
+    const int nchunks = a.K >> 6, cpb = (nchunks + a.ksplit - 1) / a.ksplit;
+    const size_t xbytes = NORM ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
+    const size_t lds = xbytes + (size_t)WAVES * NT * 256 * 4;
+    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_narrow: needs %zu bytes of LDS", lds);
+    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM>;
+    static bool attr = false;
+    if (!attr) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+// NORM kernels are specialised on K (x row registers); PKS = 2 only where the registers allow it
+template <int NT, int EPI, int WAVES>
+int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
+    const int nch = a.K >> 6;
+    if (a.part_in) {
+        if (nch == 24) return launch_narrow_k<NT, EPI, WAVES, 24, 2, true>(a, groups, s);
+        if (nch == 56) return launch_narrow_k<NT, EPI, WAVES, 56, 2, true>(a, groups, s);
+        kr_set_error("kr_linear_decode_narrow: deferred partial sums need K = 1536 or 3584 (K=%d)", a.K);
+        return KR_ERR_ARG;
+    }
+    if (nch == 24) return launch_narrow_k<NT, EPI, WAVES, 24, 0, true>(a, groups, s);
+    if (nch == 56) return launch_narrow_k<NT, EPI, WAVES, 56, 0, true>(a, groups, s);
+    return launch_narrow_k<NT, EPI, WAVES, 0, 0, true>(a, groups, s);
+}
+
+// =====================================================================================
 // decode attention with in-launch merge
 // =====================================================================================
 // grid = (n_split, kv_heads, batch); 4 waves; wave `part` = split*4 + wave walks 64-key blocks
@@ -1006,6 +1345,56 @@ extern "C" int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, co
             return launch_wide<DEPI_ARGMAX>(a, blocks, waves, s);
         default:
             kr_set_error("kr_linear_decode_wide: mode %d not supported (PLAIN, SILU8, ARGMAX)", mode);
+            return KR_ERR_ARG;
+    }
+}
+
+extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                       kr_bf16* x_out, int64_t ldxo, const kr_bf16* w_packed, const kr_bf16* bias,
+                                       const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                                       kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
+                                       const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
+                                       kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
+                                       kr_stream s) {
+    KR_CHECK_ARG(x && w_packed, "kr_linear_decode_narrow: null pointer");
+    KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode_narrow: M=%d must be in 1..16", M);
+    KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 64 == 0, "kr_linear_decode_narrow: N=%d K=%d (N%%16, K%%64)", N, K);
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_narrow: ldx");
+    KR_CHECK_ARG(waves == 8 || waves == 16, "kr_linear_decode_narrow: waves=%d (8 or 16)", waves);
+    KR_CHECK_ARG(ksplit >= 1 && ksplit <= 8 && ksplit <= (K >> 6), "kr_linear_decode_narrow: ksplit=%d", ksplit);
+    KR_CHECK_ARG(!norm_w || K <= 4096, "kr_linear_decode_narrow: fused RMSNorm supports K <= 4096");
+    KR_CHECK_ARG(!part_in || (norm_w && n_part_in == 2 && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0),
+                 "kr_linear_decode_narrow: partial sums need the norm prologue, 2 slabs and a separate x_out");
+    DecLinArgs a{};
+    a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.ksplit = ksplit;
+    a.part_in = part_in; a.x_out = x_out; a.ldxo = ldxo;
+    a.cs_table = cs_table; a.cs_stride = cs_stride; a.prompt_len = prompt_len; a.ctx_len = ctx_len;
+    a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
+    a.heads = heads; a.kv_heads = kv_heads; a.s_max = s_max;
+    const int ntiles = N >> 4;
+    switch (mode) {
+        case DEPI_PLAIN:
+            KR_CHECK_ARG(ldc >= N && (ldc & 3) == 0 && (!residual || (ldr & 3) == 0), "kr_linear_decode_narrow: PLAIN ldc / ldr");
+            if (ksplit > 1) {  // deferred split-K: f32 slabs [ksplit][M][ldc], summed by the consumer
+                KR_CHECK_ARG(out_f32 && !out && !bias && !residual && !norm_w,
+                             "kr_linear_decode_narrow: split-K writes f32 slabs only (no bias / residual / norm)");
+                return waves == 16 ? launch_narrow_k<1, DEPI_PARTIAL, 16, 0, 0, false>(a, ntiles, s)
+                                   : launch_narrow_k<1, DEPI_PARTIAL, 8, 0, 0, false>(a, ntiles, s);
+            }
+            KR_CHECK_ARG(out || out_f32, "kr_linear_decode_narrow: PLAIN output");
+            if (norm_w) return launch_narrow_norm<1, DEPI_PLAIN, 8>(a, ntiles, s);  // x rows live in registers: 8 waves
+            return waves == 16 ? launch_narrow_k<1, DEPI_PLAIN, 16, 0, 0, false>(a, ntiles, s)
+                               : launch_narrow_k<1, DEPI_PLAIN, 8, 0, 0, false>(a, ntiles, s);
+        case DEPI_ROPE_KV:
+            KR_CHECK_ARG(norm_w && bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
+                         "kr_linear_decode_narrow: ROPE_KV pointers");
+            KR_CHECK_ARG(N == (heads + 2 * kv_heads) * 128 && s_max % 64 == 0 && ksplit == 1,
+                         "kr_linear_decode_narrow: ROPE_KV needs head_dim 128, ksplit 1");
+            return launch_narrow_norm<2, DEPI_ROPE_KV, 8>(a, ntiles / 2, s);
+        default:
+            kr_set_error("kr_linear_decode_narrow: mode %d not supported (PLAIN, ROPE_KV)", mode);
             return KR_ERR_ARG;
     }
 }

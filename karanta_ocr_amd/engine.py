@@ -235,6 +235,8 @@ class Engine:
         self.vtcache = z(t.num_layers, B, t.num_kv_heads, self.s_max // 64, t.head_dim, 64)
         # decode state
         self.d_x = z(B, t.hidden_size)
+        self.d_x2 = z(B, t.hidden_size)  # the other residual buffer (deferred split-K ping-pong)
+        self.d_part = z(2, B, t.hidden_size, dtype=torch.float32)  # down_proj slabs of the deferred split
         self.d_qkv = z(B, t.qkv_dim)
         self.d_q = z(B, t.num_heads, t.head_dim)
         self.d_o = z(B, t.q_dim)
@@ -251,6 +253,12 @@ class Engine:
             v_ = os.environ.get("KARANTA_WV_" + name.upper())
             if v_:
                 setattr(self, "wv_" + name, int(v_))
+        # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
+        # reduction deferred to the next layer's qkv prologue (K = 1536 / 3584 only)
+        self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
+        self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "0") == "1"  # 6.3 us vs 5.1 us: off
+        self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
+                           and t.hidden_size in (1536, 3584))
         # gate/up and lm_head: one wave per 16-row tile (kr_linear_decode_wide) when K allows it
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
@@ -296,6 +304,20 @@ class Engine:
                                 ptr(attn_partials), self.n_split, ptr(self.d_cs), self.max_new, ptr(self.d_plen),
                                 ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max,
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
+
+    def _dec_narrow(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=8, ksplit=1,
+                    part_in=None, x_out=None, kc=0, vc=0):
+        """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32."""
+        t = self.cfg.text
+        N, K = W.shape
+        o = out if out is not None else out_f32
+        ldc = o.stride(-2) if o is not None else 0  # slabs of the deferred split are [ksplit][M][ldc] with the CURRENT M, packed in d_part
+        self.L.kr_linear_decode_narrow(mode, ptr(x), x.stride(0), ptr(part_in), 2 if part_in is not None else 0, ptr(x_out),
+                                       x_out.stride(0) if x_out is not None else 0, ptr(W), ptr(bias), ptr(norm_w),
+                                       t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
+                                       ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs), self.max_new,
+                                       ptr(self.d_plen), ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads,
+                                       t.num_kv_heads, self.s_max, self.s)
 
     def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None):
         """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
@@ -469,15 +491,18 @@ class Engine:
             self._lm_head_and_sample(B)
         return lens
 
-    def _lm_head_and_sample(self, B: int):
+    def _lm_head_and_sample(self, B: int, x=None):
         """final RMSNorm (fused) -> lm_head with per-workgroup argmax partials -> greedy token,
-        bookkeeping and the next step's rotary table (TF:839, :1320-1323; generate(do_sample=False))."""
+        bookkeeping and the next step's rotary table (TF:839, :1320-1323; generate(do_sample=False)).
+        x = the residual buffer holding the last layer's output (d_x unless the decode step ended on the
+        other buffer); the next step's input embedding always goes to d_x."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
+        x = self.d_x if x is None else x
         if self.wide_mode:
-            self._dec_wide(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
+            self._dec_wide(DEC_ARGMAX, x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
                            out_f32=self.d_logits if self._want_logits else None)
         else:
-            self._dec(DEC_ARGMAX, self.d_x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
+            self._dec(DEC_ARGMAX, x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
                       out_f32=self.d_logits if self._want_logits else None, waves=self.wv_wide)
         L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
                            ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_plen), ptr(self.d_ctx),
@@ -486,12 +511,15 @@ class Engine:
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
-        """One decode step = 5 launches per layer + 2 (Qwen2VLDecoderLayer TF:559-624, final norm
-        TF:839, lm_head TF:1320-1323): [RMSNorm+QKV+bias+M-RoPE+KV append] -> attention ->
-        [o_proj+residual] -> [RMSNorm+gate/up+SiLU*mul] -> [down_proj+residual]."""
+        """One decode step = 6 launches per layer + 2 (Qwen2VLDecoderLayer TF:559-624, final norm
+        TF:839, lm_head TF:1320-1323): [(down_proj slabs +) RMSNorm+QKV+bias+M-RoPE+KV append] -> attention
+        partials -> merge -> [o_proj+residual] -> [RMSNorm+gate/up+SiLU*mul] -> [down_proj (+residual | slabs)]."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         H, KVH, hd = t.num_heads, t.num_kv_heads, t.head_dim
-        for i in range(t.num_layers):
+        nl = t.num_layers
+        x, x_other = self.d_x, self.d_x2   # residual stream: swaps buffers at every deferred reduction
+        pending = False                    # down_proj slabs of the previous layer waiting in d_part
+        for i in range(nl):
             p = f"llm.{i}."
             # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base
             kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])
@@ -499,16 +527,29 @@ class Engine:
                 a0 = w.layout[p + "ln1.w"][0]
                 a1 = w.layout[p + "down.w"][0] + 2 * int(np.prod(w.layout[p + "down.w"][1]))
                 L.kr_prefetch(w.arena.data_ptr() + a0, a1 - a0, 512, s)
-            self._dec(DEC_ROPE_KV, self.d_x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
-                      waves=self.wv_qkv, kc=kc, vc=vc)
+            if self.narrow_mode:
+                if pending:
+                    self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
+                                     norm_w=w.view(p + "ln1.w"), part_in=self.d_part, x_out=x_other, kc=kc, vc=vc)
+                    x, x_other = x_other, x
+                    pending = False
+                else:
+                    self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
+                                     norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc)
+            else:
+                self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
+                          waves=self.wv_qkv, kc=kc, vc=vc)
             L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
                                    self.s_max, self.n_split, hd ** -0.5, s)
             if self.merge_in_o_proj:
-                self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o,
+                self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o,
                           attn_partials=self.d_ws)
             else:
                 L.kr_attn_decode_merge(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
-                self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_o)
+                if self.narrow_o:
+                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8)
+                else:
+                    self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
             if self._prof_on:
                 # [e0][e1] gate/up [e2]: the empty bracket e0..e1 measures what two back-to-back event
                 # packets cost by themselves; it is subtracted from the bracket around the launch
@@ -516,16 +557,23 @@ class Engine:
                 L.kr_event_record(e0, s)
                 L.kr_event_record(e1, s)
             if self.wide_mode:
-                self._dec_wide(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+                self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
             else:
-                self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                self._dec(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                           waves=self.wv_wide)
             if self._prof_on:
                 L.kr_event_record(e2, s)
-            self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=self.d_x, res=self.d_x, waves=self.wv_down)
+            if self.defer_down and i + 1 < nl:
+                # 2 workgroups per tile; the slabs are added to x by the next layer's qkv prologue
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=16, ksplit=2)
+                pending = True
+            elif self.narrow_mode:
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=16)
+            else:
+                self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self.wv_down)
             for _ in range(self._extra_nulls):  # diagnostic: price of one more (empty) launch in the chain
                 L.kr_launch_null(s)
-        self._lm_head_and_sample(B)
+        self._lm_head_and_sample(B, x)
 
     # ------------------------------------------------------------------ live kernel timing (bench.py roofline)
     def _prof_event_pair(self):

@@ -831,6 +831,133 @@ def test_linear_wide_rejects_bad_shapes(L):
         L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 512, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 8, 16, 512, 1, 9, 0, 0, 0)
 
 
+def narrow_call(L, mode, x, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_w=0, res=0, ldr=0, waves=8, ksplit=1,
+                part_in=0, x_out=0, cs=0, cs_stride=0, plen=0, ctx=0, q_out=0, kc=0, vc=0, heads=0, kv_heads=0, s_max=64):
+    L.kr_linear_decode_narrow(mode, x, K, part_in, 2 if part_in else 0, x_out, K, W, bias, norm_w, 1e-6, res, ldr, out,
+                              out_f32, ldc, M, N, K, waves, ksplit, cs, cs_stride, plen, ctx, q_out, kc, vc, heads,
+                              kv_heads, s_max, 0)
+
+
+@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("N,K,waves", [(16, 64, 8), (48, 256, 8), (1536, 1536, 8), (96, 8960, 16), (96, 8960, 8),
+                                       (16 * 5, 64 * 19, 16), (32, 3584, 8)])
+def test_linear_narrow_plain_exact_on_integers(L, M, N, K, waves):
+    """K split over the waves of one workgroup (uneven chunk counts, waves without any chunk), x fragments straight
+    from global memory; the zeroed K tail makes a wrong chunk order visible."""
+    rng = np.random.default_rng(M + N + K + waves)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    W[:, K // 2 + 8:] = 0
+    W[::3, 10:40] = 1
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    out = torch.full((M, N), 9.0, dtype=torch.bfloat16, device=DEV)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(out), ldc=N, waves=waves)
+    np.testing.assert_array_equal(host(out), ref_linear(x, W))
+    res, bias = rnd(rng, M, N), rnd(rng, N, scale=0.1)
+    rd, bd = dev_bf16(res), dev_bf16(bias)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(rd), ldc=N, res=ptr(rd), ldr=N, bias=ptr(bd), waves=waves)
+    assert_close_bf16(host(rd), ref_linear(x, W, bias, res), what="narrow plain in-place residual")
+
+
+@pytest.mark.parametrize("M,N,K,ksplit,waves", [(8, 1536, 8960, 2, 16), (16, 96, 8960, 3, 8), (3, 48, 256, 2, 8),
+                                                (8, 64, 64 * 9, 8, 8)])
+def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
+    """ksplit > 1 writes f32 slabs [ksplit][M][N]; their sum is the product (exact on integers)."""
+    rng = np.random.default_rng(M + N + ksplit)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    slabs = torch.full((ksplit, M, N), 7.0, dtype=torch.float32, device=DEV)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(slabs), ldc=N, waves=waves, ksplit=ksplit)
+    got = slabs.cpu().numpy()
+    np.testing.assert_array_equal(got.sum(0), ref_linear(x, W))
+    cpb = -(-(K // 64) // ksplit) * 64
+    for k in range(ksplit):      # slab k holds exactly its K range
+        np.testing.assert_array_equal(got[k], ref_linear(x[:, k * cpb:(k + 1) * cpb], W[:, k * cpb:(k + 1) * cpb])
+                                      if k * cpb < K else np.zeros((M, N), np.float32))
+    with pytest.raises(KarantaHipError):   # slabs only: no residual / bf16 output in the split form
+        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(xd), ldc=N, waves=waves, ksplit=ksplit)
+
+
+@pytest.mark.parametrize("M,K,parts", [(8, 1536, True), (8, 1536, False), (16, 3584, True), (3, 256, False), (11, 1536, True)])
+def test_linear_narrow_norm_with_deferred_partials(L, M, K, parts):
+    """x_new = bf16(x + slab0 + slab1) -> x_out (written once, by workgroup 0), RMSNorm(x_new) @ W^T + bias."""
+    rng = np.random.default_rng(300 + M + K)
+    N = 16 * 9
+    x, W, nw = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    bias = rnd(rng, N, scale=0.1)
+    p = (rng.standard_normal((2, M, K)) * 0.5).astype(np.float32)
+    xd, Wd, nd, bd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw), dev_bf16(bias)
+    pd = torch.from_numpy(p).to(DEV)
+    xo = torch.full((M, K), 5.0, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(out), ldc=N, norm_w=ptr(nd), bias=ptr(bd),
+                part_in=ptr(pd) if parts else 0, x_out=ptr(xo) if parts else 0)
+    x_new = bf16_round(x + p[0] + p[1]) if parts else x
+    if parts:
+        got_x = host(xo)
+        assert np.abs(got_x - x_new).max() <= np.abs(x_new).max() * 2 ** -7     # fp32 sum order may move one bf16 ulp
+        x_new = got_x
+    xn = bf16_round(O.rms_norm(x_new, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(host(out), ref_linear(xn, W, bias), what="narrow norm + partials")
+
+
+def test_linear_narrow_partials_reject_unsupported_k(L):
+    x = torch.zeros(8, 256, dtype=torch.bfloat16, device=DEV); p = torch.zeros(2, 8, 256, device=DEV)
+    with pytest.raises(KarantaHipError):
+        narrow_call(L, DEC_PLAIN, ptr(x), ptr(x), 8, 16, 256, out=ptr(x), ldc=16, norm_w=ptr(x), part_in=ptr(p), x_out=ptr(p))
+    with pytest.raises(KarantaHipError):   # x_out must not alias x
+        L.kr_linear_decode_narrow(DEC_PLAIN, ptr(x), 256, ptr(p), 2, ptr(x), 256, ptr(x), 0, ptr(x), 1e-6, 0, 0, ptr(x), 0, 16,
+                                  8, 16, 256, 8, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+
+
+@pytest.mark.parametrize("H,KVH,K,parts", [(2, 1, 1024, False), (12, 2, 1536, True), (3, 1, 1536, False), (28, 4, 3584, True)])
+def test_linear_narrow_rope_kv(L, H, KVH, K, parts):
+    """Fused (partial sums +) RMSNorm + qkv projection + bias + M-RoPE + q / K-cache / V^T-cache writes."""
+    rng = np.random.default_rng(170 + H)
+    hd, B, s_max, T = 128, 5, 256, 7
+    N = (H + 2 * KVH) * hd
+    plen = np.asarray([0, 3, 60, 64, 198], np.int32)
+    step = np.asarray([0, 2, 3, 0, 6], np.int32)
+    ctxs = plen + step
+    x, W = rnd(rng, B, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
+    bias, nw = rnd(rng, N, scale=0.1), bf16_round(1 + 0.1 * rnd(rng, K))
+    p = (rng.standard_normal((2, B, K)) * 0.5).astype(np.float32)
+    ang = rng.uniform(0, 6.28, size=(B, T, 64)).astype(np.float32)
+    cs = np.concatenate([bf16_round(np.cos(ang)), bf16_round(np.sin(ang))], -1).astype(np.float32)
+    kc = rnd(rng, B, KVH, s_max, hd); vt = rnd(rng, B, KVH, s_max // 64, hd, 64)
+    kc_d, vt_d = dev_bf16(kc), dev_bf16(vt)
+    q_d = torch.zeros(B, H, hd, dtype=torch.bfloat16, device=DEV)
+    xd, Wd, bd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(bias), dev_bf16(nw)
+    pd = torch.from_numpy(p).to(DEV); xo = torch.zeros(B, K, dtype=torch.bfloat16, device=DEV)
+    cs_d, ctx_d, pl_d = torch.from_numpy(cs).to(DEV), torch.from_numpy(ctxs).to(DEV), torch.from_numpy(plen).to(DEV)
+    narrow_call(L, DEC_ROPE_KV, ptr(xd), ptr(Wd), B, N, K, bias=ptr(bd), norm_w=ptr(nd), part_in=ptr(pd) if parts else 0,
+                x_out=ptr(xo) if parts else 0, cs=ptr(cs_d), cs_stride=T, plen=ptr(pl_d), ctx=ptr(ctx_d), q_out=ptr(q_d),
+                kc=ptr(kc_d), vc=ptr(vt_d), heads=H, kv_heads=KVH, s_max=s_max)
+    x_new = host(xo) if parts else x
+    if parts:
+        ref_x = bf16_round(x + p[0] + p[1])
+        assert np.abs(x_new - ref_x).max() <= np.abs(ref_x).max() * 2 ** -7
+    xn = bf16_round(O.rms_norm(x_new, nw, 1e-6, O._Policy("bf16")))
+    qkv = bf16_round(ref_linear(xn, W, bias))
+    q = qkv[:, :H * hd].reshape(B, H, hd); k = qkv[:, H * hd:(H + KVH) * hd].reshape(B, KVH, hd)
+    v = qkv[:, (H + KVH) * hd:].reshape(B, KVH, hd)
+    csb = cs[np.arange(B), step]
+    cos, sin = np.concatenate([csb[:, :64]] * 2, -1), np.concatenate([csb[:, 64:]] * 2, -1)
+    qr = q * cos[:, None] + O.rotate_half(q) * sin[:, None]
+    kr = k * cos[:, None] + O.rotate_half(k) * sin[:, None]
+    assert_close_bf16(host(q_d), qr, abs_=3e-2, what="narrow fused q")
+    got_k, got_vt = host(kc_d), host(vt_d)
+    gv = got_vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd)
+    ref_v_all = vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd).copy()
+    ref_k_all = kc.copy()
+    for b, c in enumerate(ctxs):
+        assert_close_bf16(got_k[b, :, c], kr[b], abs_=3e-2, what="narrow fused k append")
+        assert_close_bf16(gv[b, :, c], v[b], abs_=3e-2, what="narrow fused v append")
+        ref_k_all[b, :, c] = got_k[b, :, c]
+        ref_v_all[b, :, c] = gv[b, :, c]
+    np.testing.assert_array_equal(got_k, ref_k_all)
+    np.testing.assert_array_equal(gv, ref_v_all)
+
+
 def test_sample_greedy_eos_and_pad(L):
     B, d, n_part = 3, 64, 5
     rng = np.random.default_rng(81)
