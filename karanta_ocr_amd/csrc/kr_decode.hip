@@ -671,10 +671,11 @@ template <> struct NarrowCfg<24> { static constexpr int RL = 3; };
 template <> struct NarrowCfg<56> { static constexpr int RL = 7; };
 constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 
-template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM>
+// U = ring depth in 64-wide K chunks: the host picks the smallest instantiated U that covers a wave's share of K
+// (then every chunk is requested up front and at most one request per wave is redundant), else the deepest ring.
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U>
 __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int U = (WAVES == 16 ? 6 : 8) / NT;
     constexpr int RL = NarrowCfg<NCH>::RL;
     constexpr bool FULL = NCH != 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -686,8 +687,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
     const int nblk = cb1 - cb0;
-    const int per = (nblk + WAVES - 1) / WAVES;
-    const int c0 = min(cb0 + wave * per, cb1), c1 = min(c0 + per, cb1);
+    const int c0 = cb0 + (wave * nblk) / WAVES, c1 = cb0 + ((wave + 1) * nblk) / WAVES;  // even shares, contiguous
     const int xrow = nblk * 128 + 16;
     float* red = reinterpret_cast<float*>(smem + (NORM ? ((M * xrow + 127) & ~127) : 0));  // [WAVES][NT][64][4]
 
@@ -959,13 +959,13 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     }
 }
 
-template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM>
-int launch_narrow_k(DecLinArgs& a, int groups, kr_stream s) {
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U>
+int launch_narrow_u(DecLinArgs& a, int groups, kr_stream s) {
     const int nchunks = a.K >> 6, cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const size_t xbytes = NORM ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
     const size_t lds = xbytes + (size_t)WAVES * NT * 256 * 4;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_narrow: needs %zu bytes of LDS", lds);
-    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM>;
+    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM, U>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -976,19 +976,44 @@ int launch_narrow_k(DecLinArgs& a, int groups, kr_stream s) {
     return KR_OK;
 }
 
+// chunks of K the busiest wave of a workgroup owns
+inline int narrow_share(const DecLinArgs& a, int waves) {
+    const int nchunks = a.K >> 6, cpb = (nchunks + a.ksplit - 1) / a.ksplit;
+    return (cpb + waves - 1) / waves;
+}
+
+// x fragments straight from global memory (o_proj, down_proj): rings of 3 / 5 / 8 chunks (x + weights = 16 U VGPRs)
+template <int EPI, int WAVES>
+int launch_narrow_direct(DecLinArgs& a, int groups, kr_stream s) {
+    const int share = narrow_share(a, WAVES);
+    if (share <= 3) return launch_narrow_u<1, EPI, WAVES, 0, 0, false, 3>(a, groups, s);
+    if constexpr (WAVES == 16) {  // 128-VGPR budget
+        return launch_narrow_u<1, EPI, WAVES, 0, 0, false, 5>(a, groups, s);
+    } else {
+        if (share <= 5) return launch_narrow_u<1, EPI, WAVES, 0, 0, false, 5>(a, groups, s);
+        return launch_narrow_u<1, EPI, WAVES, 0, 0, false, 8>(a, groups, s);
+    }
+}
+
 // NORM kernels are specialised on K (x row registers); PKS = 2 only where the registers allow it
-template <int NT, int EPI, int WAVES>
+template <int NT, int EPI, int NCH, int PKS>
+int launch_narrow_norm_u(DecLinArgs& a, int groups, kr_stream s) {
+    if (narrow_share(a, 8) <= 3) return launch_narrow_u<NT, EPI, 8, NCH, PKS, true, 3>(a, groups, s);
+    return launch_narrow_u<NT, EPI, 8, NCH, PKS, true, 8 / NT>(a, groups, s);
+}
+
+template <int NT, int EPI>
 int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
     const int nch = a.K >> 6;
     if (a.part_in) {
-        if (nch == 24) return launch_narrow_k<NT, EPI, WAVES, 24, 2, true>(a, groups, s);
-        if (nch == 56) return launch_narrow_k<NT, EPI, WAVES, 56, 2, true>(a, groups, s);
+        if (nch == 24) return launch_narrow_norm_u<NT, EPI, 24, 2>(a, groups, s);
+        if (nch == 56) return launch_narrow_norm_u<NT, EPI, 56, 2>(a, groups, s);
         kr_set_error("kr_linear_decode_narrow: deferred partial sums need K = 1536 or 3584 (K=%d)", a.K);
         return KR_ERR_ARG;
     }
-    if (nch == 24) return launch_narrow_k<NT, EPI, WAVES, 24, 0, true>(a, groups, s);
-    if (nch == 56) return launch_narrow_k<NT, EPI, WAVES, 56, 0, true>(a, groups, s);
-    return launch_narrow_k<NT, EPI, WAVES, 0, 0, true>(a, groups, s);
+    if (nch == 24) return launch_narrow_norm_u<NT, EPI, 24, 0>(a, groups, s);
+    if (nch == 56) return launch_narrow_norm_u<NT, EPI, 56, 0>(a, groups, s);
+    return launch_narrow_norm_u<NT, EPI, 0, 0>(a, groups, s);
 }
 
 // =====================================================================================
@@ -1380,19 +1405,19 @@ extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, 
             if (ksplit > 1) {  // deferred split-K: f32 slabs [ksplit][M][ldc], summed by the consumer
                 KR_CHECK_ARG(out_f32 && !out && !bias && !residual && !norm_w,
                              "kr_linear_decode_narrow: split-K writes f32 slabs only (no bias / residual / norm)");
-                return waves == 16 ? launch_narrow_k<1, DEPI_PARTIAL, 16, 0, 0, false>(a, ntiles, s)
-                                   : launch_narrow_k<1, DEPI_PARTIAL, 8, 0, 0, false>(a, ntiles, s);
+                return waves == 16 ? launch_narrow_direct<DEPI_PARTIAL, 16>(a, ntiles, s)
+                                   : launch_narrow_direct<DEPI_PARTIAL, 8>(a, ntiles, s);
             }
             KR_CHECK_ARG(out || out_f32, "kr_linear_decode_narrow: PLAIN output");
-            if (norm_w) return launch_narrow_norm<1, DEPI_PLAIN, 8>(a, ntiles, s);  // x rows live in registers: 8 waves
-            return waves == 16 ? launch_narrow_k<1, DEPI_PLAIN, 16, 0, 0, false>(a, ntiles, s)
-                               : launch_narrow_k<1, DEPI_PLAIN, 8, 0, 0, false>(a, ntiles, s);
+            if (norm_w) return launch_narrow_norm<1, DEPI_PLAIN>(a, ntiles, s);  // x rows live in registers: 8 waves
+            return waves == 16 ? launch_narrow_direct<DEPI_PLAIN, 16>(a, ntiles, s)
+                               : launch_narrow_direct<DEPI_PLAIN, 8>(a, ntiles, s);
         case DEPI_ROPE_KV:
             KR_CHECK_ARG(norm_w && bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
                          "kr_linear_decode_narrow: ROPE_KV pointers");
             KR_CHECK_ARG(N == (heads + 2 * kv_heads) * 128 && s_max % 64 == 0 && ksplit == 1,
                          "kr_linear_decode_narrow: ROPE_KV needs head_dim 128, ksplit 1");
-            return launch_narrow_norm<2, DEPI_ROPE_KV, 8>(a, ntiles / 2, s);
+            return launch_narrow_norm<2, DEPI_ROPE_KV>(a, ntiles / 2, s);
         default:
             kr_set_error("kr_linear_decode_narrow: mode %d not supported (PLAIN, ROPE_KV)", mode);
             return KR_ERR_ARG;

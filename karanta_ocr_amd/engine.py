@@ -256,7 +256,7 @@ class Engine:
         # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
         # reduction deferred to the next layer's qkv prologue (K = 1536 / 3584 only)
         self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
-        self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "0") == "1"  # 6.3 us vs 5.1 us: off
+        self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
                            and t.hidden_size in (1536, 3584))
         # gate/up and lm_head: one wave per 16-row tile (kr_linear_decode_wide) when K allows it
