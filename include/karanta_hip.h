@@ -246,7 +246,8 @@ int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_p
  * reduction and no barrier after the prologue; an 8-deep register ring streams on across tile boundaries
  * (K % 512 == 0, K <= 4096).  `blocks` workgroups of `waves` (<= 8) waves; wave (b, w) walks tiles
  * b + blocks*(w + waves*i).  Modes PLAIN / SILU8 / ARGMAX as kr_linear_decode; ARGMAX partials are per
- * tile: amax_val / amax_idx [M][N/16]. */
+ * wave: amax_val / amax_idx [M][blocks*waves], slot b + blocks*w (value -inf, index INT_MAX for a wave
+ * without tiles). */
 int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                           const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                           kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,

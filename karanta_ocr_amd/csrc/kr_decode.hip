@@ -538,9 +538,18 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
         }
     }
     __syncthreads();
-    if (!ACTIVE) return;
-    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 16;
     const int b = fr;
+    if (!ACTIVE) {
+        if (EPI == DEPI_ARGMAX && fg == 0 && b < M) {  // the sampler reads every wave's partial
+            a.amax_val[(int64_t)b * stride + t] = -INFINITY;
+            a.amax_idx[(int64_t)b * stride + t] = 0x7fffffff;
+        }
+        return;
+    }
+    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 16;
+    const int pidx = t;  // this wave's partial-argmax slot: blockIdx.x + blocks * wave
+    float rbv = -INFINITY;
+    int rbi = 0x7fffffff;
 
     for (; t < ntiles; t += stride) {
         const int tn = t + stride;
@@ -580,23 +589,11 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[j]) * u4[j]);
                 *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
             }
-        } else if (EPI == DEPI_ARGMAX) {
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
+        } else if (EPI == DEPI_ARGMAX) {  // running argmax over this wave's tiles, written once after the loop
             const int n = t * 16 + fg * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) better(bv, bi, acc[j], n + j);
+            for (int j = 0; j < 4; ++j) better(rbv, rbi, acc[j], n + j);
             if (a.out_f32 && b < M) *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = acc;
-#pragma unroll
-            for (int o = 16; o < 64; o <<= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                better(bv, bi, ov, oi);
-            }
-            if (fg == 0 && b < M) {
-                a.amax_val[(int64_t)b * ntiles + t] = bv;
-                a.amax_idx[(int64_t)b * ntiles + t] = bi;
-            }
         } else if (b < M) {  // PLAIN
             const int n = t * 16 + fg * 4;
             float v[4];
@@ -620,6 +617,18 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
                 *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
             }
+        }
+    }
+    if (EPI == DEPI_ARGMAX) {
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float ov = __shfl_xor(rbv, o, 64);
+            const int oi = __shfl_xor(rbi, o, 64);
+            better(rbv, rbi, ov, oi);
+        }
+        if (fg == 0 && b < M) {
+            a.amax_val[(int64_t)b * stride + pidx] = rbv;
+            a.amax_idx[(int64_t)b * stride + pidx] = rbi;
         }
     }
 }
@@ -1181,17 +1190,39 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
 
 // Merge of the split-KV partials as a launch of its own: one 128-thread workgroup per (sequence, head).
 // (Cheaper end-to-end than replicating the merge in every o_proj workgroup's prologue: measured.)
+// NS > 0: all n_split records are requested at once (one memory round trip instead of two dependent loops).
+template <int NS>
 __global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict__ ws, kr_bf16* __restrict__ out, int n_split) {
     constexpr int HD = 128, REC = HD + 4;
     const int bh = blockIdx.x, d = threadIdx.x;
-    const float* w = ws + (int64_t)bh * n_split * REC;
-    float mm = -1e30f;
-    for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * REC + HD]);
     float acc = 0.f, ll = 0.f;
-    for (int p = 0; p < n_split; ++p) {
-        const float sc = __builtin_amdgcn_exp2f(w[p * REC + HD] - mm);
-        acc += w[p * REC + d] * sc;
-        ll += w[p * REC + HD + 1] * sc;
+    if constexpr (NS > 0) {
+        const float* w = ws + (int64_t)bh * NS * REC;
+        float m[NS], l[NS], o[NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            m[p] = w[p * REC + HD];
+            l[p] = w[p * REC + HD + 1];
+            o[p] = w[p * REC + d];
+        }
+        float mm = -1e30f;
+#pragma unroll
+        for (int p = 0; p < NS; ++p) mm = fmaxf(mm, m[p]);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            const float sc = __builtin_amdgcn_exp2f(m[p] - mm);
+            acc += o[p] * sc;
+            ll += l[p] * sc;
+        }
+    } else {
+        const float* w = ws + (int64_t)bh * n_split * REC;
+        float mm = -1e30f;
+        for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * REC + HD]);
+        for (int p = 0; p < n_split; ++p) {
+            const float sc = __builtin_amdgcn_exp2f(w[p * REC + HD] - mm);
+            acc += w[p * REC + d] * sc;
+            ll += w[p * REC + HD + 1] * sc;
+        }
     }
     out[(int64_t)bh * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
 }
@@ -1447,7 +1478,12 @@ extern "C" int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int ba
                                     kr_stream s) {
     KR_CHECK_ARG(workspace && out && batch > 0 && heads > 0 && n_split > 0, "kr_attn_decode_merge: bad args");
     KR_CHECK_ARG(hd == 128, "kr_attn_decode_merge: hd=%d (only 128)", hd);
-    attn_merge_kernel<<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split);
+    switch (n_split) {
+        case 4: attn_merge_kernel<4><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
+        case 8: attn_merge_kernel<8><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
+        case 16: attn_merge_kernel<16><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
+        default: attn_merge_kernel<0><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split);
+    }
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

@@ -15,8 +15,9 @@ for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != "FETCH_SIZE":
         continue
     name = r["Kernel_Name"]
-    if "dec_linear_kernel" in name or "attn_decode2" in name:
-        short = re.search(r"(dec_linear_kernel<[^>]*>|attn_decode2_kernel<[^>]*>)", name).group(1)
+    m = re.search(r"(dec_linear_kernel<[^>]*>|dec_wide_kernel<[^>]*>|dec_narrow_kernel<[^>]*>|attn_decode2_kernel<[^>]*>)", name)
+    if m:
+        short = m.group(1)
         g[(short, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
 res = {}
 for (name, grid), v in g.items():

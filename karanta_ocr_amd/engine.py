@@ -263,7 +263,8 @@ class Engine:
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
         self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
-        self.n_amax = t.vocab_size // 16 if self.wide_mode else (t.vocab_size // 16 + 1) // 2
+        wb, ww = self._wide_geometry(t.vocab_size)
+        self.n_amax = wb * ww if self.wide_mode else (t.vocab_size // 16 + 1) // 2  # one argmax partial per wave
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
         self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
         self.d_plen = z(B, dtype=torch.int32)
@@ -319,14 +320,18 @@ class Engine:
                                        ptr(self.d_plen), ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads,
                                        t.num_kv_heads, self.s_max, self.s)
 
+    def _wide_geometry(self, N: int):
+        """(workgroups, waves) of a wide launch.  No idle waves: W = tiles per CU (at most 8), then just enough
+        workgroups for one tile per wave (gate/up of the 2B decoder: 1120 tiles = 224 workgroups x 5 waves);
+        beyond that the waves loop over their tiles."""
+        tiles = N // 16
+        waves = self.wide_waves or min(8, -(-tiles // self.wide_blocks))
+        return min(self.wide_blocks, -(-tiles // waves)), waves
+
     def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None):
         """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
         N, K = W.shape
-        tiles = N // 16
-        # no idle waves: W = tiles per CU (at most 8), then just enough workgroups for one tile per wave
-        # (gate/up of the 2B decoder: 1120 tiles = 224 workgroups x 5 waves); beyond that the waves loop
-        waves = self.wide_waves or min(8, -(-tiles // self.wide_blocks))
-        blocks = min(self.wide_blocks, -(-tiles // waves))
+        blocks, waves = self._wide_geometry(N)
         o = out if out is not None else out_f32
         self.L.kr_linear_decode_wide(mode, ptr(x), x.stride(0), ptr(W), 0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0,
                                      ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0, M, N, K, blocks, waves,
@@ -587,9 +592,8 @@ class Engine:
         return pair
 
     def kernel_profile(self, reset: bool = True) -> Dict[str, float]:
-        """Durations of the decode gate/up projection (`dec_linear_kernel<2, SILU>`, the kernel that moves
-        half of the decoder's bytes) measured with HIP events on the launch stream during the profiled
-        eager steps.  Each sample is a HIP-event bracket around the one launch, minus an empty bracket
+        """Durations of the decode gate/up projection (the kernel that moves half of the decoder's bytes)
+        measured with HIP events on the launch stream during the profiled eager steps.  Each sample is a HIP-event bracket around the one launch, minus an empty bracket
         (two events, nothing between) recorded right before it — the event packets' own cost.  Returns {launches, avg_us, min_us, bracket_us, null_bracket_us, bytes_per_launch}."""
         self.stream.synchronize()
         ms = C.c_float()
@@ -609,6 +613,45 @@ class Engine:
         null = float(np.mean(nulls)) if nulls else 0.0
         return {"launches": len(vals), "bracket_us": raw, "null_bracket_us": null, "avg_us": max(raw - null, 0.0),
                 "min_us": float(np.min(vals) - null) if vals else 0.0, "bytes_per_launch": nbytes}
+
+    def gate_up_chain_profile(self, B: int, reps: int = 8) -> Dict[str, float]:
+        """Average launch duration of the decode gate/up kernel, HIP events on the launch stream around a replayed
+        graph of reps x num_layers back-to-back launches, each on its own layer's weights (so no launch finds its
+        weights in a cache: 28 x 55 MB against 32 MB of L2 and 256 MB of Infinity Cache).  The per-launch figure
+        includes the dispatch gap between dependent launches, as a rocprofv3 kernel span in a graph replay does."""
+        t, w, L = self.cfg.text, self.w, self.L
+        e0, e1 = self._prof_event_pair()
+        self._prof_next -= 1
+        def chain(n):
+            for _ in range(n):
+                for i in range(t.num_layers):
+                    p = f"llm.{i}."
+                    if self.wide_mode:
+                        self._dec_wide(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+                    else:
+                        self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                                  waves=self.wv_wide)
+        chain(1)                               # eager once (function attributes), then captured: a replayed
+        self.stream.synchronize()              # graph issues the launches at the GPU's pace, not Python's
+        g = C.c_void_p()
+        L.kr_graph_begin_capture(self.s)
+        try:
+            chain(reps)
+        finally:
+            L.kr_graph_end_capture(self.s, C.byref(g))
+        ms, best = C.c_float(), None
+        for _ in range(3):
+            L.kr_event_record(e0, self.s)
+            L.kr_graph_launch(g, self.s)
+            L.kr_event_record(e1, self.s)
+            L.kr_event_synchronize(e1)
+            L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+            best = ms.value if best is None else min(best, ms.value)
+        L.kr_graph_destroy(g)
+        ms.value = best
+        n = reps * t.num_layers
+        nbytes = 2 * (2 * t.intermediate_size * t.hidden_size + t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
+        return {"launches": n, "avg_us": ms.value * 1e3 / n, "bytes_per_launch": nbytes}
 
     def _graph_for(self, B: int) -> int:
         key = (B, self._ignore_eos)

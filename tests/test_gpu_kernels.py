@@ -803,24 +803,39 @@ def test_linear_wide_argmax_and_sample(L):
     nw = np.ones(d, np.float32)
     logits_ref = ref_linear(bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16"))), W)
     xd, Wd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw)
-    n_part = V // 16
+    blocks, waves = 6, 4
+    n_part = blocks * waves
     av = torch.zeros(B, n_part, dtype=torch.float32, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
     lg = torch.zeros(B, V, dtype=torch.float32, device=DEV)
-    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, ptr(lg), V, B, V, d, 6, 4,
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, ptr(lg), V, B, V, d, blocks, waves,
                             ptr(av), ptr(ai), 0)
     got = host(lg)
     np.testing.assert_allclose(got, logits_ref, atol=2e-2, rtol=1e-2)
     avh, aih = av.cpu().numpy(), ai.cpu().numpy()
     for b in range(B):
-        for t in range(n_part):
-            seg = got[b, t * 16:(t + 1) * 16]
-            assert avh[b, t] == seg.max() and aih[b, t] == t * 16 + int(seg.argmax())
-    # without the logits buffer the partials are the same
-    av2 = torch.zeros_like(av); ai2 = torch.zeros_like(ai)
-    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, 0, 0, B, V, d, 256, 8,
+        for p_ in range(n_part):       # partial p = the tiles p, p + n_part, ...; ties -> lowest index
+            cols = np.concatenate([np.arange(t * 16, t * 16 + 16) for t in range(p_, V // 16, n_part)])
+            j = int(np.argmax(got[b, cols]))
+            assert avh[b, p_] == got[b, cols[j]] and aih[b, p_] == cols[j]
+        assert aih[b, int(np.lexsort((aih[b], -avh[b]))[0])] == int(got[b].argmax())
+    # without the logits buffer; more waves than tiles: empty partials are (-inf, INT_MAX)
+    blocks2, waves2 = 256, 8
+    av2 = torch.zeros(B, blocks2 * waves2, device=DEV); ai2 = torch.zeros(B, blocks2 * waves2, dtype=torch.int32, device=DEV)
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), d, ptr(Wd), 0, ptr(nd), 1e-6, 0, 0, 0, 0, 0, B, V, d, blocks2, waves2,
                             ptr(av2), ptr(ai2), 0)
     torch.cuda.synchronize()
-    assert torch.equal(av, av2) and torch.equal(ai, ai2)
+    a2, i2 = av2.cpu().numpy(), ai2.cpu().numpy()
+    assert np.isneginf(a2[:, V // 16:]).all() and (i2[:, V // 16:] == 0x7fffffff).all()
+    for b in range(B):
+        assert i2[b, int(np.lexsort((i2[b], -a2[b]))[0])] == int(got[b].argmax())
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.full((4, 4), -1, dtype=torch.int32, device=DEV)
+    plen = torch.zeros(B, dtype=torch.int32, device=DEV); ctx = torch.zeros(B, dtype=torch.int32, device=DEV)
+    fin = torch.zeros(B, dtype=torch.int32, device=DEV); eos = torch.tensor([-5], dtype=torch.int32, device=DEV)
+    table = rnd(rng, V, d); td = dev_bf16(table); xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
+    L.kr_sample_greedy(ptr(av2), ptr(ai2), blocks2 * waves2, ptr(td), d, ptr(tok), ptr(hist), 4, ptr(plen), ptr(ctx), ptr(fin),
+                       ptr(eos), 1, 0, 0, ptr(xn), B, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(tok.cpu().numpy(), got.argmax(1))
 
 
 def test_linear_wide_rejects_bad_shapes(L):
