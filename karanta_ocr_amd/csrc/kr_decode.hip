@@ -1147,6 +1147,15 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
         }
         if (n_split == 1 && out) {
             out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+        } else if (out) {
+            // in-launch merge: the records travel past the (per-XCD, non-coherent) L2 with agent-scope relaxed
+            // atomics, so no cache write-back / invalidate is needed around the arrival counter
+            float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * REC;
+            __hip_atomic_store(w + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(w + HD, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w + HD + 1, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * REC;
             w[d] = acc;
@@ -1156,33 +1165,42 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
             }
         }
     }
-    if (n_split == 1 || !out) return;  // out == NULL: the consumer (o_proj prologue) merges the partials
-    // ---- cross-workgroup merge by the last arriver (agent-scope release / acquire)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n_split == 1 || !out) return;  // out == NULL: a later launch (kr_attn_decode_merge) merges the partials
+    // ---- cross-workgroup merge by the last arriver.  Nobody waits: the other workgroups just leave.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have been acknowledged
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = __hip_atomic_fetch_add(counters + b * kv_heads + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = (old == n_split - 1);
-        if (old == n_split - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(counters + b * kv_heads + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (old == n_split - 1) __hip_atomic_store(counters + b * kv_heads + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!last_s) return;
+    constexpr int MAXS = 16;
     for (int e = tid; e < group * HD; e += NTHR) {
         const int gg = e >> 7, d = e & 127;
         const float* w = ws + (int64_t)(bh0 + gg) * n_split * REC;
+        float m[MAXS], l[MAXS], o[MAXS];
+#pragma unroll
+        for (int p = 0; p < MAXS; ++p) {
+            if (p < n_split) {
+                m[p] = __hip_atomic_load(w + p * REC + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                l[p] = __hip_atomic_load(w + p * REC + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                o[p] = __hip_atomic_load(w + p * REC + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         float mm = -1e30f;
-        for (int p = 0; p < n_split; ++p) mm = fmaxf(mm, w[p * REC + HD]);
+#pragma unroll
+        for (int p = 0; p < MAXS; ++p)
+            if (p < n_split) mm = fmaxf(mm, m[p]);
         float acc = 0.f, ll = 0.f;
-        for (int p = 0; p < n_split; ++p) {
-            const float sc = __builtin_amdgcn_exp2f(w[p * REC + HD] - mm);
-            acc += w[p * REC + d] * sc;
-            ll += w[p * REC + HD + 1] * sc;
+#pragma unroll
+        for (int p = 0; p < MAXS; ++p) {
+            if (p < n_split) {
+                const float sc = __builtin_amdgcn_exp2f(m[p] - mm);
+                acc += o[p] * sc;
+                ll += l[p] * sc;
+            }
         }
         out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
     }
@@ -1462,6 +1480,7 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     KR_CHECK_ARG(hd == 128, "kr_attn_decode_fused: hd=%d (only 128)", hd);
     KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_fused: GQA group must be <= 16");
     KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
+    KR_CHECK_ARG(!out || n_split <= 16, "kr_attn_decode_fused: the in-launch merge takes at most 16 splits");
     KR_CHECK_ARG(!out || n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
     // few splits: 8 waves per workgroup keep the same number of waves streaming the cache
     if (n_split <= 4)

@@ -243,6 +243,7 @@ class Engine:
         self.d_act = z(B, t.intermediate_size)
         self.d_logits = z(B, t.vocab_size, dtype=torch.float32)
         self.d_ws = z(B * t.num_heads * self.n_split * (t.head_dim + 4), dtype=torch.float32)
+        self.d_cnt = z(B * t.num_kv_heads, dtype=torch.int32)  # arrival counters of the in-launch attention merge
         # waves per workgroup of the narrow decode linears: enough waves that every wave still
         # streams >= 2 K-chunks, no cross-workgroup reduction (each fence/atomic hop costs microseconds)
         self.wv_qkv = self._waves(t.hidden_size // 64)
@@ -255,6 +256,7 @@ class Engine:
                 setattr(self, "wv_" + name, int(v_))
         # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
         # reduction deferred to the next layer's qkv prologue (K = 1536 / 3584 only)
+        self.attn_fused_merge = os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"
         self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
         self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
@@ -544,9 +546,18 @@ class Engine:
             else:
                 self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                           waves=self.wv_qkv, kc=kc, vc=vc)
-            L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
-                                   self.s_max, self.n_split, hd ** -0.5, s)
-            if self.merge_in_o_proj:
+            if self.attn_fused_merge:  # the last split workgroup of each (sequence, kv head) merges: no merge launch
+                L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o), ptr(self.d_ws), ptr(self.d_cnt),
+                                       B, H, KVH, hd, self.s_max, self.n_split, hd ** -0.5, s)
+            else:
+                L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
+                                       self.s_max, self.n_split, hd ** -0.5, s)
+            if self.attn_fused_merge:
+                if self.narrow_o:
+                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8)
+                else:
+                    self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
+            elif self.merge_in_o_proj:
                 self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o,
                           attn_partials=self.d_ws)
             else:
