@@ -253,38 +253,55 @@ __global__ void __launch_bounds__(256) attn_varlen_kernel(const kr_bf16* __restr
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
             }
         }
-        // ---- mask, online softmax (lane = query; rows = keys)
+        // ---- mask, online softmax (lane = query; rows = keys).  The softmax is the VALU-bound part of this
+        // kernel (PMC: vector ALU ~70 % busy, MFMA 22 %), so: masks only on tiles that need one (wave-uniform
+        // test), the scale folded into one fma per score, P converted to bf16 pairwise, and a LAZY running max:
+        // O and l are rescaled only when some query's max grew by more than 2^8 since its last rescale — the
+        // numerator and the denominator keep using the same (stale) reference, so the quotient is unchanged and
+        // bf16(P) keeps its relative precision at values up to 256.
+        bool need_mask = t * 64 + 64 > kv_len_seg;
+        if (CAUSAL) need_mask |= t * 64 + 63 > q_pos0 + wave * 32;
+        if (need_mask) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const bool ok = key < kv_len_seg && (!CAUSAL || key <= qpos);
+                    s[sub][r] = ok ? s[sub][r] : -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = key < kv_len_seg && (!CAUSAL || key <= qpos);
-                const float v = ok ? s[sub][r] * scale_log2e : -INFINITY;
-                s[sub][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__any(m_new - m_run > 8.0f)) {  // first tile (m_run = -1e30), then rarely
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
         float psum = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
-                const __bf16 pb = f2bf(p);
-                psum += bf2f(pb);  // normaliser of the bf16 P actually multiplied into V
-                pf[sub][r >> 3][r & 7] = pb;
+            for (int h8 = 0; h8 < 2; ++h8) {
+                f32x8 pv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pv[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][h8 * 8 + j], scale_log2e, -m_run));
+                    psum += pv[j];
+                }
+                pf[sub][h8] = __builtin_convertvector(pv, bf16x8);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        l_run += psum;
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
