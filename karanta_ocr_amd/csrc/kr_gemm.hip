@@ -1,7 +1,8 @@
 // Dense linears on the MI355X matrix cores.
 //
 //  gemm_kernel : C[M,N] = epi(A[M,K] W[N,K]^T + bias) (+R)   M large (ViT, merger, decoder prefill)
-//                128x128x64 block tile, 4 waves (2x2, 64x64 each), v_mfma_f32_16x16x32_bf16,
+//                128x128x64 block tile, 4 waves (2x2, 64x64 each) or 256x256x64, 8 waves (2x4, 128x64 each),
+//                v_mfma_f32_16x16x32_bf16,
 //                both operands K-contiguous, staged HBM->LDS with 16-byte LDS-DMA
 //                (global_load_lds_dwordx4) into an XOR-swizzled image (swizzle applied on the
 //                per-lane SOURCE address, linear LDS destination), double buffered.
@@ -16,86 +17,96 @@
 // =====================================================================================
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
+// Tile geometries.  G128: 128x128 block, 4 waves (2x2) of 64x64 — 2-3 workgroups per CU hide the staging
+// latency of each other; the shape for small / ragged M.  G256: 256x256 block, 8 waves (2x4) of 128x64 — half the
+// LDS-DMA traffic and a quarter of the barriers per flop, 0.375 instead of 0.5 LDS fragment reads per MFMA, one
+// workgroup per CU (128 KiB of LDS, 128 accumulator registers); for the large-M GEMMs of the ViT and the prefill.
+struct G128 { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
+struct G256 { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4; };
 
 // LDS image of a [128 rows][64 k] bf16 tile: 128-byte rows of eight 16-byte chunks; chunk c of
 // row r is stored at chunk position c ^ ((r >> 1) & 7): conflict-free for the ds_read_b128
 // fragment reads below (16 distinct rows x 4 k-chunks per instruction).
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-// Stage one [128][64] tile (rows row0.., k k0..) of a row-major [rows_total][ld] matrix.
+// Stage one [ROWS][64] tile (rows row0.., k k0..) of a row-major [rows_total][ld] matrix.
 // Each wave-instruction writes 1 KiB contiguous LDS (= 8 tile rows).
 // PACKED: the matrix is stored in the decode layout [rows/16][ld/32][4][16][8] (one MFMA fragment
 // block = 1 KiB, see kr_decode.hip): chunk c (8 k) of row r lives at block (r/16, k/32), group
 // (k%32)/8, row r%16 — a wave-instruction still fetches eight 128-byte segments.
-template <bool PACKED>
+template <bool PACKED, int ROWS, int NTHR>
 __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_total,
                                            int k0, char* lds_tile, int tid, int wave) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int idx = p * 256 + tid;  // chunk index inside the tile image
+    for (int p = 0; p < ROWS * 8 / NTHR; ++p) {
+        const int idx = p * NTHR + tid;  // chunk index inside the tile image
         const int r = idx >> 3, cp = idx & 7;
         const int c = cp ^ ((r >> 1) & 7);  // which global chunk lands at this LDS position
         int64_t gr = row0 + r;
         gr = gr < rows_total ? gr : rows_total - 1;
         const kr_bf16* src = PACKED ? g + ((((gr >> 4) * (ld >> 5) + (k0 >> 5) + (c >> 2)) * 4 + (c & 3)) * 16 + (gr & 15)) * 8
                                     : g + gr * ld + k0 + c * 8;
-        char* dst = lds_tile + (p * 256 + wave * 64) * 16;  // wave-uniform; hardware adds lane*16
+        char* dst = lds_tile + (p * NTHR + wave * 64) * 16;  // wave-uniform; hardware adds lane*16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 }
 
-template <int EPI, bool WPACK>
-__global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
+template <int EPI, bool WPACK, typename G>
+__global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
                                                    const kr_bf16* __restrict__ W, const kr_bf16* __restrict__ bias,
                                                    const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C,
                                                    int64_t ldc, int64_t M, int N, int K, int tiles_n, unsigned nwg) {
+    constexpr int BM = G::BM, BN = G::BN, NTHR = G::WM * G::WN * 64;
+    constexpr int WTM = BM / G::WM, WTN = BN / G::WN;  // wave tile
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile, W tile)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / G::WN, wc = wave % G::WN;
 
     const unsigned wg = xcd_remap(blockIdx.x, nwg);
     const int64_t m0 = (int64_t)(wg / tiles_n) * BM;
     const int n0 = (int)(wg % tiles_n) * BN;
 
-    f32x4 acc[4][4];  // [nt][mt]: rows (regs) = n, col (lane&15) = m
+    f32x4 acc[NT][MT];  // [nt][mt]: rows (regs) = n, col (lane&15) = m
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    stage_tile<false>(A, lda, m0, M, 0, smem, tid, wave);
-    stage_tile<WPACK>(W, K, n0, N, 0, smem + TILE_BYTES, tid, wave);
+    stage_tile<false, BM, NTHR>(A, lda, m0, M, 0, smem, tid, wave);
+    stage_tile<WPACK, BN, NTHR>(W, K, n0, N, 0, smem + A_BYTES, tid, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+        char* cur = smem + (kt & 1) * STAGE;
         if (kt + 1 < nk) {
-            char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile<false>(A, lda, m0, M, (kt + 1) * BK, nxt, tid, wave);
-            stage_tile<WPACK>(W, K, n0, N, (kt + 1) * BK, nxt + TILE_BYTES, tid, wave);
+            char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            stage_tile<false, BM, NTHR>(A, lda, m0, M, (kt + 1) * BK, nxt, tid, wave);
+            stage_tile<WPACK, BN, NTHR>(W, K, n0, N, (kt + 1) * BK, nxt + A_BYTES, tid, wave);
         }
         const char* At = cur;
-        const char* Wt = cur + TILE_BYTES;
+        const char* Wt = cur + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xa[4], wb[4];
+            bf16x8 xa[MT], wb[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xa[t] = *reinterpret_cast<const bf16x8*>(At + lds_off(wr * 64 + t * 16 + fr, ks * 4 + fg));
-                wb[t] = *reinterpret_cast<const bf16x8*>(Wt + lds_off(wc * 64 + t * 16 + fr, ks * 4 + fg));
-            }
+            for (int t = 0; t < NT; ++t)
+                wb[t] = *reinterpret_cast<const bf16x8*>(Wt + lds_off(wc * WTN + t * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < MT; ++t)
+                xa[t] = *reinterpret_cast<const bf16x8*>(At + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fg));
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][mt], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -104,18 +115,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
 
     // ---------------- epilogue: lane holds 4 consecutive n for one m
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int64_t m = m0 + wr * 64 + mt * 16 + fr;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = m0 + wr * WTM + mt * 16 + fr;
         if (EPI != KR_EPI_SILU_MUL8 && m >= M) continue;  // (SILU_MUL8 shuffles across lanes: no early exit)
         if (EPI == KR_EPI_SILU_MUL8) {
             // gate/up interleaved in groups of 8 rows: a 16-row tile holds gate rows in lane groups 0,1
             // and the matching up rows in lane groups 2,3 (lane ^ 32)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 float u[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(acc[nt][mt][j], 32, 64);
-                const int n = n0 + wc * 64 + nt * 16;
+                const int n = n0 + wc * WTN + nt * 16;
                 if (fg < 2 && n < N && m < M) {
                     bf16x4 o;
 #pragma unroll
@@ -125,10 +136,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
             }
         } else if (EPI == KR_EPI_SILU_MUL) {
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int n = n0 + wc * 64 + pr * 32 + fg * 4;  // gate row index in W'
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                const int n = n0 + wc * WTN + pr * 32 + fg * 4;  // gate row index in W'
                 if (n >= N) continue;
-                const int oc = ((n0 + wc * 64) >> 1) + pr * 16 + fg * 4;
+                const int oc = ((n0 + wc * WTN) >> 1) + pr * 16 + fg * 4;
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[2 * pr][mt][j]) * acc[2 * pr + 1][mt][j]);
@@ -136,8 +147,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
             }
         } else {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wc * 64 + nt * 16 + fg * 4;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + wc * WTN + nt * 16 + fg * 4;
                 if (n >= N) continue;
                 float v[4];
 #pragma unroll
@@ -168,23 +179,43 @@ __global__ void __launch_bounds__(256) gemm_kernel(const kr_bf16* __restrict__ A
     }
 }
 
-template <int EPI, bool WPACK>
-int launch_gemm2(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+template <int EPI, bool WPACK, typename G>
+int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
                  kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
-    const int64_t tiles_m = (M + BM - 1) / BM;
-    const int tiles_n = (N + BN - 1) / BN;
+    constexpr int LDS = 2 * (G::BM + G::BN) * BK * 2;
+    const int64_t tiles_m = (M + G::BM - 1) / G::BM;
+    const int tiles_n = (N + G::BN - 1) / G::BN;
     const int64_t nwg = tiles_m * tiles_n;
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK, G>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    gemm_kernel<EPI, WPACK><<<(unsigned)nwg, 256, 4 * TILE_BYTES, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
-                                                                              tiles_n, (unsigned)nwg);
+    gemm_kernel<EPI, WPACK, G><<<(unsigned)nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
+                                                                                      tiles_n, (unsigned)nwg);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+// 0 = automatic, 128 / 256 = forced (KARANTA_GEMM_TILE, tuning sweeps)
+inline int gemm_tile_choice(int64_t M, int N, int K) {
+    const char* env = getenv("KARANTA_GEMM_TILE");  // read per call: the tests flip it between launches
+    const int forced = env ? atoi(env) : 0;
+    if (forced == 128 || forced == 256) return forced;
+    // the 256x256 tile needs enough workgroups to fill 256 CUs a few times over, no N padding, and either several
+    // N tiles or a long K (measured on the ViT / prefill shapes, gemm_microbench.py: +10-20 % there, -3 % on
+    // N = 1280, K = 1280)
+    const int64_t wgs = ((M + 255) / 256) * ((N + 255) / 256);
+    return (wgs >= 512 && N % 256 == 0 && (N >= 2048 || K >= 4096)) ? 256 : 128;
+}
+
+template <int EPI, bool WPACK>
+int launch_gemm2(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                 kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
+    if (gemm_tile_choice(M, N, K) == 256) return launch_gemm3<EPI, WPACK, G256>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
+    return launch_gemm3<EPI, WPACK, G128>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
 }
 
 template <int EPI>

@@ -1,0 +1,45 @@
+"""Times kr_gemm_bf16 on the ViT / prefill shapes of the bench workload with both tile geometries.
+Run on the GPU box: python karanta_ocr_amd/csrc/tools/gemm_microbench.py"""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from karanta_ocr_amd._lib import EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8, lib, ptr  # noqa: E402
+
+L = lib()
+dev = "cuda:0"
+st = torch.cuda.Stream()
+S = st.cuda_stream
+SHAPES = [("vit qkv", 39200, 3840, 1280, EPI_NONE, 0), ("vit proj", 39200, 1280, 1280, EPI_NONE, 0),
+          ("vit fc1", 39200, 5120, 1280, EPI_QUICK_GELU, 0), ("vit fc2", 39200, 1280, 5120, EPI_NONE, 0),
+          ("merger fc1", 9800, 5120, 5120, EPI_NONE, 0), ("merger fc2", 9800, 1536, 5120, EPI_NONE, 0),
+          ("prefill qkv", 11152, 2048, 1536, EPI_NONE, 1), ("prefill o", 11152, 1536, 1536, EPI_NONE, 1),
+          ("prefill gate_up", 11152, 17920, 1536, EPI_SILU_MUL8, 1), ("prefill down", 11152, 1536, 8960, EPI_NONE, 1)]
+
+
+def run(name, M, N, K, epi, packed, reps=5):
+    a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+    w = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()   # timing only: the packed layout has the same footprint
+    nc = N // 2 if epi == EPI_SILU_MUL8 else N
+    c = torch.empty(M, nc, device=dev, dtype=torch.bfloat16)
+    bias = torch.zeros(N, device=dev, dtype=torch.bfloat16)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
+    out = {}
+    for tile in (128, 256):
+        os.environ["KARANTA_GEMM_TILE"] = str(tile)
+        call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
+        call(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            L.kr_event_record(e0, S); call(); L.kr_event_record(e1, S); L.kr_event_synchronize(e1)
+            ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms)); best = min(best, ms.value)
+        out[tile] = best
+    fl = 2.0 * M * N * K
+    print(f"{name:16s} M={M:6d} N={N:6d} K={K:5d}: 128-tile {out[128]*1e3:8.1f} us {fl/out[128]/1e9:7.0f} TF/s | "
+          f"256-tile {out[256]*1e3:8.1f} us {fl/out[256]/1e9:7.0f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    torch.zeros(1, device=dev)
+    for sh in SHAPES:
+        run(*sh)

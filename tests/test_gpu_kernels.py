@@ -207,6 +207,47 @@ def test_gemm_exact_on_integers(L, M, N, K):
     np.testing.assert_array_equal(got, ref_linear(A, W))
 
 
+@pytest.fixture
+def tile256():
+    """Force the 256x256 / 8-wave GEMM geometry (chosen automatically only for very large M)."""
+    import os
+    os.environ["KARANTA_GEMM_TILE"] = "256"
+    yield
+    os.environ.pop("KARANTA_GEMM_TILE", None)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (255, 256, 64), (256, 256, 128), (257, 272, 192), (700, 528, 64),
+                                   (513, 1280, 1216)])
+def test_gemm_256_tile_exact_on_integers(L, tile256, M, N, K):
+    rng = np.random.default_rng(M * 1000 + N + K + 1)
+    A, W = ints(rng, M, K), ints(rng, N, K)
+    if K > 256:
+        W[:, 200:] = 0
+    np.testing.assert_array_equal(run_gemm(L, A, W), ref_linear(A, W))
+    np.testing.assert_array_equal(run_gemm(L, A, W, packed=True), ref_linear(A, W))
+
+
+@pytest.mark.parametrize("epi", [EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF])
+def test_gemm_256_tile_epilogues(L, tile256, epi):
+    rng = np.random.default_rng(77 + epi)
+    M, N, K = 300, 528, 128
+    A, W, bias, res = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N, scale=0.1), rnd(rng, M, N)
+    assert_close_bf16(run_gemm(L, A, W, bias, res, epi), ref_linear(A, W, bias, res, epi), what=f"256-tile epi {epi}")
+    # asymmetric operands: a transposed fragment map cannot hide
+    A2 = np.zeros((M, K), np.float32); A2[np.arange(M), np.arange(M) % K] = 1.0
+    W2 = (np.arange(N * K).reshape(N, K) % 7 - 3).astype(np.float32)
+    np.testing.assert_array_equal(run_gemm(L, A2, W2), ref_linear(A2, W2))
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_256_tile_silu_mul8(L, tile256, packed):
+    rng = np.random.default_rng(78)
+    M, ff, K = 270, 8 * 70, 128
+    A, W = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5)
+    assert_close_bf16(run_gemm(L, A, W, epi=EPI_SILU_MUL8, packed=packed), ref_linear(A, W, epi=EPI_SILU_MUL8),
+                      what="256-tile silu8")
+
+
 def test_gemm_asymmetric_operands_catch_transposes(L):
     M, N, K = 128, 128, 64
     A = np.zeros((M, K), np.float32); A[np.arange(64), np.arange(64)] = 1  # rows 0..63 = identity on K
