@@ -286,7 +286,10 @@ int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int he
 
 /* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out[b] and
  * history[(ctx_len[b] + 1 - prompt_len[b]) * hist_stride + b] (= this sequence's generated-token
- * index), EOS / pad handling as kr_argmax_embed, ctx_len[b] += 1, embedding gather into x_next. */
+ * index), EOS / pad handling as kr_argmax_embed, ctx_len[b] += 1, embedding gather into x_next.
+ * ignore_eos is a bit set: bit 0 = ignore EOS (fixed-length benchmarking), bit 1 = a finished sequence is
+ * frozen (no history write, ctx_len not advanced; the pad token is still fed back) — the slot scheduler's mode:
+ * a finished slot idles in place until the host prefills a new request into it. */
 int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part,
                      const kr_bf16* embed_table, int d, int32_t* tokens_out, int32_t* history,
                      int hist_stride, const int32_t* prompt_len, int32_t* ctx_len, int32_t* finished,

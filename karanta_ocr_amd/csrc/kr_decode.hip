@@ -1279,9 +1279,18 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
     for (int w = 1; w < 4; ++w) better(bv, bi, s_v[w], s_i[w]);
     int tok = bi;
     const int was_finished = finished[b];
+    const bool freeze = (ignore_eos & 2) != 0;  // bit 1: a finished sequence stops advancing (slot scheduler)
+    ignore_eos &= 1;
     if (was_finished && !ignore_eos) tok = pad_id;
     const int new_ctx = ctx_len[b] + 1;  // tokens cached once the sampled token has been fed back
     __syncthreads();
+    if (freeze && was_finished && !ignore_eos) {
+        // the slot idles at its last position (its KV row is rewritten in place, its history stays as it is)
+        // until the host admits a new request into it
+        if (tid == 0) tokens_out[b] = tok;
+        for (int c = tid; c < (d >> 3); c += 256) st8(x_next + (int64_t)b * d + c * 8, ld8(table + (int64_t)tok * d + c * 8));
+        return;
+    }
     if (tid == 0) {
         tokens_out[b] = tok;
         history[(int64_t)(new_ctx - prompt_len[b]) * hist_stride + b] = tok;  // generated-token index of this sequence

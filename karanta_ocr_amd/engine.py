@@ -185,6 +185,7 @@ class Engine:
         self.max_patches = max_patches
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
+        self._ignore_eos = self._freeze_finished = self._want_logits = False
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
         self._prefetch_mode = int(os.environ.get("KARANTA_PREFETCH", "0"))
@@ -411,12 +412,19 @@ class Engine:
         return self.img_embeds[:T]
 
     # ------------------------------------------------------------------ prefill
-    def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int) -> List[int]:
+    def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int,
+                slots: Optional[Sequence[int]] = None) -> List[int]:
         """embed+scatter, M-RoPE, 28 x decoder layer over the flattened prompts (causal varlen
         attention writing the KV cache), last-token logits -> first greedy token.
-        Leaves the decode state (d_x, d_ctx, d_delta, history row 0) ready.  Returns prompt lengths."""
+        Leaves the decode state (d_x, d_ctx, d_delta, history row 0) ready.  Returns prompt lengths.
+        ``slots`` (slot scheduler): the cache / state slots the pages go to; only those slots' state is
+        touched, the other sequences keep decoding from where they are."""
         cfg, t, L, s, w, dev = self.cfg, self.cfg.text, self.L, self.s, self.w, self.device
         B = len(pages)
+        whole_batch = slots is None
+        slots = list(range(B)) if whole_batch else [int(j) for j in slots]
+        if len(slots) != B or len(set(slots)) != B or min(slots) < 0 or max(slots) >= self.B:
+            raise KarantaHipError(f"slots {slots} do not name {B} distinct slots below {self.B}")
         lens = [int(len(p.input_ids)) for p in pages]
         M = sum(lens)
         if M > self.max_tokens:
@@ -446,30 +454,38 @@ class Engine:
         if img_off != n_image_tokens_total:
             raise KarantaHipError(f"Image features and image tokens do not match, tokens: {img_off}, "
                                   f"features: {n_image_tokens_total}")
-        plan = POS.prefill_attn_plan(lens, list(range(B)), t.num_kv_heads, self.s_max)
+        plan = POS.prefill_attn_plan(lens, slots, t.num_kv_heads, self.s_max)
         last_rows = (np.cumsum(lens) - 1).astype(np.int32)
-        ctx0 = np.zeros(self.B, np.int32)
-        ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_sample_greedy adds 1 -> number of cached tokens
         with torch.cuda.stream(self.stream):
             self._h2d(self.p_src, src)
             self._h2d(self.p_cos, cos)
             self._h2d(self.p_sin, sin)
-            self._h2d(self.d_delta, deltas)
-            self._h2d(self.d_ctx, ctx0)
-            plen = np.zeros(self.B, np.int32)
-            plen[:B] = lens
-            self._h2d(self.d_plen, plen)
             # rotary table of every decode position of every sequence: pos = P + k + delta (all three
             # M-RoPE axes equal for generated text, TF:1124-1136), cos/sin rounded to bf16 (TF:169)
             kk = np.arange(self.max_new, dtype=np.int64)
-            cs = np.zeros((self.B, self.max_new, t.head_dim), np.float32)
+            cs = np.zeros((B, self.max_new, t.head_dim), np.float32)
             for b in range(B):
                 p1 = lens[b] + kk + int(deltas[b])
                 c_, s_ = POS.mrope_tables(np.stack([p1, p1, p1]), t.head_dim, t.rope_theta, t.mrope_section)
                 cs[b, :, : t.head_dim // 2], cs[b, :, t.head_dim // 2:] = c_[:, : t.head_dim // 2], s_[:, : t.head_dim // 2]
-            self._h2d(self.d_cs, cs)
+            if whole_batch:
+                ctx0 = np.zeros(self.B, np.int32)
+                ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_sample_greedy adds 1 -> number of cached tokens
+                plen = np.zeros(self.B, np.int32)
+                plen[:B] = lens
+                self._h2d(self.d_delta, deltas)
+                self._h2d(self.d_ctx, ctx0)
+                self._h2d(self.d_plen, plen)
+                self._h2d(self.d_cs, cs)
+                self.d_fin.zero_()
+            else:
+                for b, j in enumerate(slots):
+                    self._h2d(self.d_delta[j:j + 1], deltas[b:b + 1])
+                    self._h2d(self.d_ctx[j:j + 1], np.asarray([lens[b] - 1], np.int32))
+                    self._h2d(self.d_plen[j:j + 1], np.asarray([lens[b]], np.int32))
+                    self._h2d(self.d_cs[j], cs[b])
+                    self.d_fin[j:j + 1].zero_()
             self._h2d(self.d_last, last_rows)
-            self.d_fin.zero_()
             t_ = lambda a: torch.from_numpy(a).to(dev)
             blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
             qblk, qlen = t_(plan.qblk), t_(plan.qblk_len)
@@ -494,27 +510,34 @@ class Engine:
                 self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL8, packed=True)
                 self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x, packed=True)
             # last position of every sequence -> final norm (fused) -> lm_head -> greedy token
-            L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)
-            self._lm_head_and_sample(B)
+            if whole_batch:
+                L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)
+                self._lm_head_and_sample(B)
+            else:
+                for b, j in enumerate(slots):
+                    L.kr_embed_scatter(ptr(self.d_last[b:]), ptr(self.p_x), 0, ptr(self.d_x[j:]), 1, d, s)
+                    self._lm_head_and_sample(1, slot0=j)
         return lens
 
-    def _lm_head_and_sample(self, B: int, x=None):
+    def _lm_head_and_sample(self, B: int, x=None, slot0: int = 0):
         """final RMSNorm (fused) -> lm_head with per-workgroup argmax partials -> greedy token,
         bookkeeping and the next step's rotary table (TF:839, :1320-1323; generate(do_sample=False)).
         x = the residual buffer holding the last layer's output (d_x unless the decode step ended on the
         other buffer); the next step's input embedding always goes to d_x."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         x = self.d_x if x is None else x
+        j = slot0  # rows j .. j+B-1 of every per-sequence array (the slot scheduler prefills single slots)
+        logits = self.d_logits[j:] if self._want_logits else None
         if self.wide_mode:
-            self._dec_wide(DEC_ARGMAX, x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
-                           out_f32=self.d_logits if self._want_logits else None)
+            self._dec_wide(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits)
         else:
-            self._dec(DEC_ARGMAX, x, w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"),
-                      out_f32=self.d_logits if self._want_logits else None, waves=self.wv_wide)
+            self._dec(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits,
+                      waves=self.wv_wide)
+        flags = (1 if self._ignore_eos else 0) | (2 if self._freeze_finished else 0)
         L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
-                           ptr(self.d_tok), ptr(self.d_hist), self.d_hist.stride(0), ptr(self.d_plen), ptr(self.d_ctx),
-                           ptr(self.d_fin), ptr(self.d_eos), self.d_eos.numel(), self.cfg.pad_token_id,
-                           1 if self._ignore_eos else 0, ptr(self.d_x), B, s)
+                           ptr(self.d_tok[j:]), ptr(self.d_hist[:, j:]), self.d_hist.stride(0), ptr(self.d_plen[j:]),
+                           ptr(self.d_ctx[j:]), ptr(self.d_fin[j:]), ptr(self.d_eos), self.d_eos.numel(),
+                           self.cfg.pad_token_id, flags, ptr(self.d_x[j:]), B, s)
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
@@ -665,7 +688,7 @@ class Engine:
         return {"launches": n, "avg_us": ms.value * 1e3 / n, "bytes_per_launch": nbytes}
 
     def _graph_for(self, B: int) -> int:
-        key = (B, self._ignore_eos)
+        key = (B, self._ignore_eos, self._freeze_finished)
         assert not self._want_logits
         g = self._graphs.get(key)
         if g is None:
@@ -697,6 +720,7 @@ class Engine:
             raise ValueError("max_new_tokens must be >= 1")
         t0 = time.perf_counter()
         self._ignore_eos = bool(ignore_eos)
+        self._freeze_finished = False
         self._want_logits = bool(return_logits)
         self._last_batch = B
         if self.d_hist is None or self.max_new < max_new_tokens:
@@ -727,7 +751,7 @@ class Engine:
         steps_done = 1
         with torch.cuda.stream(self.stream):
             want_graph = use_graph and not return_logits
-            graph = self._graphs.get((B, self._ignore_eos)) if want_graph else None
+            graph = self._graphs.get((B, self._ignore_eos, False)) if want_graph else None
             while steps_done < max_new_tokens:
                 if graph is not None and profile_every and steps_done % profile_every == 0:
                     self._prof_on = True
@@ -768,6 +792,64 @@ class Engine:
             timings={"vit_s": t1 - t0, "prefill_s": t2 - t1, "decode_s": t3 - t2, "total_s": t3 - t0,
                      "decode_steps": steps_done - 1},
             logits=np.stack(logits_steps, 1) if return_logits else None)
+
+    # ------------------------------------------------------------------ slot scheduler API (continuous batching)
+    # The decode graph always runs all `max_batch` slots; a slot whose sequence has finished idles in place
+    # (kr_sample_greedy freeze bit) until `admit` prefills a new request into it.  See scheduler.SlotScheduler.
+    def begin_slots(self, max_new_tokens: int):
+        """Enter slot mode: every slot idle, per-slot history / rotary tables sized for `max_new_tokens`."""
+        if max_new_tokens < 1:
+            raise ValueError("max_new_tokens must be >= 1")
+        self._ignore_eos, self._freeze_finished, self._want_logits = False, True, False
+        self._last_batch = self.B
+        if self.d_hist is None or self.max_new < max_new_tokens:
+            self.max_new = max_new_tokens
+            self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
+            self.d_cs = torch.zeros(self.B, max_new_tokens, self.cfg.text.head_dim, dtype=torch.float32, device=self.device)
+            for g in self._graphs.values():
+                self.L.kr_graph_destroy(g)
+            self._graphs.clear()
+        with torch.cuda.stream(self.stream):
+            self.d_fin.fill_(1)
+            self.d_ctx.zero_()
+            self.d_plen.zero_()
+            self.d_x.zero_()
+        self.stream.synchronize()
+
+    def admit(self, pages: Sequence[PageRequest], slots: Sequence[int]) -> List[int]:
+        """ViT + prefill of new requests into idle slots; their first token is sampled.  Returns prompt lengths."""
+        grids = [g for p in pages for g in p.grids]
+        pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
+        n_img_tok = 0
+        if pvs:
+            n_img_tok = self.vit_forward(np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0], grids).shape[0]
+        return self.prefill(pages, n_img_tok, slots=slots)
+
+    def decode_steps(self, n: int):
+        """n decode steps over all slots (asynchronous on the engine's stream)."""
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                graph = self._graphs.get((self.B, False, True))
+                if graph is not None:
+                    self.L.kr_graph_launch(graph, self.s)
+                else:  # first step eager (kernel attributes), then captured
+                    self._decode_step_launches(self.B)
+                    self._graph_for(self.B)
+
+    def poll_slots(self):
+        """(finished[B], generated[B]): device EOS flags and tokens generated so far per slot (synchronises)."""
+        self.stream.synchronize()
+        fin = self.d_fin.cpu().numpy().astype(bool)
+        gen = (self.d_ctx.cpu().numpy() + 1 - self.d_plen.cpu().numpy()).astype(np.int64)
+        return fin, gen
+
+    def slot_tokens(self, slot: int, n: int) -> np.ndarray:
+        return self.d_hist[:n, slot].cpu().numpy().astype(np.int64)
+
+    def retire(self, slot: int):
+        """Host-side stop (length limit): the slot idles from the next step on."""
+        with torch.cuda.stream(self.stream):
+            self.d_fin[slot:slot + 1].fill_(1)
 
     def close(self):
         for g in self._graphs.values():

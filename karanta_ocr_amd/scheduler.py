@@ -1,0 +1,158 @@
+"""Continuous batching over the engine's fixed decode slots.
+
+The reference leaves scheduling to vLLM (one server per GPU, `scripts/start_multiple_vllm_servers.sh:283`; the
+pipeline only watches its `Running: n reqs, Waiting: m reqs` lines, `karanta/pipeline.py:769-800`).  Here the decode
+hipGraph always steps all `max_batch` slots; a sequence that hits EOS (device flag) or its `max_tokens` (host) frees
+its slot, and the next waiting request is prefilled into that slot while the other sequences keep their state —
+instead of the whole batch waiting for its longest member (`Engine.generate`, static batching).
+
+Only the host logic lives here; it drives `Engine.begin_slots / admit / decode_steps / poll_slots / slot_tokens /
+retire`, and any object with those six methods (the CPU tests use a fake) can stand in for the engine.
+"""
+from __future__ import annotations
+
+import collections
+from dataclasses import dataclass
+from typing import Any, Deque, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class SlotRequest:
+    page: Any                 # engine.PageRequest
+    max_tokens: int
+    tag: Any = None           # returned untouched with the result
+
+
+@dataclass
+class SlotResult:
+    tag: Any
+    tokens: np.ndarray        # generated ids, EOS included when finish_reason == "stop"
+    finish_reason: str        # "stop" | "length"
+    prompt_tokens: int
+    error: Optional[str] = None
+    request: Optional[SlotRequest] = None   # the request this answers
+
+
+class SlotScheduler:
+    """`submit()` requests, call `step()` until `idle`; every step admits what fits, runs `chunk` decode steps and
+    returns the requests that finished."""
+
+    def __init__(self, engine, max_tokens_cap: int, chunk: int = 16, eos_token_ids: Optional[Sequence[int]] = None,
+                 max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None):
+        if max_tokens_cap < 1 or chunk < 1:
+            raise ValueError("max_tokens_cap and chunk must be >= 1")
+        self.engine = engine
+        self.n_slots = int(engine.B)
+        self.cap, self.chunk = int(max_tokens_cap), int(chunk)
+        self.eos = set(int(e) for e in (eos_token_ids if eos_token_ids is not None else engine.cfg.eos_token_ids))
+        self.max_prompt_tokens = max_prompt_tokens if max_prompt_tokens is not None else getattr(engine, "max_tokens", None)
+        self.max_patches = max_patches if max_patches is not None else getattr(engine, "max_patches", None)
+        self.waiting: Deque[SlotRequest] = collections.deque()
+        self.active: Dict[int, SlotRequest] = {}     # slot -> request
+        self.prompt_len: Dict[int, int] = {}
+        self.steps = 0                               # decode steps run
+        self.slot_steps_busy = 0                     # sum over steps of occupied slots (utilisation numerator)
+        # a slot may run up to chunk - 1 steps past its limit before the host looks: size the history for that
+        engine.begin_slots(self.cap + self.chunk)
+
+    # ------------------------------------------------------------------ public
+    def submit(self, req: SlotRequest) -> None:
+        if req.max_tokens < 1:
+            raise ValueError("max_tokens must be >= 1")
+        self.waiting.append(req)
+
+    @property
+    def idle(self) -> bool:
+        return not self.waiting and not self.active
+
+    @property
+    def running(self) -> int:
+        return len(self.active)
+
+    def step(self) -> List[SlotResult]:
+        done: List[SlotResult] = self._admit()
+        if self.active:
+            self.engine.decode_steps(self.chunk)
+            self.steps += self.chunk
+            self.slot_steps_busy += self.chunk * len(self.active)
+            done += self._harvest()
+        return done
+
+    def run(self, requests: Iterable[SlotRequest]) -> List[SlotResult]:
+        """All requests to completion; results in submission order."""
+        reqs = list(requests)
+        order = {id(r): i for i, r in enumerate(reqs)}
+        for r in reqs:
+            self.submit(r)
+        out: List[Optional[SlotResult]] = [None] * len(reqs)
+        left = len(reqs)
+        while left:
+            for res in self.step():
+                i = order.get(id(res.request))
+                if i is not None and out[i] is None:
+                    out[i] = res
+                    left -= 1
+        return out  # type: ignore[return-value]
+
+    # ------------------------------------------------------------------ internals
+    def _admit(self) -> List[SlotResult]:
+        free = [j for j in range(self.n_slots) if j not in self.active]
+        batch: List[SlotRequest] = []
+        tok_budget = self.max_prompt_tokens
+        patch_budget = self.max_patches
+        failed: List[SlotResult] = []
+        while self.waiting and len(batch) < len(free):
+            r = self.waiting[0]
+            n_tok = int(len(r.page.input_ids))
+            n_patch = int(len(r.page.pixel_values)) if getattr(r.page, "pixel_values", None) is not None else 0
+            over_tok = tok_budget is not None and n_tok > tok_budget
+            over_patch = patch_budget is not None and n_patch > patch_budget
+            if over_tok or over_patch:
+                if not batch and (self.max_prompt_tokens is not None and n_tok > self.max_prompt_tokens
+                                  or self.max_patches is not None and n_patch > self.max_patches):
+                    # can never fit: fail it instead of blocking the queue
+                    self.waiting.popleft()
+                    failed.append(self._failure(r, f"request does not fit the engine ({n_tok} prompt tokens, {n_patch} patches)"))
+                    continue
+                break  # fits an emptier admission round
+            self.waiting.popleft()
+            batch.append(r)
+            if tok_budget is not None:
+                tok_budget -= n_tok
+            if patch_budget is not None:
+                patch_budget -= n_patch
+        if batch:
+            slots = free[:len(batch)]
+            try:
+                lens = self.engine.admit([r.page for r in batch], slots)
+            except Exception as e:  # the admission as a whole failed: none of these requests entered a slot
+                return failed + [self._failure(r, f"{type(e).__name__}: {e}") for r in batch]
+            for r, j, n in zip(batch, slots, lens):
+                self.active[j] = r
+                self.prompt_len[j] = int(n)
+        return failed
+
+    def _failure(self, r: SlotRequest, msg: str) -> SlotResult:
+        return SlotResult(r.tag, np.zeros(0, np.int64), "length", 0, error=msg, request=r)
+
+    def _harvest(self) -> List[SlotResult]:
+        fin, gen = self.engine.poll_slots()
+        out: List[SlotResult] = []
+        for j in sorted(self.active):
+            r = self.active[j]
+            limit = min(int(r.max_tokens), self.cap)
+            if not (fin[j] or gen[j] >= limit):
+                continue
+            n = int(min(gen[j], limit))
+            toks = np.asarray(self.engine.slot_tokens(j, n), np.int64)
+            reason = "length"
+            hit = np.flatnonzero(np.isin(toks, list(self.eos))) if self.eos else np.zeros(0, np.int64)
+            if hit.size:
+                toks, reason = toks[: int(hit[0]) + 1], "stop"
+            if not fin[j]:
+                self.engine.retire(j)
+            out.append(SlotResult(r.tag, toks, reason, self.prompt_len.pop(j), request=r))
+            del self.active[j]
+        return out

@@ -150,20 +150,27 @@ class ChatFrontend:
 
 # ----------------------------------------------------------------------------- in-process server
 class LocalServer:
-    """Static-batching scheduler in front of one engine (one GPU).  Thread-safe: callers block in
-    :meth:`chat_completions` while a worker thread groups whatever is waiting (up to the engine's
-    max batch) into one ``generate`` call."""
+    """Scheduler in front of one engine (one GPU).  Thread-safe: callers block in :meth:`chat_completions`
+    while a worker thread runs the engine.
+
+    ``continuous=False``: static batching — whatever is waiting (up to the engine's max batch) goes into one
+    ``generate`` call and leaves together.  ``continuous=True``: the slot scheduler (scheduler.SlotScheduler) —
+    a request leaves as soon as it hits EOS or its ``max_tokens`` and the next waiting request is prefilled into
+    its slot while the others keep decoding; ``max_tokens_cap`` bounds any request's ``max_tokens`` and
+    ``chunk`` is the number of decode steps between two looks at the device's finished flags."""
 
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
-                 batch_wait_s: float = 0.005, log=print):
+                 batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
+                 chunk: int = 16):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
         self.batch_wait_s, self.log = batch_wait_s, log
+        self.continuous, self.max_tokens_cap, self.chunk = bool(continuous), int(max_tokens_cap), int(chunk)
         self._q: "queue.Queue" = queue.Queue()
         self._running = 0
         self._stop = False
         self.pages_done = 0
         self.latencies: List[float] = []
-        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread = threading.Thread(target=self._loop_continuous if self.continuous else self._loop, daemon=True)
         self._thread.start()
         # the reference watches the server's output for one of these lines (pipeline.py:790-800)
         self.log("Starting vLLM API server (karanta MI355X engine)")
@@ -230,13 +237,7 @@ class LocalServer:
                 pages = [PageRequest(s["req"].input_ids, s["req"].pixel_values, s["req"].grids) for s in batch]
                 res = self.engine.generate(pages, max(s["req"].max_tokens for s in batch))
                 for s, toks, reason in zip(batch, res.tokens, res.finish_reasons):
-                    mt = s["req"].max_tokens
-                    if len(toks) > mt:
-                        toks, reason = toks[:mt], "length"
-                    eos = set(int(e) for e in self.engine.cfg.eos_token_ids)
-                    if reason == "stop" and len(toks) and int(toks[-1]) in eos:
-                        toks = toks[:-1]  # the EOS token is not part of the message content
-                    s["tokens"], s["reason"] = toks, reason
+                    self._finish(s, toks, reason)
             except Exception as e:  # engine failure -> 500 for every request of the batch
                 for s in batch:
                     s["error"] = f"{type(e).__name__}: {e}"
@@ -244,6 +245,80 @@ class LocalServer:
             self._running = 0
             for s in batch:
                 s["done"].set()
+
+
+    def _finish(self, s: Dict[str, Any], toks, reason: str):
+        mt = s["req"].max_tokens
+        if len(toks) > mt:
+            toks, reason = toks[:mt], "length"
+        eos = set(int(e) for e in self.engine.cfg.eos_token_ids)
+        if reason == "stop" and len(toks) and int(toks[-1]) in eos:
+            toks = toks[:-1]  # the EOS token is not part of the message content
+        s["tokens"], s["reason"] = toks, reason
+
+    def _loop_continuous(self):
+        from .engine import PageRequest
+        from .scheduler import SlotRequest, SlotScheduler
+
+        try:
+            sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk)
+        except Exception as e:  # cannot enter slot mode: every request gets a 500
+            sch, boot_error = None, f"{type(e).__name__}: {e}"
+        last = (-1, -1)
+        while not self._stop:
+            # block only when there is nothing to decode; otherwise take what has arrived and keep stepping
+            try:
+                first = self._q.get(block=sch is None or sch.idle, timeout=None)
+            except queue.Empty:
+                first = False
+            got = [] if first is False else [first]
+            while True:
+                try:
+                    got.append(self._q.get_nowait())
+                except queue.Empty:
+                    break
+            for s in got:
+                if s is None:
+                    self._stop = True
+                elif sch is None:
+                    s["error"] = boot_error
+                    s["done"].set()
+                else:
+                    r = s["req"]
+                    sch.submit(SlotRequest(PageRequest(r.input_ids, r.pixel_values, r.grids), max(1, int(r.max_tokens)), tag=s))
+            if self._stop or sch is None:
+                continue
+            try:
+                results = sch.step()
+            except Exception as e:  # engine failure mid-flight: everything in a slot or waiting fails, slot mode restarts
+                msg = f"{type(e).__name__}: {e}"
+                for r in list(sch.active.values()) + list(sch.waiting):
+                    r.tag["error"] = msg
+                    r.tag["done"].set()
+                self.pages_done += len(sch.active) + len(sch.waiting)
+                try:
+                    sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk)
+                except Exception as e2:
+                    sch, boot_error = None, f"{type(e2).__name__}: {e2}"
+                continue
+            self._running = sch.running
+            now = (sch.running, len(sch.waiting) + self._q.qsize())
+            if now != last:  # vLLM's stats line, printed when it changes (pipeline.py:782-800 scrapes it)
+                self.log(f"Running: {now[0]} reqs, Waiting: {now[1]} reqs")
+                last = now
+            for res in results:
+                s = res.tag
+                if res.error:
+                    s["error"] = res.error
+                else:
+                    self._finish(s, res.tokens, res.finish_reason)
+                self.pages_done += 1
+                s["done"].set()
+        # shutting down: nobody is left waiting forever
+        if sch is not None:
+            for r in list(sch.active.values()) + list(sch.waiting):
+                r.tag["error"] = "server shutting down"
+                r.tag["done"].set()
 
 
 # registry used by the in-process VLLMClient (clients.py): port -> LocalServer

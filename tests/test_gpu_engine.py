@@ -134,3 +134,81 @@ def test_image_token_mismatch_is_an_error(engines, tiny_models):
     ids = np.asarray([1, cfg.image_token_id, cfg.image_token_id, 2], np.int64)  # needs 4 placeholders
     with pytest.raises(ValueError, match="do not match"):
         eng.generate([PageRequest(ids, pv, [grid])], 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name):
+    """Continuous batching: 7 ragged requests through 3 slots (2 of the engine's 4 stay idle throughout) — every
+    request's tokens equal the ones it gets alone from `generate`, whichever slot it lands in, whatever its slot
+    held before and whatever its neighbours are doing; EOS (made frequent by construction) and length limits both
+    free slots mid-flight."""
+    import dataclasses
+    from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
+    cfg, w, P = tiny_models[name]
+    base = engines[name]
+    rng = np.random.default_rng(123)
+    pages, limits = [], [9, 20, 5, 14, 1, 17, 11]
+    for i, mt in enumerate(limits):
+        h, wd = [(112, 168), (56, 84), (140, 140), (56, 56)][i % 4]
+        pv, grid = IP.image_to_patches(IP.synthetic_page(20 + i, h, wd))
+        T = grid[1] * grid[2] // 4
+        ids = np.concatenate([rng.integers(0, 400, 2 + i), [cfg.vision_start_token_id], [cfg.image_token_id] * T,
+                              [cfg.vision_end_token_id], rng.integers(0, 400, 3)]).astype(np.int64)
+        pages.append(PageRequest(ids, pv, [grid]))
+    free = [base.generate([pg], 20, ignore_eos=True).tokens[0] for pg in pages]
+    # an EOS set that some of the free-running sequences hit early, some late, some never
+    eos = (int(free[0][4]), int(free[3][9]), int(free[5][2]))
+    cfg2 = dataclasses.replace(cfg, eos_token_ids=eos)
+    eng = Engine(cfg2, max_batch=3, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2)
+    eng.load_weights(w)
+    solo = [eng.generate([pg], mt) for pg, mt in zip(pages, limits)]
+    sch = SlotScheduler(eng, max_tokens_cap=20, chunk=3)
+    res = sch.run([SlotRequest(pg, mt, tag=i) for i, (pg, mt) in enumerate(zip(pages, limits))])
+    assert [r.tag for r in res] == list(range(len(pages)))
+    reasons = set()
+    for r, s, pg in zip(res, solo, pages):
+        assert r.error is None and r.prompt_tokens == len(pg.input_ids)
+        np.testing.assert_array_equal(r.tokens, s.tokens[0])
+        assert r.finish_reason == s.finish_reasons[0]
+        reasons.add(r.finish_reason)
+    assert reasons == {"stop", "length"}, "the construction should exercise both ways out of a slot"
+    assert sch.steps > 0 and sch.slot_steps_busy <= sch.steps * 3
+    # static generate() still works on the same engine afterwards (leaves slot mode)
+    again = eng.generate([pages[1]], limits[1])
+    np.testing.assert_array_equal(again.tokens[0], solo[1].tokens[0])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_server_continuous_mode_end_to_end(engines, tiny_models):
+    """OpenAI-shaped requests through LocalServer(continuous=True) on the real engine: concurrent callers, ragged
+    images and limits; every completion equals the one the static server gives for the same request."""
+    import threading
+    from karanta_ocr_amd import serving as S
+    cfg, w, P = tiny_models["tiny"]
+    eng = Engine(cfg, max_batch=2, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2)
+    eng.load_weights(w)
+    front = S.ChatFrontend(cfg, S.ByteTokenizer(cfg))
+    def request(i):
+        h, wd = [(56, 84), (112, 112), (84, 56)][i % 3]
+        url = IP.encode_png_data_url(IP.synthetic_page(40 + i, h, wd))
+        return {"model": "karantaocr", "max_tokens": [6, 15, 3, 11, 9][i], "temperature": 0.0,
+                "messages": [{"role": "user", "content": [{"type": "text", "text": f"page {i}"},
+                                                          {"type": "image_url", "image_url": {"url": url}}]}]}
+    static = S.LocalServer(eng, front, log=lambda *_: None)
+    want = [static.chat_completions(request(i)) for i in range(5)]
+    static.close()
+    logs = []
+    srv = S.LocalServer(eng, front, log=logs.append, continuous=True, max_tokens_cap=16, chunk=2)
+    got = [None] * 5
+    ts = [threading.Thread(target=lambda i=i: got.__setitem__(i, srv.chat_completions(request(i)))) for i in range(5)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    srv.close()
+    for (ws, wb), (gs, gb) in zip(want, got):
+        assert ws == gs == 200
+        assert gb["choices"][0]["message"]["content"] == wb["choices"][0]["message"]["content"]
+        assert gb["choices"][0]["finish_reason"] == wb["choices"][0]["finish_reason"]
+        assert gb["usage"] == wb["usage"]
+    assert any("Running:" in l for l in logs) and srv.pages_done == 5
+    eng.close()

@@ -1014,6 +1014,31 @@ def test_linear_narrow_rope_kv(L, H, KVH, K, parts):
     np.testing.assert_array_equal(gv, ref_v_all)
 
 
+def test_sample_greedy_freeze_finished(L):
+    """Flag bit 1: a finished sequence neither advances ctx_len nor writes history (slot scheduler)."""
+    B, d, n_part = 3, 64, 4
+    rng = np.random.default_rng(91)
+    av = torch.tensor([[1, 5, 2, 0], [3, 1, 9, 2], [4, 4, 4, 8]], dtype=torch.float32, device=DEV)
+    ai = torch.tensor([[10, 11, 12, 13], [20, 21, 22, 23], [30, 31, 32, 33]], dtype=torch.int32, device=DEV)
+    table = rnd(rng, 64, d); td = dev_bf16(table)
+    tok = torch.zeros(B, dtype=torch.int32, device=DEV); hist = torch.full((6, B), -1, dtype=torch.int32, device=DEV)
+    plen = torch.tensor([4, 4, 4], dtype=torch.int32, device=DEV)
+    ctx = torch.tensor([5, 6, 7], dtype=torch.int32, device=DEV)
+    fin = torch.tensor([0, 1, 0], dtype=torch.int32, device=DEV)
+    eos = torch.tensor([33], dtype=torch.int32, device=DEV)
+    xn = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):
+        L.kr_sample_greedy(ptr(av), ptr(ai), n_part, ptr(td), d, ptr(tok), ptr(hist), B, ptr(plen), ptr(ctx), ptr(fin), ptr(eos),
+                           1, 63, 2, ptr(xn), B, 0)
+    torch.cuda.synchronize()
+    assert tok.cpu().tolist() == [11, 63, 63]                 # row 1 frozen all along, row 2 hit EOS in call 1
+    assert ctx.cpu().tolist() == [7, 6, 8]                    # +2, frozen, +1 then frozen
+    assert fin.cpu().tolist() == [0, 1, 1]
+    h = hist.cpu().numpy()
+    assert h[2, 0] == 11 and h[3, 0] == 11 and h[4, 2] == 33 and (h[:, 1] == -1).all() and (h[5] == -1).all()
+    np.testing.assert_array_equal(host(xn), table[[11, 63, 63]])
+
+
 def test_sample_greedy_eos_and_pad(L):
     B, d, n_part = 3, 64, 5
     rng = np.random.default_rng(81)

@@ -1,0 +1,143 @@
+"""Slot scheduler (continuous batching) host logic against a fake engine that follows the Engine slot API."""
+import numpy as np
+import pytest
+
+from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
+
+
+class Page:
+    def __init__(self, ids, n_patches=0):
+        self.input_ids = np.asarray(ids)
+        self.pixel_values = np.zeros((n_patches, 4), np.float32) if n_patches else None
+        self.grids = []
+
+
+class FakeEngine:
+    """Deterministic stand-in: slot j's sequence for a prompt is script[prompt[0]] (list of token ids)."""
+    class cfg:
+        eos_token_ids = (99,)
+
+    def __init__(self, n_slots, script, max_tokens=1000, max_patches=1000):
+        self.B, self.script, self.max_tokens, self.max_patches = n_slots, script, max_tokens, max_patches
+        self.log = []
+        self.fail_admit = False
+
+    def begin_slots(self, max_new):
+        self.max_new = max_new
+        self.seq = [None] * self.B
+        self.gen = [0] * self.B
+        self.fin = [True] * self.B
+        self.hist = [[] for _ in range(self.B)]
+
+    def admit(self, pages, slots):
+        if self.fail_admit:
+            raise RuntimeError("boom")
+        assert len(set(slots)) == len(slots) and all(self.fin[j] for j in slots), "admitted into a busy slot"
+        assert sum(len(p.input_ids) for p in pages) <= self.max_tokens
+        self.log.append(("admit", tuple(slots)))
+        for p, j in zip(pages, slots):
+            self.seq[j] = list(self.script[int(p.input_ids[0])])
+            self.hist[j], self.gen[j], self.fin[j] = [], 0, False
+            self._emit(j)
+        return [len(p.input_ids) for p in pages]
+
+    def _emit(self, j):
+        if self.fin[j]:
+            return                                   # frozen
+        tok = self.seq[j][self.gen[j]] if self.gen[j] < len(self.seq[j]) else 7
+        assert self.gen[j] < self.max_new + 1, "history overflow"
+        self.hist[j].append(tok)
+        self.gen[j] += 1
+        if tok == 99:
+            self.fin[j] = True
+
+    def decode_steps(self, n):
+        self.log.append(("steps", n, sum(not f for f in self.fin)))
+        for _ in range(n):
+            for j in range(self.B):
+                self._emit(j)
+
+    def poll_slots(self):
+        return np.asarray(self.fin), np.asarray(self.gen)
+
+    def slot_tokens(self, j, n):
+        return np.asarray(self.hist[j][:n])
+
+    def retire(self, j):
+        self.fin[j] = True
+
+
+SCRIPT = {0: [1, 2, 3, 99], 1: [5] * 40, 2: [99], 3: [4, 4, 99, 8, 8], 4: [6] * 7 + [99], 5: [9] * 100}
+
+
+def test_results_match_the_scripts_and_keep_submission_order():
+    eng = FakeEngine(2, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=32, chunk=4)
+    reqs = [SlotRequest(Page([k, 0, 0]), mt, tag=f"r{k}") for k, mt in [(0, 10), (1, 9), (2, 5), (3, 30), (4, 30), (5, 32)]]
+    res = sch.run(reqs)
+    assert [r.tag for r in res] == ["r0", "r1", "r2", "r3", "r4", "r5"]
+    assert res[0].tokens.tolist() == [1, 2, 3, 99] and res[0].finish_reason == "stop"
+    assert res[1].tokens.tolist() == [5] * 9 and res[1].finish_reason == "length"
+    assert res[2].tokens.tolist() == [99] and res[2].finish_reason == "stop"          # EOS as the very first token
+    assert res[3].tokens.tolist() == [4, 4, 99] and res[3].finish_reason == "stop"    # nothing after the EOS
+    assert res[4].tokens.tolist() == [6] * 7 + [99]
+    assert res[5].tokens.tolist() == [9] * 32 and res[5].finish_reason == "length"    # the scheduler's cap
+    assert all(r.prompt_tokens == 3 and r.error is None for r in res)
+    assert sch.idle and sch.running == 0
+
+
+def test_slots_are_refilled_while_others_keep_decoding():
+    eng = FakeEngine(2, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=64, chunk=4)
+    for k, mt in [(5, 60), (0, 10), (3, 10), (4, 20)]:
+        sch.submit(SlotRequest(Page([k]), mt, tag=k))
+    done = []
+    while not sch.idle:
+        done += sch.step()
+    admits = [e for e in eng.log if e[0] == "admit"]
+    assert admits[0] == ("admit", (0, 1))                 # both slots filled at once
+    assert all(a[1] == (1,) for a in admits[1:])          # the long request keeps slot 0; slot 1 turns over
+    assert [r.tag for r in done] == [0, 3, 4, 5]          # completion order, not submission order
+    # static batching would have idled slot 1 for the whole 60-token request
+    assert sch.slot_steps_busy / (sch.steps * 2) > 0.6   # three short requests shared slot 1 while slot 0 ran the long one
+
+
+def test_length_limit_between_polls_never_overruns_history():
+    eng = FakeEngine(1, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=10, chunk=7)     # polls at 8, 15 generated tokens
+    (r,) = sch.run([SlotRequest(Page([5]), 10)])
+    assert r.tokens.tolist() == [9] * 10 and r.finish_reason == "length"
+    assert eng.max_new == 17 and max(eng.gen) <= 17
+
+
+def test_prompt_budget_splits_admissions_and_rejects_what_can_never_fit():
+    eng = FakeEngine(3, SCRIPT, max_tokens=10)
+    sch = SlotScheduler(eng, max_tokens_cap=8, chunk=2)
+    reqs = [SlotRequest(Page([0] * 6), 4, "a"), SlotRequest(Page([0] * 6), 4, "b"), SlotRequest(Page([0] * 11), 4, "big"),
+            SlotRequest(Page([2] * 3), 4, "c")]
+    res = sch.run(reqs)
+    assert [e[1] for e in eng.log if e[0] == "admit"][0] == (0,)       # 6 + 6 > 10: one per admission round
+    big = res[2]
+    assert big.error and "does not fit" in big.error and big.tokens.size == 0
+    assert [r.error for r in res[:2]] == [None, None] and res[3].tokens.tolist() == [99]
+
+
+def test_engine_failure_fails_only_that_admission():
+    eng = FakeEngine(2, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=8, chunk=2)
+    eng.fail_admit = True
+    sch.submit(SlotRequest(Page([0]), 4, "x"))
+    (r,) = sch.step()
+    assert r.error.startswith("RuntimeError") and sch.idle
+    eng.fail_admit = False
+    (ok,) = sch.run([SlotRequest(Page([0]), 8, "y")])
+    assert ok.error is None and ok.tokens.tolist() == [1, 2, 3, 99]
+
+
+def test_argument_checks():
+    eng = FakeEngine(1, SCRIPT)
+    with pytest.raises(ValueError):
+        SlotScheduler(eng, 0)
+    sch = SlotScheduler(eng, 4)
+    with pytest.raises(ValueError):
+        sch.submit(SlotRequest(Page([0]), 0))

@@ -193,3 +193,100 @@ def test_http_shim_round_trip(server):
         assert any("ready to roll" in l for l in server.logs)
     finally:
         httpd.shutdown()
+
+
+# ----------------------------------------------------------------------------- continuous batching mode
+class FakeSlotEngine:
+    """Slot-API stand-in (Engine.begin_slots / admit / decode_steps / poll_slots / slot_tokens / retire): every
+    request generates b"OK<eos>" except prompts holding 50 or more 'y', which generate 'z' forever."""
+    B = 2
+    cfg = CFG
+    max_tokens = 4096
+    max_patches = 1 << 20
+
+    def __init__(self, fail_after=None):
+        self.admits, self.step_calls, self.fail_after = [], 0, fail_after
+
+    def begin_slots(self, max_new):
+        self.max_new = max_new
+        self.seq, self.hist, self.fin = [None] * self.B, [[] for _ in range(self.B)], [True] * self.B
+
+    def _emit(self, j):
+        if not self.fin[j]:
+            k = len(self.hist[j])
+            tok = self.seq[j][k] if k < len(self.seq[j]) else ord("z")
+            self.hist[j].append(tok)
+            self.fin[j] = tok == CFG.eos_token_ids[0]
+
+    def admit(self, pages, slots):
+        self.admits.append(tuple(slots))
+        for p, j in zip(pages, slots):
+            long_one = int((np.asarray(p.input_ids) == ord("y")).sum()) >= 50
+            self.seq[j] = [] if long_one else list(b"OK") + [CFG.eos_token_ids[0]]
+            self.hist[j], self.fin[j] = [], False
+            self._emit(j)
+        return [len(p.input_ids) for p in pages]
+
+    def decode_steps(self, n):
+        self.step_calls += 1
+        if self.fail_after is not None and self.step_calls > self.fail_after:
+            raise RuntimeError("boom")
+        for _ in range(n):
+            for j in range(self.B):
+                self._emit(j)
+
+    def poll_slots(self):
+        return np.asarray(self.fin), np.asarray([len(h) for h in self.hist])
+
+    def slot_tokens(self, j, n):
+        return np.asarray(self.hist[j][:n], np.int64)
+
+    def retire(self, j):
+        self.fin[j] = True
+
+
+@pytest.fixture
+def cserver():
+    logs = []
+    srv = S.LocalServer(FakeSlotEngine(), S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=logs.append, continuous=True,
+                        max_tokens_cap=12, chunk=2)
+    srv.logs = logs
+    yield srv
+    srv.close()
+
+
+def test_continuous_mode_same_schema_and_log_protocol(cserver):
+    status, body = cserver.chat_completions({"model": "karantaocr", "messages": vision_message(), "max_tokens": 16})
+    assert status == 200 and body["choices"][0]["message"]["content"] == "OK" and body["choices"][0]["finish_reason"] == "stop"
+    assert body["usage"]["completion_tokens"] == 2          # 'O', 'K' (the EOS is dropped from the content, as in static mode)
+    import re
+    assert any(re.search(r"Running: (\d+)", l) and re.search(r"(?:Waiting|Pending):\s*(\d+)", l) for l in cserver.logs)
+    status, body = cserver.chat_completions({"messages": [{"role": "user", "content": "x"}], "max_tokens": 1})
+    assert status == 200 and body["choices"][0]["finish_reason"] == "length" and body["usage"]["completion_tokens"] == 1
+
+
+def test_continuous_mode_short_requests_overtake_a_long_one(cserver):
+    import threading
+    out = {}
+    def call(name, text, mt):
+        out[name] = cserver.chat_completions({"messages": [{"role": "user", "content": text}], "max_tokens": mt})
+    long_t = threading.Thread(target=call, args=("long", "y" * 60, 12))
+    long_t.start()
+    shorts = [threading.Thread(target=call, args=(f"s{i}", "x", 8)) for i in range(5)]
+    [t.start() for t in shorts]; [t.join() for t in shorts]; long_t.join()
+    assert all(out[f"s{i}"][0] == 200 and out[f"s{i}"][1]["choices"][0]["message"]["content"] == "OK" for i in range(5))
+    status, body = out["long"]
+    assert status == 200 and body["choices"][0]["finish_reason"] == "length" and body["choices"][0]["message"]["content"] == "z" * 12
+    # five short requests went through the one slot the long request left free
+    assert len(cserver.engine.admits) >= 3 and cserver.pages_done == 6
+
+
+def test_continuous_mode_engine_failure_is_500_and_the_server_recovers():
+    eng = FakeSlotEngine(fail_after=0)
+    srv = S.LocalServer(eng, S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None, continuous=True, max_tokens_cap=8, chunk=2)
+    status, body = srv.chat_completions({"messages": [{"role": "user", "content": "x"}]})
+    assert status == 500 and "boom" in body["error"]["message"]
+    eng.fail_after = None
+    status, body = srv.chat_completions({"messages": [{"role": "user", "content": "x"}]})
+    srv.close()
+    assert status == 200 and body["choices"][0]["message"]["content"] == "OK"
