@@ -284,6 +284,16 @@ int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16*
 int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split,
                          kr_stream s);
 
+/* Temperature sampling as an argmax (Gumbel-max): per row b, partial argmax over n_part vocabulary slices of
+ * logits[b][i] / T_b + G(seed_b, n_b, i), n_b = ctx_len[b] + 1 - prompt_len[b] (index of the token being
+ * generated), G = -ln(-ln(u)) from a counter-based hash (definition in kr_decode.hip, restated in the oracle);
+ * T_b == 0: plain argmax.  Writes amax_val / amax_idx [batch][n_part] for kr_sample_greedy, replacing the
+ * greedy partials of the lm_head.  Replaces vLLM's sampler for requests with temperature > 0
+ * (/root/reference/karanta/pipeline.py:281,301; bulk_processing/workers/vllm_client.py:155). */
+int kr_gumbel_argmax(const float* logits, int64_t ld_logits, int vocab, const float* temperature,
+                     const uint32_t* seed, const int32_t* ctx_len, const int32_t* prompt_len, float* amax_val,
+                     int32_t* amax_idx, int n_part, int batch, kr_stream s);
+
 /* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out[b] and
  * history[(ctx_len[b] + 1 - prompt_len[b]) * hist_stride + b] (= this sequence's generated-token
  * index), EOS / pad handling as kr_argmax_embed, ctx_len[b] += 1, embedding gather into x_next.

@@ -1246,6 +1246,66 @@ __global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict
 }
 
 // =====================================================================================
+// temperature sampling as an argmax (Gumbel-max): token = argmax_i( logit_i / T + G_i )
+// =====================================================================================
+// G_i = -ln(-ln(u_i)), u_i = ((h_i >> 8) + 0.5) * 2^-24, h_i = mix(mix(seed ^ n * 0x9E3779B1) + i) with
+// mix = the "lowbias32" integer finaliser and n = the index of the token being generated in its sequence
+// (ctx_len + 1 - prompt_len).  A counter-based generator: no state, any (sequence, step, token) draw can be
+// recomputed — the oracle does exactly that.  T == 0 rows get no noise: plain argmax, ties to the lowest index.
+// The reference's requests carry temperature 0.1 (first attempt, karanta/pipeline.py:281,301) or 0.7
+// (VLLMClient.generate default, bulk_processing/workers/vllm_client.py:155); vLLM's own sampler draws from the
+// same softmax(logits / T) distribution with a different generator.
+__device__ __forceinline__ unsigned kr_mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) gumbel_argmax_kernel(const float* __restrict__ logits, int64_t ld, int vocab,
+                                                            const float* __restrict__ temperature,
+                                                            const unsigned* __restrict__ seed,
+                                                            const int32_t* __restrict__ ctx_len,
+                                                            const int32_t* __restrict__ prompt_len,
+                                                            float* __restrict__ amax_val, int32_t* __restrict__ amax_idx) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    const int p = blockIdx.x, n_part = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (((vocab + n_part - 1) / n_part) + 3) & ~3;
+    const int i0 = p * per, i1 = min(vocab, i0 + per);
+    const float T = temperature[b];
+    const float inv_t = T > 0.f ? 1.0f / T : 1.0f;
+    const unsigned base = kr_mix32(seed[b] ^ ((unsigned)(ctx_len[b] + 1 - prompt_len[b]) * 0x9E3779B1u));
+    const float* row = logits + (int64_t)b * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = i0 + tid; i < i1; i += 256) {
+        float v = row[i] * inv_t;
+        if (T > 0.f) {
+            const unsigned h = kr_mix32(base + (unsigned)i);
+            const float u = ((float)(h >> 8) + 0.5f) * 5.9604644775390625e-08f;  // 2^-24: u in (0, 1), exact in f32
+            v += -logf(-logf(u));
+        }
+        better(bv, bi, v, i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        better(bv, bi, ov, oi);
+    }
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) better(bv, bi, s_v[w], s_i[w]);
+        amax_val[(int64_t)b * n_part + p] = bv;
+        amax_idx[(int64_t)b * n_part + p] = bi;
+    }
+}
+
+// =====================================================================================
 // greedy sampling from the lm_head partials + per-step bookkeeping
 // =====================================================================================
 __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restrict__ amax_val,
@@ -1512,6 +1572,17 @@ extern "C" int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int ba
         case 16: attn_merge_kernel<16><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
         default: attn_merge_kernel<0><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split);
     }
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_gumbel_argmax(const float* logits, int64_t ld_logits, int vocab, const float* temperature,
+                                const uint32_t* seed, const int32_t* ctx_len, const int32_t* prompt_len, float* amax_val,
+                                int32_t* amax_idx, int n_part, int batch, kr_stream s) {
+    KR_CHECK_ARG(logits && temperature && seed && ctx_len && prompt_len && amax_val && amax_idx, "kr_gumbel_argmax: null pointer");
+    KR_CHECK_ARG(vocab > 0 && ld_logits >= vocab && n_part > 0 && n_part <= 65535 && batch > 0, "kr_gumbel_argmax: bad sizes");
+    gumbel_argmax_kernel<<<dim3(n_part, batch), 256, 0, kr_hs(s)>>>(logits, ld_logits, vocab, temperature, seed, ctx_len, prompt_len,
+                                                                    amax_val, amax_idx);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

@@ -156,6 +156,8 @@ class PageRequest:
     input_ids: np.ndarray                      # int64 [P]
     pixel_values: Optional[np.ndarray] = None  # fp32 [n_patches, 1176] (all images concatenated)
     grids: List[Tuple[int, int, int]] = field(default_factory=list)
+    temperature: float = 0.0                   # 0: greedy; > 0: Gumbel-max sampling (kr_gumbel_argmax)
+    seed: int = 0                              # the sampler is counter-based: (seed, token index) fixes every draw
 
 
 @dataclass
@@ -185,7 +187,7 @@ class Engine:
         self.max_patches = max_patches
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
-        self._ignore_eos = self._freeze_finished = self._want_logits = False
+        self._ignore_eos = self._freeze_finished = self._want_logits = self._sampling = False
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
         self._prefetch_mode = int(os.environ.get("KARANTA_PREFETCH", "0"))
@@ -276,6 +278,8 @@ class Engine:
         self.d_delta = z(B, dtype=torch.int32)
         self.d_tok = z(B, dtype=torch.int32)
         self.d_fin = z(B, dtype=torch.int32)
+        self.d_temp = z(B, dtype=torch.float32)   # per-slot sampling temperature and seed
+        self.d_seed = z(B, dtype=torch.int32)
         self.max_new = 0
         self.d_hist = None
         self.d_eos = torch.tensor(list(self.cfg.eos_token_ids), dtype=torch.int32, device=dev)
@@ -468,7 +472,16 @@ class Engine:
                 p1 = lens[b] + kk + int(deltas[b])
                 c_, s_ = POS.mrope_tables(np.stack([p1, p1, p1]), t.head_dim, t.rope_theta, t.mrope_section)
                 cs[b, :, : t.head_dim // 2], cs[b, :, t.head_dim // 2:] = c_[:, : t.head_dim // 2], s_[:, : t.head_dim // 2]
+            temps = np.asarray([float(getattr(p, "temperature", 0.0) or 0.0) for p in pages], np.float32)
+            seeds = np.asarray([int(getattr(p, "seed", 0) or 0) & 0xFFFFFFFF for p in pages], np.uint32).view(np.int32)
+            if temps.max(initial=0.0) > 0 and not self._sampling:
+                raise KarantaHipError("a page asks for temperature > 0 but the engine is in its greedy configuration "
+                                      "(generate() decides from its pages; begin_slots(sampling=True) for slot mode)")
             if whole_batch:
+                tb, sb = np.zeros(self.B, np.float32), np.zeros(self.B, np.int32)
+                tb[:B], sb[:B] = temps, seeds
+                self._h2d(self.d_temp, tb)
+                self._h2d(self.d_seed, sb)
                 ctx0 = np.zeros(self.B, np.int32)
                 ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_sample_greedy adds 1 -> number of cached tokens
                 plen = np.zeros(self.B, np.int32)
@@ -484,6 +497,8 @@ class Engine:
                     self._h2d(self.d_ctx[j:j + 1], np.asarray([lens[b] - 1], np.int32))
                     self._h2d(self.d_plen[j:j + 1], np.asarray([lens[b]], np.int32))
                     self._h2d(self.d_cs[j], cs[b])
+                    self._h2d(self.d_temp[j:j + 1], temps[b:b + 1])
+                    self._h2d(self.d_seed[j:j + 1], seeds[b:b + 1])
                     self.d_fin[j:j + 1].zero_()
             self._h2d(self.d_last, last_rows)
             t_ = lambda a: torch.from_numpy(a).to(dev)
@@ -527,14 +542,21 @@ class Engine:
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         x = self.d_x if x is None else x
         j = slot0  # rows j .. j+B-1 of every per-sequence array (the slot scheduler prefills single slots)
-        logits = self.d_logits[j:] if self._want_logits else None
+        logits = self.d_logits[j:] if (self._want_logits or self._sampling) else None
         if self.wide_mode:
             self._dec_wide(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits)
         else:
             self._dec(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits,
                       waves=self.wv_wide)
+        n_part = self.n_amax
+        if self._sampling:
+            # temperature > 0 somewhere in the batch: the partial argmax is redone on logits / T + Gumbel noise
+            # (rows with T = 0 get their plain argmax back)
+            n_part = min(64, self.n_amax)
+            L.kr_gumbel_argmax(ptr(logits), self.d_logits.stride(0), t.vocab_size, ptr(self.d_temp[j:]), ptr(self.d_seed[j:]),
+                               ptr(self.d_ctx[j:]), ptr(self.d_plen[j:]), ptr(self.d_amax_v), ptr(self.d_amax_i), n_part, B, s)
         flags = (1 if self._ignore_eos else 0) | (2 if self._freeze_finished else 0)
-        L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), self.n_amax, ptr(w.view("llm.embed")), t.hidden_size,
+        L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), n_part, ptr(w.view("llm.embed")), t.hidden_size,
                            ptr(self.d_tok[j:]), ptr(self.d_hist[:, j:]), self.d_hist.stride(0), ptr(self.d_plen[j:]),
                            ptr(self.d_ctx[j:]), ptr(self.d_fin[j:]), ptr(self.d_eos), self.d_eos.numel(),
                            self.cfg.pad_token_id, flags, ptr(self.d_x[j:]), B, s)
@@ -688,7 +710,7 @@ class Engine:
         return {"launches": n, "avg_us": ms.value * 1e3 / n, "bytes_per_launch": nbytes}
 
     def _graph_for(self, B: int) -> int:
-        key = (B, self._ignore_eos, self._freeze_finished)
+        key = (B, self._ignore_eos, self._freeze_finished, self._sampling)
         assert not self._want_logits
         g = self._graphs.get(key)
         if g is None:
@@ -722,6 +744,7 @@ class Engine:
         self._ignore_eos = bool(ignore_eos)
         self._freeze_finished = False
         self._want_logits = bool(return_logits)
+        self._sampling = any(float(getattr(p, "temperature", 0.0) or 0.0) > 0 for p in pages)
         self._last_batch = B
         if self.d_hist is None or self.max_new < max_new_tokens:
             self.max_new = max_new_tokens
@@ -751,7 +774,7 @@ class Engine:
         steps_done = 1
         with torch.cuda.stream(self.stream):
             want_graph = use_graph and not return_logits
-            graph = self._graphs.get((B, self._ignore_eos, False)) if want_graph else None
+            graph = self._graphs.get((B, self._ignore_eos, False, self._sampling)) if want_graph else None
             while steps_done < max_new_tokens:
                 if graph is not None and profile_every and steps_done % profile_every == 0:
                     self._prof_on = True
@@ -796,11 +819,12 @@ class Engine:
     # ------------------------------------------------------------------ slot scheduler API (continuous batching)
     # The decode graph always runs all `max_batch` slots; a slot whose sequence has finished idles in place
     # (kr_sample_greedy freeze bit) until `admit` prefills a new request into it.  See scheduler.SlotScheduler.
-    def begin_slots(self, max_new_tokens: int):
-        """Enter slot mode: every slot idle, per-slot history / rotary tables sized for `max_new_tokens`."""
+    def begin_slots(self, max_new_tokens: int, sampling: bool = False):
+        """Enter slot mode: every slot idle, per-slot history / rotary tables sized for `max_new_tokens`.
+        sampling=True: the decode graph carries the Gumbel-max pass, so requests may ask for temperature > 0."""
         if max_new_tokens < 1:
             raise ValueError("max_new_tokens must be >= 1")
-        self._ignore_eos, self._freeze_finished, self._want_logits = False, True, False
+        self._ignore_eos, self._freeze_finished, self._want_logits, self._sampling = False, True, False, bool(sampling)
         self._last_batch = self.B
         if self.d_hist is None or self.max_new < max_new_tokens:
             self.max_new = max_new_tokens
@@ -811,6 +835,7 @@ class Engine:
             self._graphs.clear()
         with torch.cuda.stream(self.stream):
             self.d_fin.fill_(1)
+            self.d_temp.zero_()
             self.d_ctx.zero_()
             self.d_plen.zero_()
             self.d_x.zero_()
@@ -829,7 +854,7 @@ class Engine:
         """n decode steps over all slots (asynchronous on the engine's stream)."""
         with torch.cuda.stream(self.stream):
             for _ in range(n):
-                graph = self._graphs.get((self.B, False, True))
+                graph = self._graphs.get((self.B, False, True, self._sampling))
                 if graph is not None:
                     self.L.kr_graph_launch(graph, self.s)
                 else:  # first step eager (kernel attributes), then captured

@@ -40,7 +40,7 @@ class SlotScheduler:
     returns the requests that finished."""
 
     def __init__(self, engine, max_tokens_cap: int, chunk: int = 16, eos_token_ids: Optional[Sequence[int]] = None,
-                 max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None):
+                 max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False):
         if max_tokens_cap < 1 or chunk < 1:
             raise ValueError("max_tokens_cap and chunk must be >= 1")
         self.engine = engine
@@ -55,7 +55,11 @@ class SlotScheduler:
         self.steps = 0                               # decode steps run
         self.slot_steps_busy = 0                     # sum over steps of occupied slots (utilisation numerator)
         # a slot may run up to chunk - 1 steps past its limit before the host looks: size the history for that
-        engine.begin_slots(self.cap + self.chunk)
+        # sampling: pages may carry temperature > 0 (the decode graph then includes the Gumbel-max pass)
+        if sampling:
+            engine.begin_slots(self.cap + self.chunk, sampling=True)
+        else:
+            engine.begin_slots(self.cap + self.chunk)
 
     # ------------------------------------------------------------------ public
     def submit(self, req: SlotRequest) -> None:

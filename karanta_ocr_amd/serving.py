@@ -12,9 +12,11 @@ back into exactly the response JSON those callers parse:
 Status codes follow what ``process_page`` distinguishes (pipeline.py:321-332): 200, 400 (bad
 request: caller skips the attempt), 500 (internal error: caller retries).
 
-Not built yet: continuous batching, sampling with temperature > 0
-(requests are served greedy — the reference's ``build_page_query`` default of 0.0, pipeline.py:170),
-``guided_regex`` / ``response_format`` constrained decoding, logprobs.
+``temperature`` is honoured (0 or absent: greedy — the reference's ``build_page_query`` default, pipeline.py:170;
+``process_page`` sends 0.1 on its first attempt, :281,:301): Gumbel-max sampling from softmax(logits / T)
+(kr_gumbel_argmax), reproducible through the OpenAI ``seed`` field, a random seed per request otherwise.
+``top_p`` / ``top_k`` are not applied.  Not built yet: ``guided_regex`` /
+``response_format`` constrained decoding, logprobs (accepted, ignored).
 """
 from __future__ import annotations
 
@@ -84,6 +86,8 @@ class ParsedRequest:
     grids: List[Tuple[int, int, int]]
     max_tokens: int
     model: str
+    temperature: float = 0.0
+    seed: Optional[int] = None      # None: the server draws one per request
 
 
 class ChatFrontend:
@@ -144,8 +148,15 @@ class ChatFrontend:
         ids += [self.tok.im_start] + self.tok.encode("assistant") + [self.tok.newline]
         if len(ids) + max_tokens > self.max_model_len:
             raise BadRequest(f"prompt ({len(ids)} tokens) + max_tokens ({max_tokens}) exceeds max_model_len {self.max_model_len}")
+        try:
+            temperature = float(req.get("temperature") or 0.0)
+            seed = None if req.get("seed") is None else int(req["seed"]) & 0xFFFFFFFF
+        except (TypeError, ValueError) as e:
+            raise BadRequest(f"temperature / seed: {e}") from e
+        if not (0.0 <= temperature <= 100.0):   # NaN fails both comparisons
+            raise BadRequest("temperature must be in [0, 100]")
         return ParsedRequest(np.asarray(ids, np.int64), np.concatenate(pvs, 0) if pvs else None, grids, max_tokens,
-                             str(req.get("model", "karantaocr")))
+                             str(req.get("model", "karantaocr")), temperature, seed)
 
 
 # ----------------------------------------------------------------------------- in-process server
@@ -161,8 +172,9 @@ class LocalServer:
 
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
                  batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
-                 chunk: int = 16):
+                 chunk: int = 16, honor_temperature: bool = True):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
+        self.honor_temperature = bool(honor_temperature)   # False: every request is served greedy
         self.batch_wait_s, self.log = batch_wait_s, log
         self.continuous, self.max_tokens_cap, self.chunk = bool(continuous), int(max_tokens_cap), int(chunk)
         self._q: "queue.Queue" = queue.Queue()
@@ -234,7 +246,7 @@ class LocalServer:
             # same shape as vLLM's periodic stats line that the reference scrapes (pipeline.py:782-800)
             self.log(f"Running: {self._running} reqs, Waiting: {self._q.qsize()} reqs")
             try:
-                pages = [PageRequest(s["req"].input_ids, s["req"].pixel_values, s["req"].grids) for s in batch]
+                pages = [self._page(s["req"]) for s in batch]
                 res = self.engine.generate(pages, max(s["req"].max_tokens for s in batch))
                 for s, toks, reason in zip(batch, res.tokens, res.finish_reasons):
                     self._finish(s, toks, reason)
@@ -246,6 +258,14 @@ class LocalServer:
             for s in batch:
                 s["done"].set()
 
+
+    def _page(self, r: ParsedRequest):
+        from .engine import PageRequest
+        import random
+        if self.honor_temperature and r.temperature > 0:
+            seed = r.seed if r.seed is not None else random.getrandbits(32)
+            return PageRequest(r.input_ids, r.pixel_values, r.grids, temperature=r.temperature, seed=seed)
+        return PageRequest(r.input_ids, r.pixel_values, r.grids)
 
     def _finish(self, s: Dict[str, Any], toks, reason: str):
         mt = s["req"].max_tokens
@@ -261,7 +281,7 @@ class LocalServer:
         from .scheduler import SlotRequest, SlotScheduler
 
         try:
-            sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk)
+            sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature)
         except Exception as e:  # cannot enter slot mode: every request gets a 500
             sch, boot_error = None, f"{type(e).__name__}: {e}"
         last = (-1, -1)
@@ -285,7 +305,7 @@ class LocalServer:
                     s["done"].set()
                 else:
                     r = s["req"]
-                    sch.submit(SlotRequest(PageRequest(r.input_ids, r.pixel_values, r.grids), max(1, int(r.max_tokens)), tag=s))
+                    sch.submit(SlotRequest(self._page(r), max(1, int(r.max_tokens)), tag=s))
             if self._stop or sch is None:
                 continue
             try:
@@ -297,7 +317,7 @@ class LocalServer:
                     r.tag["done"].set()
                 self.pages_done += len(sch.active) + len(sch.waiting)
                 try:
-                    sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk)
+                    sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature)
                 except Exception as e2:
                     sch, boot_error = None, f"{type(e2).__name__}: {e2}"
                 continue

@@ -464,15 +464,42 @@ def embed_and_scatter(input_ids: np.ndarray, image_embeds: Optional[np.ndarray],
     return emb
 
 
+def _mix32(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, np.uint64) & 0xFFFFFFFF
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & 0xFFFFFFFF
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & 0xFFFFFFFF
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def gumbel_noise(seed: int, n: int, vocab: int) -> np.ndarray:
+    """G_i of the build's sampler (kr_gumbel_argmax, kr_decode.hip): -ln(-ln(u_i)), u_i = ((h_i >> 8) + 0.5) 2^-24,
+    h_i = mix(mix(seed ^ n * 0x9E3779B1) + i), n = index of the token being generated.  fp32 like the kernel."""
+    base = _mix32(np.uint64((int(seed) ^ ((int(n) * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF))
+    h = _mix32((base + np.arange(vocab, dtype=np.uint64)) & 0xFFFFFFFF)
+    u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    return -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+
+
+def sample_scores(logits: np.ndarray, temperature: float, seed: int, n: int) -> np.ndarray:
+    """What the sampler takes the argmax of: logits / T + G (T > 0), the logits themselves (T == 0)."""
+    logits = np.asarray(logits, np.float32)
+    if temperature <= 0:
+        return logits
+    return logits * np.float32(1.0 / np.float32(temperature)) + gumbel_noise(seed, n, logits.shape[-1])
+
+
 def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[np.ndarray],
                     image_grid_thw: Optional[Sequence[Sequence[int]]], max_new_tokens: int,
                     policy: str = "fp32", ignore_eos: bool = False,
-                    return_logits: bool = False):
+                    return_logits: bool = False, temperature: float = 0.0, seed: int = 0):
     """The call sequence of /root/reference/karanta/training/test_trained_model.py:76-99
     (``model.generate(**inputs, max_new_tokens=N)`` with ``do_sample=False``), i.e. what a
     ``temperature=0`` request to the reference's vLLM server computes
     (/root/reference/karanta/pipeline.py:166-171): ViT → scatter → prefill → greedy decode,
-    stopping at EOS.  Single-sequence or equal-length batch (no padding)."""
+    stopping at EOS.  Single-sequence or equal-length batch (no padding).
+    temperature > 0 (the reference's first attempt sends 0.1, pipeline.py:281,301): Gumbel-max sampling with the
+    build's counter-based noise (`sample_scores`); the returned "logits" are then the noisy scores."""
     input_ids = np.asarray(input_ids)
     B, P = input_ids.shape
     img = None
@@ -485,7 +512,8 @@ def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[
         pos = np.tile(np.arange(P)[None, None, :], (3, B, 1))
         delta = np.zeros((B,), dtype=np.int64)
     cache = KVCache.empty(cfg.text.num_layers)
-    logits = decoder_forward(emb, pos, weights, cfg.text, cache, policy)
+    noisy = lambda lg, n: np.stack([sample_scores(lg[b], temperature, seed, n) for b in range(B)])
+    logits = noisy(decoder_forward(emb, pos, weights, cfg.text, cache, policy), 0)
     all_logits = [logits]
     out = np.zeros((B, 0), dtype=np.int64)
     done = np.zeros((B,), dtype=bool)
@@ -501,7 +529,7 @@ def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[
             break
         e = embed_and_scatter(nxt[:, None], None, weights, cfg)
         ppos = np.tile((P + step + delta)[None, :, None], (3, 1, 1))
-        logits = decoder_forward(e, ppos, weights, cfg.text, cache, policy)
+        logits = noisy(decoder_forward(e, ppos, weights, cfg.text, cache, policy), step + 1)
         all_logits.append(logits)
     if return_logits:
         return out, np.stack(all_logits, axis=1)

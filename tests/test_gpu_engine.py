@@ -212,3 +212,35 @@ def test_server_continuous_mode_end_to_end(engines, tiny_models):
         assert gb["usage"] == wb["usage"]
     assert any("Running:" in l for l in logs) and srv.pages_done == 5
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_sampled_generation_matches_oracle(engines, tiny_models, name):
+    """temperature > 0: the engine's tokens equal the oracle's Gumbel-max draws (same counter-based noise) up to the
+    first step whose top-2 noisy scores are closer than the logit tolerance; a batch mixes sampled pages, another
+    seed and a greedy page; the same seed reproduces, another seed differs."""
+    import dataclasses
+    cfg, w, P = tiny_models[name]
+    eng = engines[name]
+    pv, grid = IP.image_to_patches(IP.synthetic_page(3, 84, 112))
+    T = grid[1] * grid[2] // 4
+    ids = np.concatenate([[5, 6, cfg.vision_start_token_id], [cfg.image_token_id] * T, [cfg.vision_end_token_id, 7, 8]]).astype(np.int64)
+    _, lg0 = O.generate_greedy(cfg, w, ids[None], pv, [grid], 1, policy="bf16", ignore_eos=True, return_logits=True)
+    # hot enough that the noise decides: the tied-embedding model's logits are an order of magnitude larger
+    temp, steps = max(0.9, 0.3 * float(np.abs(lg0[0, 0]).max())), 14
+    pages = [PageRequest(ids, pv, [grid], temperature=temp, seed=4242), PageRequest(ids, pv, [grid], temperature=temp, seed=4243),
+             PageRequest(ids, pv, [grid])]
+    res = eng.generate(pages, steps, ignore_eos=True)
+    again = eng.generate(pages[:1], steps, ignore_eos=True)
+    np.testing.assert_array_equal(res.tokens[0], again.tokens[0])                  # reproducible, batch-independent
+    assert not np.array_equal(res.tokens[0], res.tokens[1])                        # another seed, another draw
+    greedy = eng.generate([PageRequest(ids, pv, [grid])], steps, ignore_eos=True)
+    np.testing.assert_array_equal(res.tokens[2], greedy.tokens[0])                 # T = 0 row of a sampling batch
+    assert not np.array_equal(res.tokens[0], greedy.tokens[0])
+    tol = 0.02 * float(np.abs(lg0[0, 0]).max()) / temp        # the logit tolerance of the greedy tests, scaled by 1 / T
+    for k, seed in ((0, 4242), (1, 4243)):
+        ref_tok, ref_sc = O.generate_greedy(cfg, w, ids[None], pv, [grid], steps, policy="bf16", ignore_eos=True,
+                                            return_logits=True, temperature=temp, seed=seed)
+        n = compare_tokens(res.tokens[k], ref_tok[0], ref_sc[0], tol)
+        assert n >= 3, f"only {n} sampled tokens could be checked"

@@ -1014,6 +1014,56 @@ def test_linear_narrow_rope_kv(L, H, KVH, K, parts):
     np.testing.assert_array_equal(gv, ref_v_all)
 
 
+def test_gumbel_argmax_matches_oracle_noise(L):
+    """kr_gumbel_argmax partials against the oracle's sample_scores: same counter-based noise (integer hash bit-exact,
+    the two logs within float rounding), T = 0 rows untouched, ties to the lowest index, sampled frequencies follow
+    softmax(logits / T)."""
+    rng = np.random.default_rng(17)
+    B, V, n_part = 4, 5003, 7
+    logits = rng.standard_normal((B, V)).astype(np.float32) * 2
+    logits[1, 100] = logits[1, 4000] = 50.0                      # T = 0 row with an exact tie
+    temps = np.asarray([0.7, 0.0, 0.1, 1.5], np.float32)
+    seeds = np.asarray([1, 2, 0xFFFFFFFF, 12345], np.uint32)
+    plen = np.asarray([10, 5, 7, 0], np.int32); ctx = np.asarray([12, 5, 30, 2], np.int32)   # n = ctx + 1 - plen
+    ld = torch.from_numpy(logits).to(DEV)
+    av = torch.zeros(B, n_part, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
+    td, sd = torch.from_numpy(temps).to(DEV), torch.from_numpy(seeds.view(np.int32)).to(DEV)
+    pd, cd = torch.from_numpy(plen).to(DEV), torch.from_numpy(ctx).to(DEV)
+    L.kr_gumbel_argmax(ptr(ld), V, V, ptr(td), ptr(sd), ptr(cd), ptr(pd), ptr(av), ptr(ai), n_part, B, 0)
+    torch.cuda.synchronize()
+    avh, aih = av.cpu().numpy(), ai.cpu().numpy()
+    per = ((-(-V // n_part)) + 3) & ~3
+    for b in range(B):
+        sc = O.sample_scores(logits[b], float(temps[b]), int(seeds[b]), int(ctx[b] + 1 - plen[b]))
+        for p_ in range(n_part):
+            seg = sc[p_ * per:min(V, (p_ + 1) * per)]
+            j = int(np.argmax(seg))
+            top2 = np.sort(seg)[-2:]
+            if top2[1] - top2[0] > 1e-4:                         # the device's logf and numpy's differ in the last bits
+                assert aih[b, p_] == p_ * per + j
+            np.testing.assert_allclose(avh[b, p_], seg[j], rtol=2e-6, atol=2e-5)
+    assert aih[1].min() >= 0 and 100 in aih[1] and avh[1].max() == 50.0 and aih[1][np.argmax(avh[1])] == 100
+    # distribution: 3 candidates with probabilities softmax([2, 1, 0] / T), 4000 draws through n
+    lg = np.full((1, 64), -1e4, np.float32); lg[0, [3, 17, 40]] = [2.0, 1.0, 0.0]
+    T = 0.8
+    want = np.exp(np.asarray([2.0, 1.0, 0.0]) / T); want /= want.sum()
+    ldd = torch.from_numpy(lg).to(DEV); t1 = torch.tensor([T], device=DEV); s1 = torch.tensor([99], dtype=torch.int32, device=DEV)
+    p1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    counts = {3: 0, 17: 0, 40: 0}
+    a1 = torch.zeros(1, 1, device=DEV); i1 = torch.zeros(1, 1, dtype=torch.int32, device=DEV)
+    draws = 4000
+    cs = torch.arange(draws, dtype=torch.int32, device=DEV)
+    picks = []
+    for n in range(draws):
+        L.kr_gumbel_argmax(ptr(ldd), 64, 64, ptr(t1), ptr(s1), ptr(cs[n:]), ptr(p1), ptr(a1), ptr(i1), 1, 1, 0)
+        picks.append(i1.clone())
+    torch.cuda.synchronize()
+    for t_ in torch.cat(picks).cpu().numpy().ravel():
+        counts[int(t_)] += 1
+    got = np.asarray([counts[3], counts[17], counts[40]]) / draws
+    assert np.abs(got - want).max() < 0.03, (got, want)
+
+
 def test_sample_greedy_freeze_finished(L):
     """Flag bit 1: a finished sequence neither advances ctx_len nor writes history (slot scheduler)."""
     B, d, n_part = 3, 64, 4

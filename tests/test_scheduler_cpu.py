@@ -22,7 +22,7 @@ class FakeEngine:
         self.log = []
         self.fail_admit = False
 
-    def begin_slots(self, max_new):
+    def begin_slots(self, max_new, sampling=False):
         self.max_new = max_new
         self.seq = [None] * self.B
         self.gen = [0] * self.B

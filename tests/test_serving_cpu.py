@@ -205,10 +205,10 @@ class FakeSlotEngine:
     max_patches = 1 << 20
 
     def __init__(self, fail_after=None):
-        self.admits, self.step_calls, self.fail_after = [], 0, fail_after
+        self.admits, self.step_calls, self.fail_after, self.pages = [], 0, fail_after, []
 
-    def begin_slots(self, max_new):
-        self.max_new = max_new
+    def begin_slots(self, max_new, sampling=False):
+        self.max_new, self.sampling = max_new, sampling
         self.seq, self.hist, self.fin = [None] * self.B, [[] for _ in range(self.B)], [True] * self.B
 
     def _emit(self, j):
@@ -221,6 +221,7 @@ class FakeSlotEngine:
     def admit(self, pages, slots):
         self.admits.append(tuple(slots))
         for p, j in zip(pages, slots):
+            self.pages.append(p)
             long_one = int((np.asarray(p.input_ids) == ord("y")).sum()) >= 50
             self.seq[j] = [] if long_one else list(b"OK") + [CFG.eos_token_ids[0]]
             self.hist[j], self.fin[j] = [], False
@@ -290,3 +291,28 @@ def test_continuous_mode_engine_failure_is_500_and_the_server_recovers():
     status, body = srv.chat_completions({"messages": [{"role": "user", "content": "x"}]})
     srv.close()
     assert status == 200 and body["choices"][0]["message"]["content"] == "OK"
+
+
+def test_temperature_and_seed_reach_the_engine(cserver):
+    """temperature > 0 -> the page carries it with the request's seed (or a drawn one); 0 / absent -> greedy page."""
+    msg = [{"role": "user", "content": "x"}]
+    assert cserver.engine.sampling is True                      # the slot graph carries the sampling pass
+    for req in ({"messages": msg, "temperature": 0.1, "seed": 77}, {"messages": msg, "temperature": 0.7},
+                {"messages": msg, "temperature": 0.0, "seed": 5}, {"messages": msg}):
+        assert cserver.chat_completions(req)[0] == 200
+    a, b, c, d = cserver.engine.pages[-4:]
+    assert (a.temperature, a.seed) == (pytest.approx(0.1), 77)
+    assert b.temperature == pytest.approx(0.7) and 0 <= b.seed < 2 ** 32
+    assert c.temperature == 0.0 and d.temperature == 0.0
+    for bad in ({"messages": msg, "temperature": -1}, {"messages": msg, "temperature": "hot"}, {"messages": msg, "seed": "x"},
+                {"messages": msg, "temperature": float("nan")}):
+        assert cserver.chat_completions(bad)[0] == 400
+
+
+def test_honor_temperature_off_serves_greedy():
+    eng = FakeSlotEngine()
+    srv = S.LocalServer(eng, S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None, continuous=True, max_tokens_cap=8,
+                        chunk=2, honor_temperature=False)
+    assert srv.chat_completions({"messages": [{"role": "user", "content": "x"}], "temperature": 0.9})[0] == 200
+    srv.close()
+    assert eng.sampling is False and eng.pages[-1].temperature == 0.0
