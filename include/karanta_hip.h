@@ -284,6 +284,20 @@ int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16*
 int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split,
                          kr_stream s);
 
+/* GPU image front end.  kr_image_resize_bicubic_u8: HWC uint8 RGB [h][w][3] -> [rh][rw][3], bit-identical to
+ * PIL's Image.resize(..., BICUBIC) (the HF PIL processor's resize, image_processing_pil_qwen2_vl.py:126-150):
+ * horizontal pass then vertical pass of Pillow's 8-bit resample with the host-built integer tables
+ * (image_processing.resample_tables: bounds [out][2] = (first input index, taps), coeffs [out][ksize], 22
+ * fractional bits); an axis whose size does not change is skipped (tables may be NULL), tmp [h][rw][3] is needed
+ * when both change.  kr_image_normalize_patchify: x/255 -> (x - mean) / std in fp32 (mean3 / std3 are HOST
+ * arrays of 3 floats) written as pixel_values [gh*gw][3*temporal*patch*patch] in the processor's patch order
+ * (:152-187, :226-229). */
+int kr_image_resize_bicubic_u8(const uint8_t* src, int h, int w, uint8_t* dst, int rh, int rw, uint8_t* tmp,
+                               const int32_t* h_bounds, const int32_t* h_coeffs, int h_ksize,
+                               const int32_t* v_bounds, const int32_t* v_coeffs, int v_ksize, kr_stream s);
+int kr_image_normalize_patchify(const uint8_t* img, int rh, int rw, const float* mean3, const float* std3,
+                                int patch, int merge, int temporal, float* out, kr_stream s);
+
 /* Temperature sampling as an argmax (Gumbel-max): per row b, partial argmax over n_part vocabulary slices of
  * logits[b][i] / T_b + G(seed_b, n_b, i), n_b = ctx_len[b] + 1 - prompt_len[b] (index of the token being
  * generated), G = -ln(-ln(u)) from a counter-based hash (definition in kr_decode.hip, restated in the oracle);

@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import image_processing as IP
 from . import positions as POS
 from ._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8,
                    KarantaHipError, lib, ptr)
@@ -158,6 +159,7 @@ class PageRequest:
     grids: List[Tuple[int, int, int]] = field(default_factory=list)
     temperature: float = 0.0                   # 0: greedy; > 0: Gumbel-max sampling (kr_gumbel_argmax)
     seed: int = 0                              # the sampler is counter-based: (seed, token index) fixes every draw
+    images: Optional[List[np.ndarray]] = None  # instead of pixel_values: HWC uint8 RGB pages for the GPU front end
 
 
 @dataclass
@@ -188,6 +190,7 @@ class Engine:
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
         self._ignore_eos = self._freeze_finished = self._want_logits = self._sampling = False
+        self._resample_cache: Dict[tuple, tuple] = {}   # (h, w, rh, rw) -> device tables of the GPU image front end
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
         self._prefetch_mode = int(os.environ.get("KARANTA_PREFETCH", "0"))
@@ -365,6 +368,87 @@ class Engine:
                 self._vit_cache.clear()
             self._vit_cache[key] = hit
         return hit
+
+    # ------------------------------------------------------------------ GPU image front end
+    def patches_from_images(self, images: Sequence[np.ndarray], min_pixels: int = IP.MIN_PIXELS,
+                            max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT,
+                            grids: Optional[Sequence[Sequence[int]]] = None):
+        """HWC uint8 RGB pages -> (pixel_values fp32 [n, 1176] resident in HBM, grids): smart_resize on the host
+        (integers), PIL-identical bicubic resize, normalisation and patch order on the GPU
+        (kr_image_resize_bicubic_u8 / kr_image_normalize_patchify).  Same numbers as
+        image_processing.image_to_patches, bit for bit, without the host resample and with 3 bytes per pixel
+        crossing PCIe instead of 2 x 1176 floats per patch.  ``grids`` (one (1, gh, gw) per image): resize to exactly
+        gh x gw patches — what the prompt's placeholders were counted for — instead of running smart_resize here."""
+        v, L, s, dev = self.cfg.vision, self.L, self.s, self.device
+        unit = v.patch_size * v.spatial_merge_size
+        metas, total = [], 0
+        if grids is not None and len(grids) != len(images):
+            raise KarantaHipError(f"{len(images)} images but {len(grids)} grids")
+        for k, im in enumerate(images):
+            im = np.asarray(im)
+            if im.ndim == 2:
+                im = np.stack([im] * 3, axis=-1)
+            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise KarantaHipError("images must be HWC uint8 RGB arrays")
+            h, w = int(im.shape[0]), int(im.shape[1])
+            if grids is not None:
+                g = [int(x) for x in grids[k]]
+                if g[0] != 1 or g[1] % v.spatial_merge_size or g[2] % v.spatial_merge_size or min(g[1:]) < 1:
+                    raise KarantaHipError(f"image grid {tuple(g)} is not (1, even, even)")
+                rh, rw = g[1] * v.patch_size, g[2] * v.patch_size
+            else:
+                rh, rw = IP.smart_resize(h, w, unit, min_pixels, max_pixels)
+            metas.append((np.ascontiguousarray(im), h, w, rh, rw))
+            total += (rh // v.patch_size) * (rw // v.patch_size)
+        out = torch.empty(total, v.patch_dim, dtype=torch.float32, device=dev)
+        mean = (C.c_float * 3)(*[float(x) for x in IP.CLIP_MEAN])
+        std = (C.c_float * 3)(*[float(x) for x in IP.CLIP_STD])
+        grids, off = [], 0
+        with torch.cuda.stream(self.stream):
+            for im, h, w, rh, rw in metas:
+                src = torch.from_numpy(im).to(dev)
+                key = (h, w, rh, rw)
+                tabs = self._resample_cache.get(key)
+                if tabs is None:
+                    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                    hb, hk = IP.resample_tables(w, rw) if rw != w else (None, None)
+                    vb, vk = IP.resample_tables(h, rh) if rh != h else (None, None)
+                    tabs = tuple(None if a is None else t_(a) for a in (hb, hk, vb, vk))
+                    if len(self._resample_cache) > 64:
+                        self._resample_cache.clear()
+                    self._resample_cache[key] = tabs
+                hb, hk, vb, vk = tabs
+                dst = torch.empty(rh, rw, 3, dtype=torch.uint8, device=dev)
+                tmp = torch.empty(h, rw, 3, dtype=torch.uint8, device=dev) if (rw != w and rh != h) else None
+                L.kr_image_resize_bicubic_u8(ptr(src), h, w, ptr(dst), rh, rw, ptr(tmp), ptr(hb), ptr(hk),
+                                             hk.shape[1] if hk is not None else 0, ptr(vb), ptr(vk),
+                                             vk.shape[1] if vk is not None else 0, s)
+                n = (rh // v.patch_size) * (rw // v.patch_size)
+                L.kr_image_normalize_patchify(ptr(dst), rh, rw, mean, std, v.patch_size, v.spatial_merge_size,
+                                              v.temporal_patch_size, ptr(out[off:]), s)
+                grids.append((1, rh // v.patch_size, rw // v.patch_size))
+                off += n
+        return out, grids
+
+    def _pixels_for(self, pages: Sequence["PageRequest"], pixel_values_device):
+        """The pixel source of a batch of pages: caller-resident patches, the GPU front end (pages with `images`),
+        or the pages' host arrays."""
+        if pixel_values_device is not None:
+            return pixel_values_device
+        with_images = [p for p in pages if p.images]
+        if with_images:
+            if any(p.pixel_values is not None and len(p.pixel_values) for p in pages):
+                raise KarantaHipError("a batch mixes pages with `images` and pages with `pixel_values`")
+            for p in pages:
+                if len(p.images or []) != len(p.grids):
+                    raise KarantaHipError(f"a page has {len(p.images or [])} images but {len(p.grids)} grids")
+            pix, _ = self.patches_from_images([im for p in pages for im in (p.images or [])],
+                                              grids=[g for p in pages for g in p.grids])
+            return pix
+        pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
+        if not pvs:
+            return None
+        return np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0]
 
     def vit_forward(self, pixel_values, grids: Sequence[Sequence[int]]) -> torch.Tensor:
         """Qwen2VisionTransformerPretrainedModel.forward (TF:700-731).  ``pixel_values`` is fp32
@@ -756,12 +840,9 @@ class Engine:
             self._graphs.clear()
         grids = [g for p in pages for g in p.grids]
         n_img_tok = 0
-        if pixel_values_device is not None:
-            n_img_tok = self.vit_forward(pixel_values_device, grids).shape[0]
-        else:
-            pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
-            if pvs:
-                n_img_tok = self.vit_forward(np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0], grids).shape[0]
+        pix = self._pixels_for(pages, pixel_values_device)
+        if pix is not None:
+            n_img_tok = self.vit_forward(pix, grids).shape[0]
         self.stream.synchronize()
         t1 = time.perf_counter()
         lens = self.prefill(pages, n_img_tok)
@@ -844,10 +925,8 @@ class Engine:
     def admit(self, pages: Sequence[PageRequest], slots: Sequence[int]) -> List[int]:
         """ViT + prefill of new requests into idle slots; their first token is sampled.  Returns prompt lengths."""
         grids = [g for p in pages for g in p.grids]
-        pvs = [p.pixel_values for p in pages if p.pixel_values is not None and len(p.pixel_values)]
-        n_img_tok = 0
-        if pvs:
-            n_img_tok = self.vit_forward(np.concatenate(pvs, 0) if len(pvs) > 1 else pvs[0], grids).shape[0]
+        pix = self._pixels_for(pages, None)
+        n_img_tok = self.vit_forward(pix, grids).shape[0] if pix is not None else 0
         return self.prefill(pages, n_img_tok, slots=slots)
 
     def decode_steps(self, n: int):

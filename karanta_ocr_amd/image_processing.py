@@ -81,6 +81,60 @@ def image_to_patches(img, min_pixels: int = MIN_PIXELS, max_pixels: int = MAX_PI
     return pv, (1, gh, gw)
 
 
+# ----------------------------------------------------------------------------- device front end: coefficient tables
+# PIL's resize (what the HF PIL processor calls, image_processing_pil_qwen2_vl.py:126-150) is a separable
+# convolution in fixed point: per output coordinate a window [xmin, xmin + n) of the input and n integer weights
+# (Pillow src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc; 22 fractional bits for 8-bit
+# images), horizontal pass into a uint8 image, then vertical pass.  The tables are tiny and are built here in the
+# same double arithmetic; kr_image_resize_bicubic_u8 applies them on the GPU, bit-identical to PIL.
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_tables(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(bounds int32 [out, 2] = (first input index, taps), coeffs int32 [out, ksize]) of PIL's bicubic resample
+    of one axis from in_size to out_size (box = the whole axis)."""
+    support = 2.0
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = support * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    coeffs = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        bounds[xx] = (xmin, xmax)
+        for x, w in enumerate(k):   # C: (int)(+-0.5 + w * (1 << PRECISION_BITS)), truncation toward zero
+            v = w * (1 << PRECISION_BITS)
+            coeffs[xx, x] = int(-0.5 + v) if w < 0 else int(0.5 + v)
+    return bounds, coeffs
+
+
 def batch_patches(images: Sequence, **kw) -> Tuple[np.ndarray, List[Tuple[int, int, int]]]:
     pvs, grids = [], []
     for im in images:

@@ -110,7 +110,8 @@ class SlotScheduler:
         while self.waiting and len(batch) < len(free):
             r = self.waiting[0]
             n_tok = int(len(r.page.input_ids))
-            n_patch = int(len(r.page.pixel_values)) if getattr(r.page, "pixel_values", None) is not None else 0
+            n_patch = sum(int(np.prod(g)) for g in getattr(r.page, "grids", None) or [])   # from the grids: pages may
+            #                                                    carry uint8 images (GPU front end) instead of patches
             over_tok = tok_budget is not None and n_tok > tok_budget
             over_patch = patch_budget is not None and n_patch > patch_budget
             if over_tok or over_patch:

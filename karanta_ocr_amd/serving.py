@@ -88,6 +88,7 @@ class ParsedRequest:
     model: str
     temperature: float = 0.0
     seed: Optional[int] = None      # None: the server draws one per request
+    images: Optional[List[np.ndarray]] = None   # device_images front end: decoded HWC uint8 pages instead of pixel_values
 
 
 class ChatFrontend:
@@ -99,9 +100,12 @@ class ChatFrontend:
     /root/reference/karanta/data/utils.py:283-297)."""
 
     def __init__(self, cfg: ModelConfig, tokenizer, min_pixels: int = IP.MIN_PIXELS,
-                 max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT, max_model_len: int = 16384):
+                 max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT, max_model_len: int = 16384, device_images: bool = False):
         self.cfg, self.tok = cfg, tokenizer
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
+        # True: only decode the image here; the engine resizes / normalises / patchifies it on the GPU
+        # (Engine.patches_from_images, bit-identical to the host path) and 3 bytes per pixel cross PCIe
+        self.device_images = bool(device_images)
         self.max_model_len = max_model_len  # reference --max_model_len default (pipeline.py:1225-1230)
 
     def _turn(self, role: str, body: List[int]) -> List[int]:
@@ -116,7 +120,7 @@ class ChatFrontend:
         if max_tokens < 1:
             raise BadRequest("max_tokens must be >= 1")
         ids: List[int] = []
-        pvs, grids = [], []
+        pvs, grids, images = [], [], []
         if req["messages"][0].get("role") != "system":
             ids += self._turn("system", self.tok.encode(DEFAULT_SYSTEM))
         for msg in req["messages"]:
@@ -137,8 +141,18 @@ class ChatFrontend:
                         img = IP.decode_data_url(url)
                     except Exception as e:  # undecodable image -> 400, like vLLM
                         raise BadRequest(f"cannot decode image: {e}") from e
-                    pv, grid = IP.image_to_patches(img, self.min_pixels, self.max_pixels)
-                    pvs.append(pv)
+                    if self.device_images:
+                        u8 = np.asarray(img.convert("RGB"), dtype=np.uint8)
+                        unit = self.cfg.vision.patch_size * self.cfg.vision.spatial_merge_size
+                        try:
+                            rh, rw = IP.smart_resize(u8.shape[0], u8.shape[1], unit, self.min_pixels, self.max_pixels)
+                        except ValueError as e:
+                            raise BadRequest(str(e)) from e
+                        grid = (1, rh // self.cfg.vision.patch_size, rw // self.cfg.vision.patch_size)
+                        images.append(u8)
+                    else:
+                        pv, grid = IP.image_to_patches(img, self.min_pixels, self.max_pixels)
+                        pvs.append(pv)
                     grids.append(grid)
                     n_tok = grid[0] * grid[1] * grid[2] // (self.cfg.vision.spatial_merge_size ** 2)
                     body += [self.cfg.vision_start_token_id] + [self.cfg.image_token_id] * n_tok + [self.cfg.vision_end_token_id]
@@ -156,7 +170,7 @@ class ChatFrontend:
         if not (0.0 <= temperature <= 100.0):   # NaN fails both comparisons
             raise BadRequest("temperature must be in [0, 100]")
         return ParsedRequest(np.asarray(ids, np.int64), np.concatenate(pvs, 0) if pvs else None, grids, max_tokens,
-                             str(req.get("model", "karantaocr")), temperature, seed)
+                             str(req.get("model", "karantaocr")), temperature, seed, images or None)
 
 
 # ----------------------------------------------------------------------------- in-process server
@@ -262,10 +276,11 @@ class LocalServer:
     def _page(self, r: ParsedRequest):
         from .engine import PageRequest
         import random
+        page = PageRequest(r.input_ids, r.pixel_values, r.grids, images=getattr(r, "images", None))
         if self.honor_temperature and r.temperature > 0:
-            seed = r.seed if r.seed is not None else random.getrandbits(32)
-            return PageRequest(r.input_ids, r.pixel_values, r.grids, temperature=r.temperature, seed=seed)
-        return PageRequest(r.input_ids, r.pixel_values, r.grids)
+            page.temperature = r.temperature
+            page.seed = r.seed if r.seed is not None else random.getrandbits(32)
+        return page
 
     def _finish(self, s: Dict[str, Any], toks, reason: str):
         mt = s["req"].max_tokens

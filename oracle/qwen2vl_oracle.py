@@ -464,6 +464,28 @@ def embed_and_scatter(input_ids: np.ndarray, image_embeds: Optional[np.ndarray],
     return emb
 
 
+def resize_bicubic_u8(img: np.ndarray, out_h: int, out_w: int, tables) -> np.ndarray:
+    """PIL's ``Image.resize(..., BICUBIC)`` on an HWC uint8 image, restated (Pillow src/libImaging/Resample.c:
+    ImagingResampleHorizontal_8bpc then ImagingResampleVertical_8bpc; an axis whose size does not change is not
+    resampled).  ``tables(in_size, out_size)`` -> (bounds, coeffs): the build's image_processing.resample_tables."""
+    def one_axis(a, out_size):            # resamples axis 1 of [rows, in_size, C]
+        bounds, coeffs = tables(a.shape[1], out_size)
+        out = np.empty((a.shape[0], out_size, a.shape[2]), np.uint8)
+        a64 = a.astype(np.int64)
+        for xx in range(out_size):
+            x0, n = int(bounds[xx, 0]), int(bounds[xx, 1])
+            ss = (a64[:, x0:x0 + n, :] * coeffs[xx, :n].astype(np.int64)[None, :, None]).sum(1) + (1 << 21)
+            out[:, xx, :] = np.clip(ss >> 22, 0, 255).astype(np.uint8)
+        return out
+    img = np.asarray(img, np.uint8)
+    h, w, _ = img.shape
+    if out_w != w:
+        img = one_axis(img, out_w)
+    if out_h != h:
+        img = one_axis(img.transpose(1, 0, 2), out_h).transpose(1, 0, 2)
+    return np.ascontiguousarray(img)
+
+
 def _mix32(x: np.ndarray) -> np.ndarray:
     x = np.asarray(x, np.uint64) & 0xFFFFFFFF
     x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & 0xFFFFFFFF

@@ -244,3 +244,29 @@ def test_sampled_generation_matches_oracle(engines, tiny_models, name):
                                             return_logits=True, temperature=temp, seed=seed)
         n = compare_tokens(res.tokens[k], ref_tok[0], ref_sc[0], tol)
         assert n >= 3, f"only {n} sampled tokens could be checked"
+
+
+@pytest.mark.gpu
+def test_gpu_image_front_end_end_to_end(engines, tiny_models):
+    """Pages handed over as uint8 images (GPU resize / normalise / patchify) give the pixel_values and the tokens of
+    the host PIL path, exactly; grids are checked against the prompt's."""
+    cfg, w, P = tiny_models["tiny"]
+    eng = engines["tiny"]
+    imgs = [IP.synthetic_page(60, 100, 150), IP.synthetic_page(61, 56, 84), IP.synthetic_page(62, 131, 97)]
+    pages_host, pages_dev = [], []
+    for im in imgs:
+        pv, grid = IP.image_to_patches(im, max_pixels=28 * 28 * 12)      # forces a down-scale on the larger pages
+        T = grid[1] * grid[2] // 4
+        ids = np.concatenate([[9, cfg.vision_start_token_id], [cfg.image_token_id] * T, [cfg.vision_end_token_id, 3]]).astype(np.int64)
+        pages_host.append(PageRequest(ids, pv, [grid]))
+        pages_dev.append(PageRequest(ids, None, [grid], images=[im]))
+    pix, grids = eng.patches_from_images(imgs, max_pixels=28 * 28 * 12)
+    assert grids == [p.grids[0] for p in pages_host]
+    np.testing.assert_array_equal(pix.cpu().numpy(), np.concatenate([p.pixel_values for p in pages_host], 0))
+    a = eng.generate(pages_host, 8, ignore_eos=True)
+    b = eng.generate(pages_dev, 8, ignore_eos=True)          # sizes come from the pages' grids
+    for x, y in zip(a.tokens, b.tokens):
+        np.testing.assert_array_equal(x, y)
+    from karanta_ocr_amd._lib import KarantaHipError
+    with pytest.raises(KarantaHipError, match="images but"):
+        eng.generate([PageRequest(pages_dev[0].input_ids, None, pages_dev[0].grids, images=[imgs[0], imgs[1]])], 2)

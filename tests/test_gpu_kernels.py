@@ -1014,6 +1014,46 @@ def test_linear_narrow_rope_kv(L, H, KVH, K, parts):
     np.testing.assert_array_equal(gv, ref_v_all)
 
 
+@pytest.mark.parametrize("h,w,rh,rw", [(100, 160, 56, 84), (60, 90, 140, 112), (308, 200, 308, 140), (56, 84, 56, 84),
+                                       (17, 400, 28, 420), (1024, 1024, 980, 980)])
+def test_image_front_end_bit_exact_vs_pil_path(L, h, w, rh, rw):
+    """kr_image_resize_bicubic_u8 == PIL BICUBIC (uint8, bit for bit); kr_image_normalize_patchify == the host
+    processor path's fp32 pixel_values (bit for bit: one rounding per operation, same patch order)."""
+    from PIL import Image
+    from karanta_ocr_amd import image_processing as IP
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    src = torch.from_numpy(img).to(DEV)
+    dst = torch.zeros(rh, rw, 3, dtype=torch.uint8, device=DEV)
+    tmp = torch.zeros(h, rw, 3, dtype=torch.uint8, device=DEV)
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    hb, hk = (t_(a) for a in IP.resample_tables(w, rw)) if rw != w else (None, None)
+    vb, vk = (t_(a) for a in IP.resample_tables(h, rh)) if rh != h else (None, None)
+    L.kr_image_resize_bicubic_u8(ptr(src), h, w, ptr(dst), rh, rw, ptr(tmp), ptr(hb), ptr(hk), hk.shape[1] if hk is not None else 0,
+                                 ptr(vb), ptr(vk), vk.shape[1] if vk is not None else 0, 0)
+    torch.cuda.synchronize()
+    ref = np.asarray(Image.fromarray(img, "RGB").resize((rw, rh), resample=Image.BICUBIC)) if (rh, rw) != (h, w) else img
+    np.testing.assert_array_equal(dst.cpu().numpy(), ref)
+    # normalise + patchify of the resized page vs the host processor path on the original page
+    gh, gw = rh // 14, rw // 14
+    out = torch.full((gh * gw, 1176), 7.0, dtype=torch.float32, device=DEV)
+    mean = (C.c_float * 3)(*[float(x) for x in IP.CLIP_MEAN]); std = (C.c_float * 3)(*[float(x) for x in IP.CLIP_STD])
+    L.kr_image_normalize_patchify(ptr(dst), rh, rw, mean, std, 14, 2, 2, ptr(out), 0)
+    torch.cuda.synchronize()
+    pv, grid = IP.image_to_patches(ref, min_pixels=1, max_pixels=10 ** 9)    # ref is already rh x rw: no second resize
+    assert grid == (1, gh, gw)
+    np.testing.assert_array_equal(out.cpu().numpy(), pv)
+
+
+def test_image_front_end_rejects_bad_geometry(L):
+    x = torch.zeros(56, 56, 3, dtype=torch.uint8, device=DEV); o = torch.zeros(16, 1176, device=DEV)
+    mean = (C.c_float * 3)(0, 0, 0); std = (C.c_float * 3)(1, 1, 1)
+    with pytest.raises(KarantaHipError):
+        L.kr_image_normalize_patchify(ptr(x), 50, 56, mean, std, 14, 2, 2, ptr(o), 0)
+    with pytest.raises(KarantaHipError):     # both axes change but no tmp / tables
+        L.kr_image_resize_bicubic_u8(ptr(x), 56, 56, ptr(x), 28, 28, 0, 0, 0, 0, 0, 0, 0, 0)
+
+
 def test_gumbel_argmax_matches_oracle_noise(L):
     """kr_gumbel_argmax partials against the oracle's sample_scores: same counter-based noise (integer hash bit-exact,
     the two logs within float rounding), T = 0 rows untouched, ties to the lowest index, sampled frequencies follow

@@ -191,3 +191,20 @@ def test_pack_w16x64_layout():
     np.testing.assert_array_equal(unpack_w16x64(pack_w16x64(w)), w)
     with pytest.raises(ValueError):
         pack_w16x64(np.zeros((8, 64), np.float32))
+
+
+def test_resample_tables_reproduce_pil_bicubic():
+    """The GPU image front end's integer tables + the oracle's two-pass restatement == PIL's BICUBIC resize, bit for
+    bit (down- and up-scaling, one axis unchanged, both unchanged)."""
+    from PIL import Image
+    from karanta_ocr_amd import image_processing as IP
+    from oracle import qwen2vl_oracle as O
+    rng = np.random.default_rng(0)
+    for (h, w, rh, rw) in [(100, 160, 56, 84), (60, 90, 140, 112), (300, 200, 300, 140), (37, 53, 37, 53), (17, 400, 28, 420),
+                           (512, 384, 476, 364)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img, "RGB").resize((rw, rh), resample=Image.BICUBIC))
+        np.testing.assert_array_equal(O.resize_bicubic_u8(img, rh, rw, IP.resample_tables), ref)
+    b, k = IP.resample_tables(1024, 980)
+    assert b.shape == (980, 2) and k.shape[0] == 980 and (k.sum(1) - (1 << 22)).__abs__().max() <= k.shape[1]
+    assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= 1024).all()

@@ -9,7 +9,7 @@ class Page:
     def __init__(self, ids, n_patches=0):
         self.input_ids = np.asarray(ids)
         self.pixel_values = np.zeros((n_patches, 4), np.float32) if n_patches else None
-        self.grids = []
+        self.grids = [(1, 1, n_patches)] if n_patches else []
 
 
 class FakeEngine:
@@ -141,3 +141,12 @@ def test_argument_checks():
     sch = SlotScheduler(eng, 4)
     with pytest.raises(ValueError):
         sch.submit(SlotRequest(Page([0]), 0))
+
+
+def test_patch_budget_counts_grids():
+    eng = FakeEngine(2, SCRIPT, max_patches=10)
+    sch = SlotScheduler(eng, max_tokens_cap=8, chunk=2)
+    res = sch.run([SlotRequest(Page([0], n_patches=6), 4, "a"), SlotRequest(Page([0], n_patches=6), 4, "b"),
+                   SlotRequest(Page([0], n_patches=11), 4, "big")])
+    assert [e[1] for e in eng.log if e[0] == "admit"][0] == (0,)      # 6 + 6 > 10 patches: one page per admission
+    assert res[0].error is None and res[1].error is None and "does not fit" in res[2].error

@@ -316,3 +316,20 @@ def test_honor_temperature_off_serves_greedy():
     assert srv.chat_completions({"messages": [{"role": "user", "content": "x"}], "temperature": 0.9})[0] == 200
     srv.close()
     assert eng.sampling is False and eng.pages[-1].temperature == 0.0
+
+
+def test_device_images_front_end_hands_over_uint8_pages():
+    """device_images=True: the request's image stays a decoded uint8 page (the engine does the rest on the GPU); the
+    prompt has the same placeholders as the host-patch path."""
+    host = S.ChatFrontend(CFG, S.ByteTokenizer(CFG))
+    dev = S.ChatFrontend(CFG, S.ByteTokenizer(CFG), device_images=True)
+    req = {"messages": vision_message(h=100, w=150), "max_tokens": 4}
+    a, b = host.parse(req), dev.parse(req)
+    np.testing.assert_array_equal(a.input_ids, b.input_ids)
+    assert a.grids == b.grids and b.pixel_values is None and a.images is None
+    assert len(b.images) == 1 and b.images[0].dtype == np.uint8 and b.images[0].shape == (100, 150, 3)
+    eng = FakeSlotEngine()
+    srv = S.LocalServer(eng, dev, log=lambda *_: None, continuous=True, max_tokens_cap=8, chunk=2)
+    assert srv.chat_completions(req)[0] == 200
+    srv.close()
+    assert eng.pages[-1].images[0].shape == (100, 150, 3) and eng.pages[-1].pixel_values is None
