@@ -47,7 +47,9 @@ typedef uint16_t kr_bf16;
 #define KR_EPI_QUICK_GELU 1 /* x*sigmoid(1.702x): ViT fc1, TF:293-301 */
 #define KR_EPI_GELU_ERF 2   /* exact GELU: PatchMerger, TF:277-290 */
 #define KR_EPI_SILU_MUL 3   /* silu(gate)*up with gate/up rows interleaved in 16-row groups: Qwen2MLP, TF:453-466 */
-#define KR_EPI_SILU_MUL8 4  /* same, interleaved in 8-row groups (g0..g7,u0..u7,g8..): one 16-row MFMA tile = 8 features */
+#define KR_EPI_SILU_MUL8 4  /* same, interleaved in 8-row groups (g0..g7,u0..u7,g8..): one 16-row MFMA tile = 8 features;
+                             * kr_gemm_bf16 takes an optional bias here, interleaved like the rows (the biased SwiGLU
+                             * MLP of the Qwen2.5-VL vision blocks, TF25:85-97) */
 
 /* ------------------------------------------------------------------ library / device */
 int kr_version(void);

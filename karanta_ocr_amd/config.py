@@ -23,6 +23,15 @@ class VisionConfig:
     temporal_patch_size: int = 2
     in_channels: int = 3
     hidden_size: int = 1536  # merger output = decoder width
+    # "qwen2": LayerNorm + fc1/QuickGELU/fc2, full attention per image (Qwen2-VL).
+    # "qwen2_5": RMSNorm + biased SwiGLU MLP of width `intermediate_size`, attention inside `window_size`-pixel
+    # windows except in the `fullatt_block_indexes` blocks, tokens reordered window by window (Qwen2.5-VL — the
+    # family of the reference's own fine-tunes, configs/training/ocr/karanta_set_qwen_2_5_3B_vl.yaml:2, and of
+    # olmOCR-7B-0725, karanta/constants.py:22-24).
+    variant: str = "qwen2"
+    intermediate_size: int = 0
+    window_size: int = 112
+    fullatt_block_indexes: Tuple[int, ...] = ()
 
     @property
     def head_dim(self) -> int:
@@ -30,7 +39,17 @@ class VisionConfig:
 
     @property
     def mlp_dim(self) -> int:
-        return self.embed_dim * self.mlp_ratio
+        return self.intermediate_size if self.variant == "qwen2_5" else self.embed_dim * self.mlp_ratio
+
+    @property
+    def mlp_dim_padded(self) -> int:
+        """MLP width rounded up to the GEMM's BK = 64 (Qwen2.5-VL: 3420 -> 3456; the padding rows / columns are zero)."""
+        return (self.mlp_dim + 63) // 64 * 64
+
+    @property
+    def window_merge_units(self) -> int:
+        """Side of an attention window in merged (2x2 patch) units."""
+        return self.window_size // self.spatial_merge_size // self.patch_size
 
     @property
     def patch_dim(self) -> int:
@@ -163,8 +182,32 @@ TINY_GQA = replace(
     ),
 )
 
+_VISION_25 = dict(depth=32, embed_dim=1280, num_heads=16, variant="qwen2_5", intermediate_size=3420, window_size=112,
+                  fullatt_block_indexes=(7, 15, 23, 31))
+QWEN2_5_VL_3B = ModelConfig(
+    name="Qwen2.5-VL-3B",
+    vision=VisionConfig(hidden_size=2048, **_VISION_25),
+    text=TextConfig(hidden_size=2048, intermediate_size=11008, num_layers=36, num_heads=16, num_kv_heads=2,
+                    vocab_size=151936, tie_word_embeddings=True),
+)
+QWEN2_5_VL_7B = ModelConfig(
+    name="Qwen2.5-VL-7B",
+    vision=VisionConfig(hidden_size=3584, **_VISION_25),
+    text=TextConfig(hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28, num_kv_heads=4,
+                    vocab_size=152064, tie_word_embeddings=False),
+)
+
+# Qwen2.5-VL in test size: 4 vision blocks (1 and 3 full attention, 0 and 2 windowed), 56-pixel windows (2 x 2 merged
+# units = 16 patches), an MLP width that needs the zero padding (200 -> 256).
+TINY_25 = replace(
+    TINY,
+    name="tiny-2.5",
+    vision=VisionConfig(depth=4, embed_dim=320, num_heads=4, hidden_size=256, variant="qwen2_5", intermediate_size=200,
+                        window_size=56, fullatt_block_indexes=(1, 3)),
+)
+
 CONFIGS: Dict[str, ModelConfig] = {
-    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, TINY, TINY_GQA)
+    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, QWEN2_5_VL_3B, QWEN2_5_VL_7B, TINY, TINY_GQA, TINY_25)
 }
 
 
@@ -188,17 +231,18 @@ def from_hf_config_dict(d: dict, name: str = "hf") -> ModelConfig:
         mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))),
         tie_word_embeddings=bool(d.get("tie_word_embeddings", t.get("tie_word_embeddings", False))),
     )
-    vision = VisionConfig(
-        depth=v["depth"],
-        embed_dim=v["embed_dim"],
-        num_heads=v["num_heads"],
-        mlp_ratio=int(v.get("mlp_ratio", 4)),
-        patch_size=v.get("patch_size", 14),
-        spatial_merge_size=v.get("spatial_merge_size", 2),
-        temporal_patch_size=v.get("temporal_patch_size", 2),
-        in_channels=v.get("in_channels", v.get("in_chans", 3)),
-        hidden_size=v["hidden_size"],
-    )
+    common = dict(depth=v["depth"], num_heads=v["num_heads"], patch_size=v.get("patch_size", 14),
+                  spatial_merge_size=v.get("spatial_merge_size", 2), temporal_patch_size=v.get("temporal_patch_size", 2),
+                  in_channels=v.get("in_channels", v.get("in_chans", 3)))
+    if "fullatt_block_indexes" in v or d.get("model_type") == "qwen2_5_vl":
+        # Qwen2.5-VL names the tower width hidden_size and the merger output out_hidden_size
+        vision = VisionConfig(embed_dim=v["hidden_size"], hidden_size=v.get("out_hidden_size", t["hidden_size"]),
+                              variant="qwen2_5", intermediate_size=v["intermediate_size"],
+                              window_size=v.get("window_size", 112),
+                              fullatt_block_indexes=tuple(v.get("fullatt_block_indexes", (7, 15, 23, 31))), **common)
+    else:
+        vision = VisionConfig(embed_dim=v["embed_dim"], mlp_ratio=int(v.get("mlp_ratio", 4)), hidden_size=v["hidden_size"],
+                              **common)
     eos = d.get("eos_token_id", 151645)
     eos = tuple(eos) if isinstance(eos, (list, tuple)) else (eos, 151643)
     return ModelConfig(

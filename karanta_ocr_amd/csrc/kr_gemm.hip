@@ -123,14 +123,21 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
             // and the matching up rows in lane groups 2,3 (lane ^ 32)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float u[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(acc[nt][mt][j], 32, 64);
                 const int n = n0 + wc * WTN + nt * 16;
+                float g[4], u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = acc[nt][mt][j];
+                if (bias && n < N) {  // bias rows are interleaved like the weight rows: every lane adds its own
+                    const bf16x4 bv = *reinterpret_cast<const bf16x4*>(bias + n + fg * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] += bf2f(bv[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(g[j], 32, 64);
                 if (fg < 2 && n < N && m < M) {
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[nt][mt][j]) * u[j]);
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(g[j]) * u[j]);
                     *reinterpret_cast<bf16x4*>(C + m * ldc + (n >> 1) + fg * 4) = o;
                 }
             }
@@ -254,7 +261,7 @@ extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, con
                          "kr_gemm_bf16: SILU_MUL needs N%%32==0, no bias/residual");
             return launch_gemm<KR_EPI_SILU_MUL>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         case KR_EPI_SILU_MUL8:
-            KR_CHECK_ARG(ldc >= N / 2 && !bias && !residual, "kr_gemm_bf16: SILU_MUL8 takes no bias/residual");
+            KR_CHECK_ARG(ldc >= N / 2 && !residual, "kr_gemm_bf16: SILU_MUL8 takes no residual");
             return launch_gemm<KR_EPI_SILU_MUL8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         default:
             kr_set_error("kr_gemm_bf16: unknown epilogue %d", epilogue);

@@ -70,15 +70,26 @@ class DeviceWeights:
     def _plan(self):
         v, t = self.cfg.vision, self.cfg.text
         self._add("vit.patch", (v.embed_dim, v.patch_dim_padded))
+        v25 = v.variant == "qwen2_5"
         for i in range(v.depth):
             p = f"vit.{i}."
-            self._add(p + "ln1.w", (v.embed_dim,)); self._add(p + "ln1.b", (v.embed_dim,))
+            self._add(p + "ln1.w", (v.embed_dim,))
             self._add(p + "qkv.w", (3 * v.embed_dim, v.embed_dim)); self._add(p + "qkv.b", (3 * v.embed_dim,))
             self._add(p + "proj.w", (v.embed_dim, v.embed_dim)); self._add(p + "proj.b", (v.embed_dim,))
-            self._add(p + "ln2.w", (v.embed_dim,)); self._add(p + "ln2.b", (v.embed_dim,))
-            self._add(p + "fc1.w", (v.mlp_dim, v.embed_dim)); self._add(p + "fc1.b", (v.mlp_dim,))
-            self._add(p + "fc2.w", (v.embed_dim, v.mlp_dim)); self._add(p + "fc2.b", (v.embed_dim,))
-        self._add("vit.merger.ln.w", (v.embed_dim,)); self._add("vit.merger.ln.b", (v.embed_dim,))
+            self._add(p + "ln2.w", (v.embed_dim,))
+            if v25:
+                # biased SwiGLU (TF25:85-97): gate / up fused with rows AND biases interleaved in groups of 8
+                # (KR_EPI_SILU_MUL8), width zero-padded to a multiple of 64 (3420 -> 3456)
+                fp = v.mlp_dim_padded
+                self._add(p + "gate_up.w", (2 * fp, v.embed_dim)); self._add(p + "gate_up.b", (2 * fp,))
+                self._add(p + "down.w", (v.embed_dim, fp)); self._add(p + "down.b", (v.embed_dim,))
+            else:
+                self._add(p + "ln1.b", (v.embed_dim,)); self._add(p + "ln2.b", (v.embed_dim,))
+                self._add(p + "fc1.w", (v.mlp_dim, v.embed_dim)); self._add(p + "fc1.b", (v.mlp_dim,))
+                self._add(p + "fc2.w", (v.embed_dim, v.mlp_dim)); self._add(p + "fc2.b", (v.embed_dim,))
+        self._add("vit.merger.ln.w", (v.embed_dim,))
+        if not v25:
+            self._add("vit.merger.ln.b", (v.embed_dim,))
         self._add("vit.merger.fc1.w", (v.merge_dim, v.merge_dim)); self._add("vit.merger.fc1.b", (v.merge_dim,))
         self._add("vit.merger.fc2.w", (v.hidden_size, v.merge_dim)); self._add("vit.merger.fc2.b", (v.hidden_size,))
         self._add("llm.embed", (t.vocab_size, t.hidden_size))
@@ -117,15 +128,37 @@ class DeviceWeights:
         pad = np.zeros((v.embed_dim, v.patch_dim_padded), np.uint16)
         pad[:, :pe.shape[1]] = pe
         self._put("vit.patch", pad)
+        v25 = v.variant == "qwen2_5"
         for i in range(v.depth):
             s, d = f"{V}blocks.{i}.", f"vit.{i}."
-            for a, b in (("norm1.weight", "ln1.w"), ("norm1.bias", "ln1.b"), ("attn.qkv.weight", "qkv.w"),
-                         ("attn.qkv.bias", "qkv.b"), ("attn.proj.weight", "proj.w"), ("attn.proj.bias", "proj.b"),
-                         ("norm2.weight", "ln2.w"), ("norm2.bias", "ln2.b"), ("mlp.fc1.weight", "fc1.w"),
-                         ("mlp.fc1.bias", "fc1.b"), ("mlp.fc2.weight", "fc2.w"), ("mlp.fc2.bias", "fc2.b")):
+            names = [("norm1.weight", "ln1.w"), ("attn.qkv.weight", "qkv.w"), ("attn.qkv.bias", "qkv.b"),
+                     ("attn.proj.weight", "proj.w"), ("attn.proj.bias", "proj.b"), ("norm2.weight", "ln2.w")]
+            if not v25:
+                names += [("norm1.bias", "ln1.b"), ("norm2.bias", "ln2.b"), ("mlp.fc1.weight", "fc1.w"),
+                          ("mlp.fc1.bias", "fc1.b"), ("mlp.fc2.weight", "fc2.w"), ("mlp.fc2.bias", "fc2.b")]
+            for a, b in names:
                 self._put(d + b, _bits(w[s + a]))
-        for a, b in (("merger.ln_q.weight", "ln.w"), ("merger.ln_q.bias", "ln.b"), ("merger.mlp.0.weight", "fc1.w"),
-                     ("merger.mlp.0.bias", "fc1.b"), ("merger.mlp.2.weight", "fc2.w"), ("merger.mlp.2.bias", "fc2.b")):
+            if v25:
+                ffv, fp, D = v.mlp_dim, v.mlp_dim_padded, v.embed_dim
+                def padded(a, rows):            # zero rows up to the padded width
+                    out = np.zeros((rows,) + a.shape[1:], np.uint16)
+                    out[:a.shape[0]] = a
+                    return out
+                g = padded(_bits(w[s + "mlp.gate_proj.weight"]), fp).reshape(fp // 8, 8, D)
+                u = padded(_bits(w[s + "mlp.up_proj.weight"]), fp).reshape(fp // 8, 8, D)
+                self._put(d + "gate_up.w", np.stack([g, u], 1).reshape(2 * fp, D))
+                gb = padded(_bits(w[s + "mlp.gate_proj.bias"]), fp).reshape(fp // 8, 8)
+                ub = padded(_bits(w[s + "mlp.up_proj.bias"]), fp).reshape(fp // 8, 8)
+                self._put(d + "gate_up.b", np.stack([gb, ub], 1).reshape(2 * fp))
+                dw = np.zeros((D, fp), np.uint16)
+                dw[:, :ffv] = _bits(w[s + "mlp.down_proj.weight"])
+                self._put(d + "down.w", dw)
+                self._put(d + "down.b", _bits(w[s + "mlp.down_proj.bias"]))
+        merger = [("merger.ln_q.weight", "ln.w"), ("merger.mlp.0.weight", "fc1.w"), ("merger.mlp.0.bias", "fc1.b"),
+                  ("merger.mlp.2.weight", "fc2.w"), ("merger.mlp.2.bias", "fc2.b")]
+        if not v25:
+            merger.append(("merger.ln_q.bias", "ln.b"))
+        for a, b in merger:
             self._put("vit.merger." + b, _bits(w[V + a]))
         self._put("llm.embed", _bits(w[Lm + "embed_tokens.weight"]))
         ff = t.intermediate_size
@@ -212,6 +245,9 @@ class Engine:
         N, M, B = self.max_patches, self.max_tokens, self.B
         z = lambda *shape, dtype=BF16: torch.zeros(*shape, dtype=dtype, device=dev)
         nvb = N // 64 + 64  # V^T blocks: every image may add one partial block
+        if v.variant == "qwen2_5":  # windowed blocks: every window starts a V^T block, edge windows are partial ones
+            per_win = (v.window_merge_units * v.spatial_merge_size) ** 2
+            nvb = max(nvb, 2 * (N // max(1, min(64, per_win))) + 64)
         # ViT
         self.v_pix = z(N, v.patch_dim, dtype=torch.float32)
         self.v_in = z(N, v.patch_dim_padded)
@@ -222,7 +258,8 @@ class Engine:
         self.v_k = z(v.num_heads, N, v.head_dim)
         self.v_vt = z(v.num_heads, nvb, v.head_dim, 64)
         self.v_o = z(N, v.embed_dim)
-        self.v_f = z(N, v.mlp_dim)
+        self.v_f = z(N, v.mlp_dim_padded)
+        self.v_perm = None  # Qwen2.5-VL: window-order gather indices live in the per-geometry cache
         self.v_m1 = z(N // 4 + 1, v.merge_dim)
         self._vit_cache = {}
         self.img_embeds = z(N // 4 + 1, t.hidden_size)
@@ -362,8 +399,19 @@ class Engine:
             plan = POS.vit_attn_plan(key)
             cos, sin = POS.vision_rotary_tables(key, v.head_dim, v.spatial_merge_size)
             t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            dplan = lambda pl: (pl, t_(pl.blk_tok0), t_(pl.blk_ntok), t_(pl.blk_k_row0), t_(pl.blk_vt_blk), t_(pl.qblk),
+                                t_(pl.qblk_len))
+            extra = None
+            if v.variant == "qwen2_5":
+                # window order (TF25:430-446): patches move in groups of merge^2; rotary tables move with them;
+                # two attention work lists: windows, and whole images for the fullatt_block_indexes blocks
+                unit = v.spatial_merge_size ** 2
+                order, win_lens = POS.vision_window_order(key, v.spatial_merge_size, v.window_size, v.patch_size)
+                perm = (order[:, None] * unit + np.arange(unit)[None, :]).reshape(-1)      # patch-level gather
+                cos, sin = cos[perm], sin[perm]
+                extra = (t_(perm.astype(np.int32)), t_(np.argsort(order).astype(np.int32)), dplan(POS.segments_attn_plan(win_lens)))
             hit = (plan, t_(cos), t_(sin), t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0),
-                   t_(plan.blk_vt_blk), t_(plan.qblk), t_(plan.qblk_len))
+                   t_(plan.blk_vt_blk), t_(plan.qblk), t_(plan.qblk_len), extra)
             if len(self._vit_cache) > 16:
                 self._vit_cache.clear()
             self._vit_cache[key] = hit
@@ -461,7 +509,7 @@ class Engine:
         if n > self.max_patches:
             raise KarantaHipError(f"{n} patches > max_patches {self.max_patches}")
         with torch.cuda.stream(self.stream):
-            plan, cos_d, sin_d, blk_tok0, blk_ntok, blk_kr, blk_vb, qblk, qlen = self._vit_tables(grids)
+            plan, cos_d, sin_d, blk_tok0, blk_ntok, blk_kr, blk_vb, qblk, qlen, extra = self._vit_tables(grids)
             assert plan.n_tokens == n, (plan.n_tokens, n)
             if isinstance(pixel_values, torch.Tensor):
                 pix = pixel_values
@@ -474,8 +522,10 @@ class Engine:
             L.kr_cast_pad_f32_bf16(ptr(pix), ptr(self.v_in), n, v.patch_dim, v.patch_dim_padded, s)
             self._gemm(self.v_in, w.view("vit.patch"), self.v_x, n)
             nvb_total = self.v_vt.shape[1]
-            if plan.n_vt_blocks > nvb_total:
+            if plan.n_vt_blocks > nvb_total or (extra is not None and extra[2][0].n_vt_blocks > nvb_total):
                 raise KarantaHipError("too many image segments for the V^T buffer")
+            if v.variant == "qwen2_5":
+                return self._vit_blocks_qwen2_5(n, (plan, blk_tok0, blk_ntok, blk_kr, blk_vb, qblk, qlen), cos_d, sin_d, extra)
             for i in range(v.depth):
                 p = f"vit.{i}."
                 L.kr_layernorm(ptr(self.v_x), ptr(w.view(p + "ln1.w")), ptr(w.view(p + "ln1.b")), ptr(self.v_h), n, D, 1e-6, s)
@@ -497,6 +547,42 @@ class Engine:
             merged_in = self.v_h.view(-1)[: T * v.merge_dim].view(T, v.merge_dim)
             self._gemm(merged_in, w.view("vit.merger.fc1.w"), self.v_m1, T, bias=w.view("vit.merger.fc1.b"), epi=EPI_GELU_ERF)
             self._gemm(self.v_m1, w.view("vit.merger.fc2.w"), self.img_embeds, T, bias=w.view("vit.merger.fc2.b"))
+        return self.img_embeds[:T]
+
+    def _vit_blocks_qwen2_5(self, n: int, full, cos_d, sin_d, extra) -> torch.Tensor:
+        """Qwen2_5_VisionTransformerPretrainedModel.forward after the patch embedding (TF25:430-472): tokens gathered
+        into window order, RMSNorm blocks with attention inside the windows (whole images in the
+        fullatt_block_indexes blocks) and the biased SwiGLU MLP, RMSNorm merger, merged tokens scattered back."""
+        v, L, s, w = self.cfg.vision, self.L, self.s, self.w
+        D, H, hd = v.embed_dim, v.num_heads, v.head_dim
+        perm_d, inv_d, win = extra
+        # v_x (image order) -> v_h (window order) -> the blocks run on v_x again
+        L.kr_embed_scatter(ptr(perm_d), ptr(self.v_x), 0, ptr(self.v_h), n, D, s)
+        self.v_x, self.v_h = self.v_h, self.v_x
+        for i in range(v.depth):
+            p = f"vit.{i}."
+            plan, blk_tok0, blk_ntok, blk_kr, blk_vb, qblk, qlen = full if i in v.fullatt_block_indexes else win
+            L.kr_rmsnorm(ptr(self.v_x), D, ptr(w.view(p + "ln1.w")), ptr(self.v_h), n, D, 1e-6, s)
+            self._gemm(self.v_h, w.view(p + "qkv.w"), self.v_qkv, n, bias=w.view(p + "qkv.b"))
+            L.kr_qkv_prep(ptr(self.v_qkv), 3 * D, 0, D, 2 * D, ptr(cos_d), ptr(sin_d),
+                          ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
+                          ptr(self.v_q), self.v_q.stride(0), ptr(self.v_k), self.v_k.stride(0),
+                          ptr(self.v_vt), self.v_vt.stride(0), H, H, hd, s)
+            L.kr_attn_varlen(ptr(self.v_q), ptr(self.v_k), ptr(self.v_vt), ptr(self.v_o), ptr(qblk), ptr(qlen),
+                             plan.qblk.shape[0], self.v_q.shape[1], H, H, hd, self.v_k.stride(0),
+                             self.v_vt.stride(0), hd ** -0.5, 0, s)
+            self._gemm(self.v_o, w.view(p + "proj.w"), self.v_x, n, bias=w.view(p + "proj.b"), res=self.v_x)
+            L.kr_rmsnorm(ptr(self.v_x), D, ptr(w.view(p + "ln2.w")), ptr(self.v_h), n, D, 1e-6, s)
+            self._gemm(self.v_h, w.view(p + "gate_up.w"), self.v_f, n, bias=w.view(p + "gate_up.b"), epi=EPI_SILU_MUL8)
+            self._gemm(self.v_f, w.view(p + "down.w"), self.v_x, n, bias=w.view(p + "down.b"), res=self.v_x)
+        L.kr_rmsnorm(ptr(self.v_x), D, ptr(w.view("vit.merger.ln.w")), ptr(self.v_h), n, D, 1e-6, s)
+        T = n // (v.spatial_merge_size ** 2)
+        merged_in = self.v_h.view(-1)[: T * v.merge_dim].view(T, v.merge_dim)
+        self._gemm(merged_in, w.view("vit.merger.fc1.w"), self.v_m1, T, bias=w.view("vit.merger.fc1.b"), epi=EPI_GELU_ERF)
+        # second GEMM into v_m1's neighbour, then back to image order (reverse_indices, TF25:466-468)
+        tmp = self.v_o.view(-1)[: T * self.cfg.text.hidden_size].view(T, self.cfg.text.hidden_size)
+        self._gemm(self.v_m1, w.view("vit.merger.fc2.w"), tmp, T, bias=w.view("vit.merger.fc2.b"))
+        L.kr_embed_scatter(ptr(inv_d), ptr(tmp), 0, ptr(self.img_embeds), T, self.cfg.text.hidden_size, s)
         return self.img_embeds[:T]
 
     # ------------------------------------------------------------------ prefill

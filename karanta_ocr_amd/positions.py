@@ -156,6 +156,40 @@ def vit_attn_plan(grid_thw: Sequence[Sequence[int]]) -> AttnPlan:
     return make_attn_plan(lens, k_row0, vt0, causal=False)
 
 
+def vision_window_order(grid_thw: Sequence[Sequence[int]], merge: int, window_size: int, patch_size: int):
+    """Qwen2.5-VL window attention (TF25:modeling_qwen2_5_vl.py:430-446, TF:vision_utils.py:130-188): the order in
+    which the merged (merge x merge patch) units are visited window by window, and the window lengths in patches.
+    Windows are window_size // merge // patch_size units on a side, the grid padded right / bottom to whole windows
+    (by a full window when it already divides — those windows are empty and drop out)."""
+    ws = window_size // merge // patch_size
+    if ws < 1:
+        raise ValueError(f"window_size {window_size} is smaller than one merged unit")
+    order: List[np.ndarray] = []
+    win_lens: List[int] = []
+    base = 0
+    for t, h, w in grid_thw:
+        lh, lw = int(h) // merge, int(w) // merge
+        ids = np.arange(int(t) * lh * lw, dtype=np.int64).reshape(int(t), lh, lw)
+        for ti in range(int(t)):
+            for y0 in range(0, lh, ws):          # windows in row-major order, units inside a window row-major
+                for x0 in range(0, lw, ws):
+                    blk = ids[ti, y0:y0 + ws, x0:x0 + ws].reshape(-1)
+                    order.append(blk + base)
+                    win_lens.append(int(blk.size) * merge * merge)
+        base += int(t) * lh * lw
+    return (np.concatenate(order) if order else np.zeros(0, np.int64)), win_lens
+
+
+def segments_attn_plan(lens: Sequence[int]) -> AttnPlan:
+    """Full (non-causal) attention inside consecutive token segments of the given lengths; every segment starts a
+    new 64-token V^T block."""
+    lens = [int(n) for n in lens]
+    k_row0 = np.concatenate([[0], np.cumsum(lens)[:-1]]) if lens else []
+    nb = [(n + 63) // 64 for n in lens]
+    vt0 = np.concatenate([[0], np.cumsum(nb)[:-1]]) if lens else []
+    return make_attn_plan(lens, k_row0, vt0, causal=False)
+
+
 def prefill_attn_plan(prompt_lens: Sequence[int], slots: Sequence[int], kv_heads: int, s_max: int) -> AttnPlan:
     """Causal segments = sequences; keys/values live in the KV cache of the sequence's slot:
     K row0 = slot*kv_heads*s_max (+ head*s_max via the head stride), V^T block0 likewise / 64."""

@@ -51,22 +51,33 @@ def weight_shapes(cfg: ModelConfig) -> Dict[str, tuple]:
     s: Dict[str, tuple] = {}
     s["model.visual.patch_embed.proj.weight"] = (
         v.embed_dim, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size)
+    v25 = v.variant == "qwen2_5"   # RMSNorm (no bias), biased SwiGLU MLP (TF25: modeling_qwen2_5_vl.py:85-97, :294-300)
     for i in range(v.depth):
         p = f"model.visual.blocks.{i}."
         s[p + "norm1.weight"] = (v.embed_dim,)
-        s[p + "norm1.bias"] = (v.embed_dim,)
+        if not v25:
+            s[p + "norm1.bias"] = (v.embed_dim,)
         s[p + "norm2.weight"] = (v.embed_dim,)
-        s[p + "norm2.bias"] = (v.embed_dim,)
+        if not v25:
+            s[p + "norm2.bias"] = (v.embed_dim,)
         s[p + "attn.qkv.weight"] = (3 * v.embed_dim, v.embed_dim)
         s[p + "attn.qkv.bias"] = (3 * v.embed_dim,)
         s[p + "attn.proj.weight"] = (v.embed_dim, v.embed_dim)
         s[p + "attn.proj.bias"] = (v.embed_dim,)
-        s[p + "mlp.fc1.weight"] = (v.mlp_dim, v.embed_dim)
-        s[p + "mlp.fc1.bias"] = (v.mlp_dim,)
-        s[p + "mlp.fc2.weight"] = (v.embed_dim, v.mlp_dim)
-        s[p + "mlp.fc2.bias"] = (v.embed_dim,)
+        if v25:
+            for n in ("gate_proj", "up_proj"):
+                s[p + f"mlp.{n}.weight"] = (v.mlp_dim, v.embed_dim)
+                s[p + f"mlp.{n}.bias"] = (v.mlp_dim,)
+            s[p + "mlp.down_proj.weight"] = (v.embed_dim, v.mlp_dim)
+            s[p + "mlp.down_proj.bias"] = (v.embed_dim,)
+        else:
+            s[p + "mlp.fc1.weight"] = (v.mlp_dim, v.embed_dim)
+            s[p + "mlp.fc1.bias"] = (v.mlp_dim,)
+            s[p + "mlp.fc2.weight"] = (v.embed_dim, v.mlp_dim)
+            s[p + "mlp.fc2.bias"] = (v.embed_dim,)
     s["model.visual.merger.ln_q.weight"] = (v.embed_dim,)
-    s["model.visual.merger.ln_q.bias"] = (v.embed_dim,)
+    if not v25:
+        s["model.visual.merger.ln_q.bias"] = (v.embed_dim,)
     s["model.visual.merger.mlp.0.weight"] = (v.merge_dim, v.merge_dim)
     s["model.visual.merger.mlp.0.bias"] = (v.merge_dim,)
     s["model.visual.merger.mlp.2.weight"] = (v.hidden_size, v.merge_dim)

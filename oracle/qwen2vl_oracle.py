@@ -295,12 +295,105 @@ def mrope_cos_sin(position_ids: np.ndarray, head_dim: int, theta: float,
 # =============================================================================
 
 
+def vision_window_index(grid_thw: Sequence[Sequence[int]], spatial_merge_size: int, window_size: int, patch_size: int):
+    """``get_vision_window_index`` (TF:vision_utils.py:130-188) of Qwen2.5-VL: the order in which the merged
+    (2x2-patch) units are visited window by window, and the cumulative window lengths in PATCHES.  Windows are
+    ``window_size // merge // patch`` merged units on a side; the grid is padded on the right / bottom to a whole
+    number of windows (by a full window when it already divides: those empty windows drop out)."""
+    index_all, cu = [], [0]
+    base = 0
+    ws = window_size // spatial_merge_size // patch_size
+    unit = spatial_merge_size ** 2
+    for t, h, w in grid_thw:
+        lh, lw = h // spatial_merge_size, w // spatial_merge_size
+        idx = np.arange(t * lh * lw).reshape(t, lh, lw)
+        ph, pw = ws - lh % ws, ws - lw % ws
+        nh, nw = (lh + ph) // ws, (lw + pw) // ws
+        pad = np.full((t, lh + ph, lw + pw), -100, np.int64)
+        pad[:, :lh, :lw] = idx
+        pad = pad.reshape(t, nh, ws, nw, ws).transpose(0, 1, 3, 2, 4).reshape(t, nh * nw, ws, ws)
+        seqlens = (pad != -100).sum((2, 3)).reshape(-1)
+        flat = pad.reshape(-1)
+        index_all.append(flat[flat != -100] + base)
+        cu.extend((np.cumsum(seqlens) * unit + cu[-1]).tolist())
+        base += t * lh * lw
+    cu = np.asarray(cu, np.int64)
+    cu = cu[np.concatenate([[True], cu[1:] != cu[:-1]])]      # unique_consecutive
+    return np.concatenate(index_all), cu
+
+
+def _attention_segments(q, k, v, seg, H, hd, scale, pol):
+    n = q.shape[0]
+    o = np.zeros((n, H, hd), dtype=F32)
+    for s in range(len(seg) - 1):
+        a, b = int(seg[s]), int(seg[s + 1])
+        for hh in range(H):  # one 2-D BLAS call per head (numpy's batched matmul is not BLAS-backed)
+            qh, kh, vh = (np.ascontiguousarray(t[a:b, hh]) for t in (q, k, v))
+            sc = (qh @ kh.T).astype(F32, copy=False)
+            sc *= scale
+            pr = pol(softmax_lastdim(sc))
+            o[a:b, hh] = pr @ vh
+    return o
+
+
+def vit_forward_qwen2_5(pixel_values: np.ndarray, grid_thw: Sequence[Sequence[int]], weights: Dict[str, np.ndarray],
+                        vcfg, policy: str = "fp32", return_intermediates: bool = False):
+    """``Qwen2_5_VisionTransformerPretrainedModel.forward`` (TF25 = transformers/models/qwen2_5_vl/
+    modeling_qwen2_5_vl.py:408-472): PatchEmbed -> tokens and rotary tables reordered window by window (units of
+    2x2 patches) -> ``depth`` x Qwen2_5_VLVisionBlock (:294-322: RMSNorm, attention inside the windows except in
+    the ``fullatt_block_indexes`` blocks, biased SwiGLU MLP :85-97) -> PatchMerger with RMSNorm (:137-150) ->
+    merged tokens put back in image order."""
+    pol = _Policy(policy)
+    pre = "model.visual."
+    D, H = vcfg.embed_dim, vcfg.num_heads
+    hd = D // H
+    unit = vcfg.spatial_merge_size ** 2
+    inter = {}
+    x = pol(linear(pol(pixel_values), _w(weights, pre + "patch_embed.proj.weight").reshape(D, -1)))
+    inter["patch_embed"] = x
+    n = x.shape[0]
+    widx, cu_win = vision_window_index(grid_thw, vcfg.spatial_merge_size, vcfg.window_size, vcfg.patch_size)
+    inter["window_index"], inter["cu_window_seqlens"] = widx, cu_win
+    x = x.reshape(n // unit, unit, D)[widx].reshape(n, D)
+    pos = vision_position_ids(grid_thw, vcfg.spatial_merge_size)
+    cos, sin = vision_rotary_cos_sin(pos, hd)
+    cos = cos.reshape(n // unit, unit, -1)[widx].reshape(n, -1)
+    sin = sin.reshape(n // unit, unit, -1)[widx].reshape(n, -1)
+    seg_full = np.cumsum([0] + [t * h * w for t, h, w in grid_thw])
+    scale = F32(hd ** -0.5)
+    eps = 1e-6
+    for li in range(vcfg.depth):
+        p = f"{pre}blocks.{li}."
+        h1 = pol(rms_norm(x, _w(weights, p + "norm1.weight"), eps, pol))
+        qkv = pol(linear(h1, _w(weights, p + "attn.qkv.weight"), _w(weights, p + "attn.qkv.bias"))).reshape(n, 3, H, hd)
+        q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+        q = pol(q * cos[:, None, :] + rotate_half(q) * sin[:, None, :])
+        k = pol(k * cos[:, None, :] + rotate_half(k) * sin[:, None, :])
+        seg = seg_full if li in tuple(vcfg.fullatt_block_indexes) else cu_win
+        o = pol(_attention_segments(q, k, v, seg, H, hd, scale, pol).reshape(n, D))
+        x = pol(x + linear(o, _w(weights, p + "attn.proj.weight"), _w(weights, p + "attn.proj.bias")))
+        h2 = pol(rms_norm(x, _w(weights, p + "norm2.weight"), eps, pol))
+        g = pol(linear(h2, _w(weights, p + "mlp.gate_proj.weight"), _w(weights, p + "mlp.gate_proj.bias")))
+        u = pol(linear(h2, _w(weights, p + "mlp.up_proj.weight"), _w(weights, p + "mlp.up_proj.bias")))
+        a = pol(pol(silu(g)) * u)
+        x = pol(x + linear(a, _w(weights, p + "mlp.down_proj.weight"), _w(weights, p + "mlp.down_proj.bias")))
+        inter[f"block{li}"] = x
+    m = pol(rms_norm(x, _w(weights, pre + "merger.ln_q.weight"), eps, pol)).reshape(-1, D * unit)
+    m = pol(gelu_erf(linear(m, _w(weights, pre + "merger.mlp.0.weight"), _w(weights, pre + "merger.mlp.0.bias"))))
+    m = pol(linear(m, _w(weights, pre + "merger.mlp.2.weight"), _w(weights, pre + "merger.mlp.2.bias")))
+    m = m[np.argsort(widx)]
+    inter["merged"] = m
+    return (m, inter) if return_intermediates else m
+
+
 def vit_forward(pixel_values: np.ndarray, grid_thw: Sequence[Sequence[int]], weights: Dict[str, np.ndarray],
                 vcfg, policy: str = "fp32", return_intermediates: bool = False):
     """``Qwen2VisionTransformerPretrainedModel.forward`` (TF:modeling_qwen2_vl.py:700-731):
     PatchEmbed (:251-274, Conv3d ≡ GEMM) → ``depth`` × Qwen2VLVisionBlock (:425-449) with
     full non-causal attention per image (:342-422) → PatchMerger (:277-290).
     ``vcfg`` is any object with the VisionConfig attributes.  Returns merged ``[T, d]``."""
+    if getattr(vcfg, "variant", "qwen2") == "qwen2_5":
+        return vit_forward_qwen2_5(pixel_values, grid_thw, weights, vcfg, policy, return_intermediates)
     pol = _Policy(policy)
     pre = "model.visual."
     D, H = vcfg.embed_dim, vcfg.num_heads

@@ -15,9 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+GOLDEN_25 = os.path.join(ROOT, "tests", "golden", "qwen2_5vl_tiny_golden.npz")   # Qwen2.5-VL variant (make_golden_qwen2_5.py)
+
+
 @pytest.fixture(scope="session")
 def golden():
-    return dict(np.load(GOLDEN))
+    out = dict(np.load(GOLDEN))
+    out.update(np.load(GOLDEN_25))
+    return out
 
 
 @pytest.fixture(scope="session")
@@ -27,7 +32,7 @@ def tiny_models():
     from karanta_ocr_amd.weights import random_weights
 
     out = {}
-    for name, seed in (("tiny", 1234), ("tiny-gqa", 4321)):
+    for name, seed in (("tiny", 1234), ("tiny-gqa", 4321), ("tiny-2.5", 2525)):
         cfg = CONFIGS[name]
-        out[name] = (cfg, random_weights(cfg, seed), name.replace("-", "_") + "__")
+        out[name] = (cfg, random_weights(cfg, seed), name.replace("-", "_").replace(".", "_") + "__")
     return out

@@ -18,7 +18,7 @@ from karanta_ocr_amd.engine import Engine, PageRequest  # noqa: E402
 from karanta_ocr_amd.weights import bf16_round  # noqa: E402
 from oracle import qwen2vl_oracle as O  # noqa: E402
 
-MODELS = ["tiny", "tiny-gqa"]
+MODELS = ["tiny", "tiny-gqa", "tiny-2.5"]
 
 
 @pytest.fixture(scope="module")

@@ -164,6 +164,8 @@ def test_argmax_embed_state_machine(L):
 def ref_linear(A, W, bias=None, res=None, epi=EPI_NONE):
     acc = A.astype(np.float64) @ W.astype(np.float64).T
     if epi in (EPI_SILU_MUL, EPI_SILU_MUL8):
+        if bias is not None:               # interleaved like the rows: added to both halves before the activation
+            acc = acc + bias
         n = W.shape[0]
         grp = 16 if epi == EPI_SILU_MUL else 8
         g = acc.reshape(A.shape[0], n // (2 * grp), 2, grp)
@@ -297,6 +299,19 @@ def test_gemm_silu_mul8(L, packed):
     got = run_gemm(L, A, Wp, epi=EPI_SILU_MUL8, packed=packed)
     assert got.shape == (M, ff)
     assert_close_bf16(got, ref_linear(A, Wp, epi=EPI_SILU_MUL8), what="gemm silu8")
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_silu_mul8_with_interleaved_bias(L, packed):
+    """The biased SwiGLU of the Qwen2.5-VL vision MLP: bias rows interleaved like the weight rows, added before the
+    activation on both halves; zero padding rows (weight and bias) give zero features."""
+    rng = np.random.default_rng(24)
+    M, ff, K = 150, 520, 256
+    A, Wp, bias = rnd(rng, M, K), rnd(rng, 2 * ff, K, scale=K ** -0.5), rnd(rng, 2 * ff, scale=0.5)
+    Wp[-16:] = 0; bias[-16:] = 0                      # last 8 features: padding
+    got = run_gemm(L, A, Wp, bias=bias, epi=EPI_SILU_MUL8, packed=packed)
+    assert_close_bf16(got, ref_linear(A, Wp, bias, epi=EPI_SILU_MUL8), what="gemm silu8 + bias")
+    assert not got[:, -8:].any()
 
 
 def test_gemm_in_place_residual(L):

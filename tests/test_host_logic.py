@@ -208,3 +208,28 @@ def test_resample_tables_reproduce_pil_bicubic():
     b, k = IP.resample_tables(1024, 980)
     assert b.shape == (980, 2) and k.shape[0] == 980 and (k.sum(1) - (1 << 22)).__abs__().max() <= k.shape[1]
     assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= 1024).all()
+
+
+def test_qwen2_5_config_from_hf_dict_and_weight_names():
+    """A Qwen2.5-VL config.json (tower width = hidden_size, merger output = out_hidden_size) maps onto the variant
+    fields; the parameter list has RMSNorm weights without biases and the biased gate / up / down MLP."""
+    from karanta_ocr_amd.config import CONFIGS, from_hf_config_dict
+    from karanta_ocr_amd.weights import weight_shapes
+    d = {"model_type": "qwen2_5_vl", "tie_word_embeddings": True, "image_token_id": 151655,
+         "text_config": {"hidden_size": 2048, "intermediate_size": 11008, "num_hidden_layers": 36, "num_attention_heads": 16,
+                         "num_key_value_heads": 2, "vocab_size": 151936, "rms_norm_eps": 1e-6,
+                         "rope_parameters": {"rope_theta": 1000000.0, "mrope_section": [16, 24, 24]}},
+         "vision_config": {"depth": 32, "hidden_size": 1280, "out_hidden_size": 2048, "num_heads": 16, "intermediate_size": 3420,
+                           "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31], "patch_size": 14,
+                           "spatial_merge_size": 2, "temporal_patch_size": 2}}
+    cfg = from_hf_config_dict(d, "q25")
+    ref = CONFIGS["Qwen2.5-VL-3B"]
+    assert cfg.vision == ref.vision and cfg.text == ref.text
+    v = cfg.vision
+    assert (v.variant, v.mlp_dim, v.mlp_dim_padded, v.window_merge_units, v.head_dim) == ("qwen2_5", 3420, 3456, 4, 80)
+    names = weight_shapes(CONFIGS["tiny-2.5"])
+    assert "model.visual.blocks.0.norm1.bias" not in names and "model.visual.merger.ln_q.bias" not in names
+    assert names["model.visual.blocks.3.mlp.gate_proj.weight"] == (200, 320) and names["model.visual.blocks.3.mlp.down_proj.bias"] == (320,)
+    assert "model.visual.blocks.0.mlp.fc1.weight" not in names
+    old = weight_shapes(CONFIGS["tiny"])
+    assert "model.visual.blocks.0.norm1.bias" in old and "model.visual.blocks.0.mlp.fc1.weight" in old

@@ -46,7 +46,31 @@ def test_vision_positions_and_rotary(golden, tiny_models, name):
     np.testing.assert_allclose(sin, golden[P + "vit_sin"], atol=1e-6)
 
 
-@pytest.mark.parametrize("name", MODELS)
+MODELS_ALL = MODELS + ["tiny-2.5"]   # the Qwen2.5-VL fixtures hold the vision tower and the end-to-end arrays
+
+
+def test_qwen2_5_window_index(golden, tiny_models):
+    """Window order of the merged units and cumulative window lengths (HF get_vision_window_index): one grid with
+    ragged right / bottom windows, one that divides exactly (the pad-by-a-full-window path); the product's host
+    restatement (positions.vision_window_order) gives the same."""
+    from karanta_ocr_amd import positions as POS
+    cfg, w, P = tiny_models["tiny-2.5"]
+    grid = [tuple(int(x) for x in g) for g in golden[P + "vit_grid"]]
+    widx, cu = O.vision_window_index(grid, 2, cfg.vision.window_size, cfg.vision.patch_size)
+    np.testing.assert_array_equal(widx, golden[P + "vit_window_index"])
+    np.testing.assert_array_equal(cu, golden[P + "vit_cu_window_seqlens"])
+    order, lens = POS.vision_window_order(grid, 2, cfg.vision.window_size, cfg.vision.patch_size)
+    np.testing.assert_array_equal(order, widx)
+    np.testing.assert_array_equal(np.cumsum([0] + lens), cu)
+    for g in ([(1, 70, 70)], [(1, 2, 2)], [(1, 14, 6), (1, 4, 30)]):          # production-size and degenerate grids
+        a, la = POS.vision_window_order(g, 2, 112, 14)
+        b, cb = O.vision_window_index(g, 2, 112, 14)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.cumsum([0] + la), cb)
+        assert sorted(a.tolist()) == list(range(len(a)))
+
+
+@pytest.mark.parametrize("name", MODELS_ALL)
 def test_vit_forward(golden, tiny_models, name):
     cfg, w, P = tiny_models[name]
     merged, inter = O.vit_forward(golden[P + "vit_pixel_values"], golden[P + "vit_grid"], w, cfg.vision,
@@ -109,7 +133,7 @@ def test_embed_scatter_and_first_layer(golden, tiny_models, name):
     np.testing.assert_allclose(x1[0], golden[P + "e2e_hidden_layer1_in"], atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("name", MODELS_ALL)
 def test_prompt_logits_all_positions(golden, tiny_models, name):
     cfg, w, P = tiny_models[name]
     ids, grid = golden[P + "e2e_input_ids"], golden[P + "e2e_grid"]
@@ -120,7 +144,7 @@ def test_prompt_logits_all_positions(golden, tiny_models, name):
     np.testing.assert_allclose(logits[0], golden[P + "e2e_prompt_logits"], atol=5e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("name", MODELS_ALL)
 def test_greedy_generate_matches_hf(golden, tiny_models, name):
     """Token ids of HF ``generate(do_sample=False)`` and its per-step scores, with KV cache."""
     cfg, w, P = tiny_models[name]
