@@ -262,7 +262,7 @@ int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16
  *     receives f32 slabs [ksplit][M][ldc] (no bias / residual / norm); the consumer adds them.
  *   part_in (with norm_w): n_part_in (= 2) slabs [n][M][K] f32 are added to x in the prologue,
  *     x_new = bf16(x + sum of slabs) is RMS-normalised and, by workgroup 0, stored to x_out (ldxo), which
- *     must not alias x (other workgroups still read x).  K must be 1536 or 3584 for this. */
+ *     must not alias x (other workgroups still read x).  K must be 1536, 2048 or 3584 for this. */
 int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
                             kr_bf16* x_out, int64_t ldxo, const kr_bf16* w_packed, const kr_bf16* bias,
                             const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,

@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 // Wave (block b, wave w) walks tiles b + gridDim.x * (w + W * i).
 template <int NCH> struct WideCfg { static constexpr int U = 8, RL = 8; };   // generic: K <= 4096, K % 512 == 0
 template <> struct WideCfg<24> { static constexpr int U = 12, RL = 3; };     // K = 1536 (Qwen2-VL-2B)
+template <> struct WideCfg<32> { static constexpr int U = 16, RL = 4; };     // K = 2048 (Qwen2.5-VL-3B)
 template <> struct WideCfg<56> { static constexpr int U = 8, RL = 7; };      // K = 3584 (Qwen2-VL-7B): 2 x rows + norm = 84 VGPRs
 
 // ACTIVE = this wave owns at least one tile.  The two cases are separate instantiations selected by ONE
@@ -660,6 +661,7 @@ template <int EPI>
 int launch_wide(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     switch (a.K >> 6) {
         case 24: return launch_wide_n<EPI, 24>(a, blocks, waves, s);
+        case 32: return launch_wide_n<EPI, 32>(a, blocks, waves, s);
         case 56: return launch_wide_n<EPI, 56>(a, blocks, waves, s);
         default: return launch_wide_n<EPI, 0>(a, blocks, waves, s);
     }
@@ -677,6 +679,7 @@ int launch_wide(DecLinArgs& a, int blocks, int waves, kr_stream s) {
 //                 the other residual buffer), RMSNorm of x_new, QKV + bias + M-RoPE + KV append as before
 template <int NCH> struct NarrowCfg { static constexpr int RL = 8; };
 template <> struct NarrowCfg<24> { static constexpr int RL = 3; };
+template <> struct NarrowCfg<32> { static constexpr int RL = 4; };
 template <> struct NarrowCfg<56> { static constexpr int RL = 7; };
 constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 
@@ -1016,11 +1019,13 @@ int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
     const int nch = a.K >> 6;
     if (a.part_in) {
         if (nch == 24) return launch_narrow_norm_u<NT, EPI, 24, 2>(a, groups, s);
+        if (nch == 32) return launch_narrow_norm_u<NT, EPI, 32, 2>(a, groups, s);
         if (nch == 56) return launch_narrow_norm_u<NT, EPI, 56, 2>(a, groups, s);
-        kr_set_error("kr_linear_decode_narrow: deferred partial sums need K = 1536 or 3584 (K=%d)", a.K);
+        kr_set_error("kr_linear_decode_narrow: deferred partial sums need K = 1536, 2048 or 3584 (K=%d)", a.K);
         return KR_ERR_ARG;
     }
     if (nch == 24) return launch_narrow_norm_u<NT, EPI, 24, 0>(a, groups, s);
+    if (nch == 32) return launch_narrow_norm_u<NT, EPI, 32, 0>(a, groups, s);
     if (nch == 56) return launch_narrow_norm_u<NT, EPI, 56, 0>(a, groups, s);
     return launch_narrow_norm_u<NT, EPI, 0, 0>(a, groups, s);
 }

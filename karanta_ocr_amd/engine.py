@@ -298,12 +298,12 @@ class Engine:
             if v_:
                 setattr(self, "wv_" + name, int(v_))
         # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
-        # reduction deferred to the next layer's qkv prologue (K = 1536 / 3584 only)
+        # reduction deferred to the next layer's qkv prologue (K = 1536 / 2048 / 3584 only)
         self.attn_fused_merge = os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"
         self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
         self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
-                           and t.hidden_size in (1536, 3584))
+                           and t.hidden_size in (1536, 2048, 3584))
         # gate/up and lm_head: one wave per 16-row tile (kr_linear_decode_wide) when K allows it
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))

@@ -824,7 +824,7 @@ def run_wide(L, mode, x, W, blocks, waves, bias=None, res=None, norm_w=None, f32
 
 @pytest.mark.parametrize("M", [1, 8, 16])
 @pytest.mark.parametrize("N,K,blocks,waves", [(16, 512, 1, 1), (16 * 37, 512, 3, 5), (16 * 37, 1536, 256, 4),
-                                              (16 * 300, 1024, 7, 8), (16 * 41, 3584, 5, 2)])
+                                              (16 * 300, 1024, 7, 8), (16 * 41, 3584, 5, 2), (16 * 45, 2048, 4, 3)])
 def test_linear_wide_plain_exact_on_integers(L, M, N, K, blocks, waves):
     """One wave per tile, register ring running across tile boundaries: exact on small integers; the zeroed K
     tail makes a wrong chunk order / wrong next-tile prefetch visible."""
@@ -836,7 +836,7 @@ def test_linear_wide_plain_exact_on_integers(L, M, N, K, blocks, waves):
     np.testing.assert_array_equal(run_wide(L, DEC_PLAIN, x, W, blocks, waves, f32=True), ref_linear(x, W))
 
 
-@pytest.mark.parametrize("M,K,blocks,waves", [(8, 1536, 256, 5), (16, 3584, 9, 8), (3, 512, 2, 3)])
+@pytest.mark.parametrize("M,K,blocks,waves", [(8, 1536, 256, 5), (16, 3584, 9, 8), (3, 512, 2, 3), (8, 2048, 11, 6)])
 def test_linear_wide_silu8_norm_bias_residual(L, M, K, blocks, waves):
     rng = np.random.default_rng(162 + M)
     ff = 1016
@@ -948,7 +948,8 @@ def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
         narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(xd), ldc=N, waves=waves, ksplit=ksplit)
 
 
-@pytest.mark.parametrize("M,K,parts", [(8, 1536, True), (8, 1536, False), (16, 3584, True), (3, 256, False), (11, 1536, True)])
+@pytest.mark.parametrize("M,K,parts", [(8, 1536, True), (8, 1536, False), (16, 3584, True), (3, 256, False), (11, 1536, True),
+                                       (8, 2048, True), (5, 2048, False)])
 def test_linear_narrow_norm_with_deferred_partials(L, M, K, parts):
     """x_new = bf16(x + slab0 + slab1) -> x_out (written once, by workgroup 0), RMSNorm(x_new) @ W^T + bias."""
     rng = np.random.default_rng(300 + M + K)
@@ -980,7 +981,8 @@ def test_linear_narrow_partials_reject_unsupported_k(L):
                                   8, 16, 256, 8, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
 
 
-@pytest.mark.parametrize("H,KVH,K,parts", [(2, 1, 1024, False), (12, 2, 1536, True), (3, 1, 1536, False), (28, 4, 3584, True)])
+@pytest.mark.parametrize("H,KVH,K,parts", [(2, 1, 1024, False), (12, 2, 1536, True), (3, 1, 1536, False), (28, 4, 3584, True),
+                                           (16, 2, 2048, True)])
 def test_linear_narrow_rope_kv(L, H, KVH, K, parts):
     """Fused (partial sums +) RMSNorm + qkv projection + bias + M-RoPE + q / K-cache / V^T-cache writes."""
     rng = np.random.default_rng(170 + H)
