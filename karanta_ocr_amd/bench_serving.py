@@ -59,11 +59,18 @@ def main():
     out = sch.run([SlotRequest(p, m, tag=i) for i, (p, m) in enumerate(zip(pages, limits))])
     t_cont = time.perf_counter() - t0
     assert all(r.error is None and len(r.tokens) == m for r, m in zip(out, limits))
+    # the same with overlapped admission (ViT + prefill of the next page on a second stream)
+    sch2 = SlotScheduler(eng, max_tokens_cap=args.t_max, chunk=args.chunk, eos_token_ids=(), overlap=True)
+    t0 = time.perf_counter()
+    out2 = sch2.run([SlotRequest(p, m, tag=i) for i, (p, m) in enumerate(zip(pages, limits))])
+    t_over = time.perf_counter() - t0
+    assert all(r.error is None and np.array_equal(r.tokens, q.tokens) for r, q in zip(out2, out))
     print(json.dumps({
         "workload": f"{args.model}, {args.pages} synthetic {args.page}x{args.page} pages, {B} slots, output lengths "
                     f"U[{args.t_min},{args.t_max}] (mean {np.mean(limits):.0f}), random-init weights, greedy",
         "static_pages_per_s": round(args.pages / t_static, 3), "continuous_pages_per_s": round(args.pages / t_cont, 3),
-        "speedup": round(t_static / t_cont, 3), "tokens": int(sum(limits)), "static_tokens_checked": int(static_tokens),
+        "continuous_overlapped_admission_pages_per_s": round(args.pages / t_over, 3),
+        "speedup": round(t_static / t_cont, 3), "speedup_overlapped": round(t_static / t_over, 3), "tokens": int(sum(limits)), "static_tokens_checked": int(static_tokens),
         "continuous_slot_utilisation": round(sch.slot_steps_busy / max(1, sch.steps * B), 3),
         "decode_steps": {"continuous": sch.steps}, "chunk": args.chunk,
     }), flush=True)

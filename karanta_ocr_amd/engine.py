@@ -223,6 +223,7 @@ class Engine:
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
         self._ignore_eos = self._freeze_finished = self._want_logits = self._sampling = False
+        self._adm_stream = None                          # second stream of the overlapped admission (slot mode)
         self._resample_cache: Dict[tuple, tuple] = {}   # (h, w, rh, rw) -> device tables of the GPU image front end
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
@@ -587,12 +588,14 @@ class Engine:
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int,
-                slots: Optional[Sequence[int]] = None) -> List[int]:
+                slots: Optional[Sequence[int]] = None, defer_activation: bool = False):
         """embed+scatter, M-RoPE, 28 x decoder layer over the flattened prompts (causal varlen
         attention writing the KV cache), last-token logits -> first greedy token.
         Leaves the decode state (d_x, d_ctx, d_delta, history row 0) ready.  Returns prompt lengths.
         ``slots`` (slot scheduler): the cache / state slots the pages go to; only those slots' state is
-        touched, the other sequences keep decoding from where they are."""
+        touched, the other sequences keep decoding from where they are.  ``defer_activation`` (overlapped
+        admission): only the layers run here (they fill the slots' KV rows); the slot state writes and the first
+        sampling step are returned as a record for `_activate` to apply on the decode stream."""
         cfg, t, L, s, w, dev = self.cfg, self.cfg.text, self.L, self.s, self.w, self.device
         B = len(pages)
         whole_batch = slots is None
@@ -603,8 +606,9 @@ class Engine:
         M = sum(lens)
         if M > self.max_tokens:
             raise KarantaHipError(f"{M} prompt tokens > max_prompt_tokens {self.max_tokens}")
-        if max(lens) + self.max_new > self.s_max:
-            raise KarantaHipError(f"prompt {max(lens)} + max_new_tokens {self.max_new} exceeds s_max {self.s_max}")
+        room = self.s_max - (1 if self._freeze_finished else 0)   # slot mode keeps the last cache row as the parking row
+        if max(lens) + self.max_new > room:
+            raise KarantaHipError(f"prompt {max(lens)} + max_new_tokens {self.max_new} exceeds s_max {room}")
         src = np.empty(M, np.int32)
         cos = np.empty((M, t.head_dim), np.float32)
         sin = np.empty((M, t.head_dim), np.float32)
@@ -661,15 +665,8 @@ class Engine:
                 self._h2d(self.d_plen, plen)
                 self._h2d(self.d_cs, cs)
                 self.d_fin.zero_()
-            else:
-                for b, j in enumerate(slots):
-                    self._h2d(self.d_delta[j:j + 1], deltas[b:b + 1])
-                    self._h2d(self.d_ctx[j:j + 1], np.asarray([lens[b] - 1], np.int32))
-                    self._h2d(self.d_plen[j:j + 1], np.asarray([lens[b]], np.int32))
-                    self._h2d(self.d_cs[j], cs[b])
-                    self._h2d(self.d_temp[j:j + 1], temps[b:b + 1])
-                    self._h2d(self.d_seed[j:j + 1], seeds[b:b + 1])
-                    self.d_fin[j:j + 1].zero_()
+            elif not defer_activation:
+                self._write_slot_state(slots, lens, deltas, cs, temps, seeds)
             self._h2d(self.d_last, last_rows)
             t_ = lambda a: torch.from_numpy(a).to(dev)
             blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
@@ -698,11 +695,28 @@ class Engine:
             if whole_batch:
                 L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)
                 self._lm_head_and_sample(B)
-            else:
-                for b, j in enumerate(slots):
-                    L.kr_embed_scatter(ptr(self.d_last[b:]), ptr(self.p_x), 0, ptr(self.d_x[j:]), 1, d, s)
-                    self._lm_head_and_sample(1, slot0=j)
+            elif not defer_activation:
+                self._first_tokens(slots)
+        if defer_activation:
+            return {"slots": slots, "lens": lens, "deltas": deltas, "cs": cs, "temps": temps, "seeds": seeds}
         return lens
+
+    def _write_slot_state(self, slots, lens, deltas, cs, temps, seeds):
+        for b, j in enumerate(slots):
+            self._h2d(self.d_delta[j:j + 1], deltas[b:b + 1])
+            self._h2d(self.d_ctx[j:j + 1], np.asarray([lens[b] - 1], np.int32))
+            self._h2d(self.d_plen[j:j + 1], np.asarray([lens[b]], np.int32))
+            self._h2d(self.d_cs[j], cs[b])
+            self._h2d(self.d_temp[j:j + 1], temps[b:b + 1])
+            self._h2d(self.d_seed[j:j + 1], seeds[b:b + 1])
+            self.d_fin[j:j + 1].zero_()
+
+    def _first_tokens(self, slots):
+        """Last prompt position of every prefilled sequence (p_x rows d_last) -> its slot's x -> lm_head -> first token."""
+        d = self.cfg.text.hidden_size
+        for b, j in enumerate(slots):
+            self.L.kr_embed_scatter(ptr(self.d_last[b:]), ptr(self.p_x), 0, ptr(self.d_x[j:]), 1, d, self.s)
+            self._lm_head_and_sample(1, slot0=j)
 
     def _lm_head_and_sample(self, B: int, x=None, slot0: int = 0):
         """final RMSNorm (fused) -> lm_head with per-workgroup argmax partials -> greedy token,
@@ -1014,6 +1028,51 @@ class Engine:
         pix = self._pixels_for(pages, None)
         n_img_tok = self.vit_forward(pix, grids).shape[0] if pix is not None else 0
         return self.prefill(pages, n_img_tok, slots=slots)
+
+    # Overlapped admission (optional, SlotScheduler(overlap=True); measured: no gain on the ragged serving benchmark —
+    # 6.56 vs 6.57 pages/s, with or without a high-priority decode stream: the ViT / prefill launches fill all 256 CUs
+    # with long-running workgroups and the short decode launches wait for slots, so the two streams serialise in
+    # practice).  ViT + prefill of the new requests run on a second stream while the decode graph keeps
+    # stepping the other slots.  The target slots are first PARKED on the last cache row (their frozen per-step KV
+    # write then cannot land inside the rows the prefill is filling); the slot state and the first sampling step are
+    # applied on the decode stream once the admission stream has finished.
+    def admit_begin(self, pages: Sequence[PageRequest], slots: Sequence[int]):
+        slots = [int(j) for j in slots]
+        if self._adm_stream is None:
+            self._adm_stream = torch.cuda.Stream(device=self.device)
+        park = np.asarray([self.s_max - 1], np.int32)
+        with torch.cuda.stream(self.stream):
+            for j in slots:
+                self.d_fin[j:j + 1].fill_(1)
+                self._h2d(self.d_ctx[j:j + 1], park)
+                self._h2d(self.d_plen[j:j + 1], park)
+            parked = torch.cuda.Event()
+            parked.record(self.stream)
+        self._adm_stream.wait_event(parked)
+        main = (self.stream, self.s)
+        self.stream, self.s = self._adm_stream, self._adm_stream.cuda_stream
+        try:
+            grids = [g for p in pages for g in p.grids]
+            pix = self._pixels_for(pages, None)
+            n_img_tok = self.vit_forward(pix, grids).shape[0] if pix is not None else 0
+            rec = self.prefill(pages, n_img_tok, slots=slots, defer_activation=True)
+            done = torch.cuda.Event()
+            done.record(self._adm_stream)
+        finally:
+            self.stream, self.s = main
+        return {"done": done, "rec": rec}
+
+    def admit_ready(self, handle) -> bool:
+        return bool(handle["done"].query())
+
+    def admit_end(self, handle) -> List[int]:
+        """Activate the admitted slots on the decode stream (waits for the admission stream there, not on the host)."""
+        rec = handle["rec"]
+        self.stream.wait_event(handle["done"])
+        with torch.cuda.stream(self.stream):
+            self._write_slot_state(rec["slots"], rec["lens"], rec["deltas"], rec["cs"], rec["temps"], rec["seeds"])
+            self._first_tokens(rec["slots"])
+        return rec["lens"]
 
     def decode_steps(self, n: int):
         """n decode steps over all slots (asynchronous on the engine's stream)."""

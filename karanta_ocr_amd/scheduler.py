@@ -40,7 +40,8 @@ class SlotScheduler:
     returns the requests that finished."""
 
     def __init__(self, engine, max_tokens_cap: int, chunk: int = 16, eos_token_ids: Optional[Sequence[int]] = None,
-                 max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False):
+                 max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False,
+                 overlap: bool = False):
         if max_tokens_cap < 1 or chunk < 1:
             raise ValueError("max_tokens_cap and chunk must be >= 1")
         self.engine = engine
@@ -52,6 +53,10 @@ class SlotScheduler:
         self.waiting: Deque[SlotRequest] = collections.deque()
         self.active: Dict[int, SlotRequest] = {}     # slot -> request
         self.prompt_len: Dict[int, int] = {}
+        # overlap: ViT + prefill of an admission run on a second stream while the other slots keep decoding
+        # (Engine.admit_begin / admit_ready / admit_end); one admission in flight at a time
+        self.overlap = bool(overlap) and all(hasattr(engine, m) for m in ("admit_begin", "admit_ready", "admit_end"))
+        self._inflight = None                        # (handle, requests, slots)
         self.steps = 0                               # decode steps run
         self.slot_steps_busy = 0                     # sum over steps of occupied slots (utilisation numerator)
         # a slot may run up to chunk - 1 steps past its limit before the host looks: size the history for that
@@ -69,20 +74,50 @@ class SlotScheduler:
 
     @property
     def idle(self) -> bool:
-        return not self.waiting and not self.active
+        return not self.waiting and not self.active and self._inflight is None
 
     @property
     def running(self) -> int:
         return len(self.active)
 
     def step(self) -> List[SlotResult]:
-        done: List[SlotResult] = self._admit()
+        if not self.overlap:
+            done: List[SlotResult] = self._admit()
+            if self.active:
+                self._decode_chunk()
+                done += self._harvest()
+            return done
+        # overlapped: finish an admission that is through, queue the decode chunk, THEN spend host time launching the
+        # next admission (the GPU has both to run), then look at the finished flags
+        done = self._finish_admission(block=not self.active)
         if self.active:
-            self.engine.decode_steps(self.chunk)
-            self.steps += self.chunk
-            self.slot_steps_busy += self.chunk * len(self.active)
+            self._decode_chunk()
+        if self._inflight is None:
+            done += self._admit(begin_only=True)
+        if self.active:
             done += self._harvest()
         return done
+
+    def _decode_chunk(self):
+        self.engine.decode_steps(self.chunk)
+        self.steps += self.chunk
+        self.slot_steps_busy += self.chunk * len(self.active)
+
+    def _finish_admission(self, block: bool) -> List[SlotResult]:
+        if self._inflight is None:
+            return []
+        handle, batch, slots = self._inflight
+        if not block and not self.engine.admit_ready(handle):
+            return []
+        self._inflight = None
+        try:
+            lens = self.engine.admit_end(handle)
+        except Exception as e:
+            return [self._failure(r, f"{type(e).__name__}: {e}") for r in batch]
+        for r, j, n in zip(batch, slots, lens):
+            self.active[j] = r
+            self.prompt_len[j] = int(n)
+        return []
 
     def run(self, requests: Iterable[SlotRequest]) -> List[SlotResult]:
         """All requests to completion; results in submission order."""
@@ -101,7 +136,7 @@ class SlotScheduler:
         return out  # type: ignore[return-value]
 
     # ------------------------------------------------------------------ internals
-    def _admit(self) -> List[SlotResult]:
+    def _admit(self, begin_only: bool = False) -> List[SlotResult]:
         free = [j for j in range(self.n_slots) if j not in self.active]
         batch: List[SlotRequest] = []
         tok_budget = self.max_prompt_tokens
@@ -128,7 +163,13 @@ class SlotScheduler:
                 tok_budget -= n_tok
             if patch_budget is not None:
                 patch_budget -= n_patch
-        if batch:
+        if batch and begin_only:
+            slots = free[:len(batch)]
+            try:
+                self._inflight = (self.engine.admit_begin([r.page for r in batch], slots), batch, slots)
+            except Exception as e:
+                return failed + [self._failure(r, f"{type(e).__name__}: {e}") for r in batch]
+        elif batch:
             slots = free[:len(batch)]
             try:
                 lens = self.engine.admit([r.page for r in batch], slots)

@@ -137,8 +137,9 @@ def test_image_token_mismatch_is_an_error(engines, tiny_models):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("name", MODELS)
-def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name):
+def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name, overlap):
     """Continuous batching: 7 ragged requests through 3 slots (2 of the engine's 4 stay idle throughout) — every
     request's tokens equal the ones it gets alone from `generate`, whichever slot it lands in, whatever its slot
     held before and whatever its neighbours are doing; EOS (made frequent by construction) and length limits both
@@ -163,7 +164,10 @@ def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name):
     eng = Engine(cfg2, max_batch=3, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2)
     eng.load_weights(w)
     solo = [eng.generate([pg], mt) for pg, mt in zip(pages, limits)]
-    sch = SlotScheduler(eng, max_tokens_cap=20, chunk=3)
+    # overlap: ViT + prefill of an admission on a second stream while the other slots keep decoding (target slots
+    # parked on the last cache row meanwhile)
+    sch = SlotScheduler(eng, max_tokens_cap=20, chunk=3, overlap=overlap)
+    assert sch.overlap == overlap
     res = sch.run([SlotRequest(pg, mt, tag=i) for i, (pg, mt) in enumerate(zip(pages, limits))])
     assert [r.tag for r in res] == list(range(len(pages)))
     reasons = set()

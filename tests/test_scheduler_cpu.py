@@ -150,3 +150,48 @@ def test_patch_budget_counts_grids():
                    SlotRequest(Page([0], n_patches=11), 4, "big")])
     assert [e[1] for e in eng.log if e[0] == "admit"][0] == (0,)      # 6 + 6 > 10 patches: one page per admission
     assert res[0].error is None and res[1].error is None and "does not fit" in res[2].error
+
+
+class FakeAsyncEngine(FakeEngine):
+    """FakeEngine + the overlapped-admission API: an admission becomes ready after `latency` polls."""
+    latency = 2
+
+    def admit_begin(self, pages, slots):
+        assert all(self.fin[j] for j in slots), "admission into a busy slot"
+        self.log.append(("begin", tuple(slots)))
+        return {"pages": pages, "slots": list(slots), "polls": 0}
+
+    def admit_ready(self, h):
+        h["polls"] += 1
+        return h["polls"] > self.latency
+
+    def admit_end(self, h):
+        self.log.append(("end", tuple(h["slots"])))
+        return FakeEngine.admit(self, h["pages"], h["slots"])
+
+
+def test_overlapped_admission_same_results_and_decode_keeps_running():
+    reqs = lambda: [SlotRequest(Page([k, 0]), mt, tag=f"r{k}") for k, mt in [(5, 40), (0, 10), (3, 10), (4, 20), (1, 9), (2, 5)]]
+    plain = SlotScheduler(FakeEngine(2, SCRIPT), max_tokens_cap=64, chunk=3).run(reqs())
+    eng = FakeAsyncEngine(2, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=64, chunk=3, overlap=True)
+    assert sch.overlap
+    over = sch.run(reqs())
+    for a, b in zip(plain, over):
+        assert a.tag == b.tag and a.tokens.tolist() == b.tokens.tolist() and a.finish_reason == b.finish_reason
+    # decode chunks ran between the begin and the end of at least one admission (the other slot kept going)
+    kinds = [e[0] for e in eng.log]
+    i = kinds.index("begin", 1)
+    assert "steps" in kinds[i:kinds.index("end", i)]
+    assert sch.idle and sch._inflight is None
+    # an engine without the async API silently falls back
+    assert SlotScheduler(FakeEngine(2, SCRIPT), 8, overlap=True).overlap is False
+
+
+def test_overlapped_admission_failure_paths():
+    class Boom(FakeAsyncEngine):
+        def admit_end(self, h):
+            raise RuntimeError("late boom")
+    sch = SlotScheduler(Boom(2, SCRIPT), max_tokens_cap=8, chunk=2, overlap=True)
+    (r,) = sch.run([SlotRequest(Page([0]), 4, "x")])
+    assert r.error.startswith("RuntimeError: late boom") and sch.idle
