@@ -1,0 +1,121 @@
+"""``vllm serve``-shaped command line for the MI355X engine.
+
+The reference starts its model server itself: ``karanta.pipeline`` builds
+``vllm serve <model> --port N --disable-log-requests --uvicorn-log-level warning --served-model-name karantaocr
+--tensor-parallel-size T --data-parallel-size D --limit-mm-per-prompt '{"video": 0}' [--gpu-memory-utilization F]
+[--max-model-len M] [passthrough...]`` (/root/reference/karanta/pipeline.py:707-734), and its shell scripts run
+``python -m vllm.entrypoints.openai.api_server --model <model> --port N --dtype bfloat16 [--max-model-len M]
+[--trust-remote-code]`` once per GPU (scripts/start_multiple_vllm_servers.sh:283-294).  This module accepts both
+spellings, so an executable named ``vllm`` that runs ``python -m karanta_ocr_amd.cli "$@"`` (or replacing
+``vllm.entrypoints.openai.api_server`` by ``karanta_ocr_amd.cli`` in the scripts) puts this engine behind the
+unmodified pipeline: same port, same served model name, the log lines the pipeline waits for on the server's
+output (:769-800), SIGTERM / SIGINT to stop (:745-751).
+
+vLLM flags with no meaning here are accepted and ignored (tensor / data parallel sizes other than 1 are refused:
+one process drives one GPU, as the reference's own multi-GPU script does; select the GPU with HIP_VISIBLE_DEVICES).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import signal
+import sys
+import threading
+from typing import List, Optional
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="vllm", description=__doc__.split("\n\n")[0])
+    ap.add_argument("command", nargs="?", default=None, help="`serve` (vllm serve <model> ...) or omitted (api_server style)")
+    ap.add_argument("model_pos", nargs="?", default=None, metavar="model", help="model directory (config.json, *.safetensors, tokenizer.json)")
+    ap.add_argument("--model", default=None, help="api_server spelling of the model directory")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--served-model-name", default=None)
+    ap.add_argument("--max-model-len", type=int, default=16384)
+    ap.add_argument("--max-num-seqs", type=int, default=8, help="decode slots (<= 16)")
+    ap.add_argument("--tensor-parallel-size", type=int, default=1)
+    ap.add_argument("--data-parallel-size", type=int, default=1)
+    ap.add_argument("--gpu-memory-utilization", type=float, default=None)
+    ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--limit-mm-per-prompt", default=None)
+    ap.add_argument("--uvicorn-log-level", default=None)
+    ap.add_argument("--api-key", default=None)
+    ap.add_argument("--task", default=None)
+    ap.add_argument("--disable-log-requests", action="store_true")
+    ap.add_argument("--trust-remote-code", action="store_true")
+    ap.add_argument("--enforce-eager", action="store_true")
+    # this engine's own knobs
+    ap.add_argument("--max-tokens-cap", type=int, default=6000, help="largest max_tokens a request may ask for")
+    ap.add_argument("--static-batching", action="store_true", help="static batches instead of the slot scheduler")
+    ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU image front end")
+    ap.add_argument("--max-pixels", type=int, default=None)
+    ap.add_argument("--greedy", action="store_true", help="ignore request temperatures")
+    return ap
+
+
+def parse_args(argv: Optional[List[str]] = None):
+    ap = build_parser()
+    args, unknown = ap.parse_known_args(argv)
+    if args.command is not None and args.command != "serve":
+        if args.model_pos is None and args.model is None:   # `cli.py <model>` without the verb
+            args.model_pos, args.command = args.command, "serve"
+        else:
+            ap.error(f"unknown command {args.command!r} (only `serve`)")
+    model = args.model_pos or args.model
+    if not model:
+        ap.error("no model directory given")
+    if args.tensor_parallel_size != 1 or args.data_parallel_size != 1:
+        ap.error("one process serves one GPU: run one server per GPU (HIP_VISIBLE_DEVICES=i), as "
+                 "scripts/start_multiple_vllm_servers.sh does; tensor / data parallel sizes must be 1")
+    if not 1 <= args.max_num_seqs <= 16:
+        ap.error("--max-num-seqs must be in 1..16")
+    args.model_dir = model
+    args.served_model_name = args.served_model_name or os.path.basename(os.path.normpath(model))
+    args.ignored = unknown
+    return args
+
+
+def make_server(args, log=print):
+    """Engine + front end + LocalServer from parsed arguments (weights and tokenizer from args.model_dir)."""
+    from . import image_processing as IP
+    from .engine import Engine
+    from .serving import ChatFrontend, HFTokenizer, LocalServer
+    from .weights import load_checkpoint
+
+    cfg, tensors = load_checkpoint(args.model_dir)
+    max_pixels = args.max_pixels or IP.MAX_PIXELS_CLASS_DEFAULT
+    patches_per_page = max_pixels // (cfg.vision.patch_size ** 2) + 64
+    eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 63) // 64 * 64,
+                 max_patches=args.max_num_seqs * patches_per_page, max_prompt_tokens=args.max_num_seqs * args.max_model_len // 2)
+    eng.load_weights(tensors)
+    front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), max_pixels=max_pixels,
+                         max_model_len=args.max_model_len, device_images=not args.host_images)
+    return LocalServer(eng, front, served_model_name=args.served_model_name, log=log, continuous=not args.static_batching,
+                       max_tokens_cap=min(args.max_tokens_cap, args.max_model_len), honor_temperature=not args.greedy)
+
+
+def main(argv: Optional[List[str]] = None, make=make_server) -> int:
+    from .serving import serve_http
+
+    args = parse_args(argv)
+    log = lambda *a: print(*a, file=sys.stderr, flush=True)   # the pipeline reads the server's stderr and stdout alike
+    if args.ignored:
+        log(f"ignoring vLLM arguments with no meaning for this engine: {' '.join(args.ignored)}")
+    srv = make(args, log=log)
+    httpd = serve_http(srv, port=args.port, host=args.host)
+    stop = threading.Event()
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, lambda *_: stop.set())
+        except ValueError:      # not the main thread (tests)
+            pass
+    args.on_ready(httpd, srv, stop) if hasattr(args, "on_ready") else None
+    stop.wait()
+    httpd.shutdown()
+    srv.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -195,6 +195,7 @@ class LocalServer:
         self._running = 0
         self._stop = False
         self.pages_done = 0
+        self._t_start = time.time()
         self.latencies: List[float] = []
         self._thread = threading.Thread(target=self._loop_continuous if self.continuous else self._loop, daemon=True)
         self._thread.start()
@@ -204,6 +205,15 @@ class LocalServer:
     # -- public surface -------------------------------------------------------
     def health(self) -> Tuple[int, dict]:
         return 200, {"status": "ok", "engine": "karanta-mi355x", "running": self._running, "waiting": self._q.qsize()}
+
+    def metrics(self) -> Tuple[int, dict]:
+        """Pages served and request latency percentiles (the reference computes neither)."""
+        lat = sorted(self.latencies[-10000:])
+        pct = lambda q: float(lat[min(len(lat) - 1, int(q * len(lat)))]) if lat else None
+        up = max(1e-9, time.time() - self._t_start)
+        return 200, {"pages_done": self.pages_done, "uptime_s": round(up, 3), "pages_per_s": round(self.pages_done / up, 4),
+                     "running": self._running, "waiting": self._q.qsize(),
+                     "latency_s": {"p50": pct(0.50), "p95": pct(0.95), "p99": pct(0.99), "n": len(lat)}}
 
     def models(self) -> Tuple[int, dict]:
         return 200, {"object": "list", "data": [{"id": self.name, "object": "model", "owned_by": "karanta"}]}
@@ -401,6 +411,8 @@ def serve_http(server: LocalServer, port: int, host: str = "127.0.0.1"):
                 self._send(*server.health())
             elif path in ("/v1/models", "/models"):
                 self._send(*server.models())
+            elif path == "/metrics":
+                self._send(*server.metrics())
             else:
                 self._send(404, {"error": {"message": "not found", "code": 404}})
 

@@ -333,3 +333,65 @@ def test_device_images_front_end_hands_over_uint8_pages():
     assert srv.chat_completions(req)[0] == 200
     srv.close()
     assert eng.pages[-1].images[0].shape == (100, 150, 3) and eng.pages[-1].pixel_values is None
+
+
+# ----------------------------------------------------------------------------- `vllm serve`-shaped CLI + metrics
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def test_cli_accepts_the_reference_command_lines():
+    from karanta_ocr_amd import cli
+    # karanta/pipeline.py:707-734
+    a = cli.parse_args(["serve", "/models/karantaocr-2b", "--port", "30024", "--disable-log-requests", "--uvicorn-log-level",
+                        "warning", "--served-model-name", "karantaocr", "--tensor-parallel-size", "1", "--data-parallel-size", "1",
+                        "--limit-mm-per-prompt", '{"video": 0}', "--gpu-memory-utilization", "0.8", "--max-model-len", "16384",
+                        "--some-future-vllm-flag", "7"])
+    assert (a.model_dir, a.port, a.served_model_name, a.max_model_len) == ("/models/karantaocr-2b", 30024, "karantaocr", 16384)
+    assert a.ignored == ["--some-future-vllm-flag", "7"]
+    # scripts/start_multiple_vllm_servers.sh:283-294 (python -m vllm.entrypoints.openai.api_server ...)
+    b = cli.parse_args(["--model", "/models/qwen", "--port", "8001", "--dtype", "bfloat16", "--trust-remote-code"])
+    assert (b.model_dir, b.port, b.served_model_name) == ("/models/qwen", 8001, "qwen")
+    for bad in (["serve", "/m", "--tensor-parallel-size", "2"], ["serve"], ["serve", "/m", "--max-num-seqs", "64"]):
+        with pytest.raises(SystemExit):
+            cli.parse_args(bad)
+
+
+def test_cli_main_serves_until_signalled_and_metrics_endpoint():
+    """cli.main with a stub server factory: HTTP up on the requested port, ready line printed, /metrics reports the
+    pages served and latency percentiles, the stop event ends it."""
+    import threading, urllib.request
+    from karanta_ocr_amd import cli
+    made = {}
+
+    def make(args, log):
+        made["srv"] = S.LocalServer(FakeSlotEngine(), S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), served_model_name=args.served_model_name,
+                                    log=log, continuous=True, max_tokens_cap=8, chunk=2)
+        return made["srv"]
+
+    port = _free_port()
+    ready = threading.Event()
+    box = {}
+    orig = cli.parse_args
+    def parse(argv):
+        a = orig(argv)
+        a.on_ready = lambda httpd, srv, stop: (box.update(stop=stop), ready.set())
+        return a
+    cli.parse_args = parse
+    try:
+        t = threading.Thread(target=lambda: box.update(rc=cli.main(["serve", "/m", "--port", str(port), "--host", "127.0.0.1",
+                                                                   "--served-model-name", "karantaocr"], make=make)))
+        t.start()
+        assert ready.wait(10)
+        body = json.dumps({"model": "karantaocr", "messages": [{"role": "user", "content": "x"}], "max_tokens": 8}).encode()
+        req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/chat/completions", data=body, headers={"Content-Type": "application/json"})
+        assert json.loads(urllib.request.urlopen(req, timeout=10).read())["choices"][0]["message"]["content"] == "OK"
+        m = json.loads(urllib.request.urlopen(f"http://127.0.0.1:{port}/metrics", timeout=10).read())
+        assert m["pages_done"] == 1 and m["latency_s"]["n"] == 1 and m["latency_s"]["p50"] > 0 and m["pages_per_s"] > 0
+        box["stop"].set()
+        t.join(10)
+        assert box.get("rc") == 0
+    finally:
+        cli.parse_args = orig
