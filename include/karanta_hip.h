@@ -271,6 +271,25 @@ int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float
                             kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
                             kr_stream s);
 
+/* The same two kernels on fp8 (OCP e4m3fn) weights — BASELINE.json config 5: decoder Linears in fp8 with one f32 scale
+ * per output row, activations bf16.  w_packed_fp8 = weights.pack_w16x64_fp8 (one 16-row x 64-column block = 1 KiB in
+ * lane order: half the bytes per launch), converted to bf16 in registers (exact) and fed to the bf16 MFMA; w_scale
+ * [N] (in the row order of the packed matrix, i.e. interleaved like the rows for SILU8) multiplies the f32
+ * accumulators before bias / activation / rotary / slab store.  Everything else as the bf16 entry points. */
+int kr_linear_decode_wide_fp8(int mode, const kr_bf16* x, int64_t ldx, const uint8_t* w_packed_fp8, const float* w_scale,
+                              const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual,
+                              int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks,
+                              int waves, float* amax_val, int32_t* amax_idx, kr_stream s);
+int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                kr_bf16* x_out, int64_t ldxo, const uint8_t* w_packed_fp8, const float* w_scale,
+                                const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual,
+                                int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves,
+                                int ksplit, const float* cs_table, int cs_stride, const int32_t* prompt_len,
+                                const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads,
+                                int kv_heads, int s_max, kr_stream s);
+/* n fp8 e4m3fn codes -> bf16 through the hardware conversion the kernels use (test hook: pins the number format). */
+int kr_fp8_to_bf16(const uint8_t* src, kr_bf16* dst, int64_t n, kr_stream s);
+
 /* Decode attention (q_len 1, GQA, MFMA, split over n_split key ranges), kcache / vtcache = the
  * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+4] partials (o[hd], m, l, 2 pad: 16-byte aligned records).
  * out != NULL: the splits are merged in-launch by the last-arriving workgroup (counters: int32

@@ -59,6 +59,10 @@ SIGNATURES = {
     "kr_linear_decode_wide": [i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
     "kr_image_resize_bicubic_u8": [c_p, i32, i32, c_p, i32, i32, c_p, c_p, c_p, i32, c_p, c_p, i32, c_p],
     "kr_image_normalize_patchify": [c_p, i32, i32, c_p, c_p, i32, i32, i32, c_p, c_p],
+    "kr_linear_decode_wide_fp8": [i32, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
+    "kr_linear_decode_narrow_fp8": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
+                                    i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
+    "kr_fp8_to_bf16": [c_p, c_p, i64, c_p],
     "kr_gumbel_argmax": [c_p, i64, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p],
     "kr_linear_decode_narrow": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                 i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],

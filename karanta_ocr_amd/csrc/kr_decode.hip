@@ -55,7 +55,55 @@ struct DecLinArgs {
     // x prologue adds to x (the residual stream); workgroup 0 writes the sum to x_out (a different buffer than x).
     // PARTIAL epilogue: out_f32 = [ksplit][M][ldc] f32 slabs, no bias / residual.
     const float* part_in; kr_bf16* x_out; int64_t ldxo;
+    // fp8 (e4m3fn) weights: one f32 scale per output row (interleaved like the rows for SILU8), applied to the
+    // accumulators at the top of every epilogue; NULL for bf16 weights
+    const float* w_scale;
 };
+
+// One 64-wide K chunk of a 16-row weight tile in registers, and where its operands sit.
+//  bf16 : 2 KiB per chunk, two 16-byte loads per lane; lane (r, g) holds k = 32h + 8g .. +7 of k-step h
+//  fp8  : 1 KiB per chunk, ONE 16-byte load per lane; lane (r, g) holds k = 16g .. 16g+15, k-step h takes 16g + 8h .. +7
+//         (x is read in the same order, a dot product does not care), converted to bf16 in registers
+//         (v_cvt_scalef32_pk_bf16_fp8: every e4m3 value is exact in bf16; the per-row scale is applied in the epilogue)
+template <bool W8> struct WChunk;
+template <> struct WChunk<false> {
+    static constexpr int BYTES = 2048;
+    bf16x8 v[2];
+    __device__ __forceinline__ void load(const char* p, int64_t c) {
+        v[0] = ld8_nt(reinterpret_cast<const kr_bf16*>(p + c * BYTES));
+        v[1] = ld8_nt(reinterpret_cast<const kr_bf16*>(p + c * BYTES + 1024));
+    }
+    __device__ __forceinline__ bf16x8 frag(int h) const { return v[h]; }
+    static __device__ __forceinline__ int x_byte(int h, int fg) { return h * 64 + fg * 16; }  // inside the chunk's 128 B of x
+};
+template <> struct WChunk<true> {
+    static constexpr int BYTES = 1024;
+    u32x4 q;
+    __device__ __forceinline__ void load(const char* p, int64_t c) {
+        q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + c * BYTES));
+    }
+    __device__ __forceinline__ bf16x8 frag(int h) const {
+        // each conversion yields two bf16 packed in one register; they are moved as 32-bit words (element-wise
+        // extraction of the builtin's 2 x bf16 result is mis-lowered by this compiler: both halves read the low one)
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int w = (int)q[2 * h + i];
+            o[2 * i + 0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+            o[2 * i + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true));
+        }
+        return __builtin_bit_cast(bf16x8, o);
+    }
+    static __device__ __forceinline__ int x_byte(int h, int fg) { return fg * 32 + h * 16; }
+};
+
+__device__ __forceinline__ void apply_w_scale(const float* w_scale, int n, f32x4& acc) {
+    if (w_scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(w_scale + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] *= sc[j];
+    }
+}
 
 __device__ __forceinline__ void better(float& bv, int& bi, float v, int i) {
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
@@ -436,8 +484,9 @@ template <> struct WideCfg<56> { static constexpr int U = 8, RL = 7; };      // 
 // wave-uniform branch at the top of the kernel (each contains the workgroup's single barrier): a branch around
 // the weight loads inside a common body would make the compiler's s_waitcnt bookkeeping assume the shorter
 // path, and the wait for x would become a wait for the weights.
-template <int EPI, int NCH, bool ACTIVE>
+template <int EPI, int NCH, bool ACTIVE, bool W8>
 __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
+    using WC = WChunk<W8>;
     constexpr int U = WideCfg<NCH>::U, RL = WideCfg<NCH>::RL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = a.wide_waves, nblk = a.wide_blocks;
@@ -471,14 +520,12 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
         }
     }
     // ---- ... then the weight ring
-    bf16x8 wbuf[U][2];
-    const kr_bf16* wp = a.wp + ((int64_t)(ACTIVE ? t : 0) * nchunks) * 1024 + lane * 8;
+    WC wbuf[U];
+    const char* wbase = reinterpret_cast<const char*>(a.wp) + lane * 16;
+    const char* wp = wbase + ((int64_t)(ACTIVE ? t : 0) * nchunks) * WC::BYTES;
     if (ACTIVE) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wbuf[u][0] = ld8_nt(wp + (int64_t)u * 1024);
-            wbuf[u][1] = ld8_nt(wp + (int64_t)u * 1024 + 512);
-        }
+        for (int u = 0; u < U; ++u) wbuf[u].load(wp, u);
     }
     __builtin_amdgcn_sched_barrier(0);  // everything above is issued before any of the norm arithmetic below
     // ---- x -> LDS, RMS-normalised when norm_w is given
@@ -547,7 +594,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
         }
         return;
     }
-    const char* xl = smem + (fr < M ? fr : 0) * xrow + fg * 16;
+    const char* xl = smem + (fr < M ? fr : 0) * xrow;
     const int pidx = t;  // this wave's partial-argmax slot: blockIdx.x + blocks * wave
     float rbv = -INFINITY;
     int rbi = 0x7fffffff;
@@ -555,7 +602,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     for (; t < ntiles; t += stride) {
         const int tn = t + stride;
         const bool more = tn < ntiles;
-        const kr_bf16* wpn = a.wp + ((int64_t)(more ? tn : t) * nchunks) * 1024 + lane * 8;
+        const char* wpn = wbase + ((int64_t)(more ? tn : t) * nchunks) * WC::BYTES;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int cc = 0; cc < nchunks; cc += U) {
 #pragma unroll
@@ -564,22 +611,21 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
                 // keep the scheduler from hoisting every chunk's LDS reads to the top (their registers would
                 // not fit next to a whole-tile ring)
                 if ((u & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + c * 128);
-                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + 64);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][0], x0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][1], x1, acc, 0, 0, 0);
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + WC::x_byte(0, fg));
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + WC::x_byte(1, fg));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u].frag(0), x0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u].frag(1), x1, acc, 0, 0, 0);
                 const int cn = c + U;
                 if (cn < nchunks) {
-                    wbuf[u][0] = ld8_nt(wp + (int64_t)cn * 1024);
-                    wbuf[u][1] = ld8_nt(wp + (int64_t)cn * 1024 + 512);
+                    wbuf[u].load(wp, cn);
                 } else if (more) {  // the ring runs on into the next tile
-                    wbuf[u][0] = ld8_nt(wpn + (int64_t)(cn - nchunks) * 1024);
-                    wbuf[u][1] = ld8_nt(wpn + (int64_t)(cn - nchunks) * 1024 + 512);
+                    wbuf[u].load(wpn, cn - nchunks);
                 }
             }
         }
         wp = wpn;
         // ---- epilogue of this wave's tile: lane = (row b, features 4*fg .. 4*fg+3)
+        apply_w_scale(a.w_scale, t * 16 + fg * 4, acc);
         if (EPI == DEPI_SILU8) {
             float u4[4];
 #pragma unroll
@@ -634,19 +680,19 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     }
 }
 
-template <int EPI, int NCH>
+template <int EPI, int NCH, bool W8>
 __global__ void __launch_bounds__(512) dec_wide_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x + a.wide_blocks * wave < (a.N >> 4)) dec_wide_body<EPI, NCH, true>(a, smem);
-    else dec_wide_body<EPI, NCH, false>(a, smem);
+    if ((int)blockIdx.x + a.wide_blocks * wave < (a.N >> 4)) dec_wide_body<EPI, NCH, true, W8>(a, smem);
+    else dec_wide_body<EPI, NCH, false, W8>(a, smem);
 }
 
-template <int EPI, int NCH>
-int launch_wide_n(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+template <int EPI, int NCH, bool W8>
+int launch_wide_w(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     const size_t lds = (size_t)a.M * (a.K * 2 + 16);
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_wide: x needs %zu bytes of LDS", lds);
-    auto fn = &dec_wide_kernel<EPI, NCH>;
+    auto fn = &dec_wide_kernel<EPI, NCH, W8>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -655,6 +701,11 @@ int launch_wide_n(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+template <int EPI, int NCH>
+int launch_wide_n(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+    return a.w_scale ? launch_wide_w<EPI, NCH, true>(a, blocks, waves, s) : launch_wide_w<EPI, NCH, false>(a, blocks, waves, s);
 }
 
 template <int EPI>
@@ -685,9 +736,10 @@ constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 
 // U = ring depth in 64-wide K chunks: the host picks the smallest instantiated U that covers a wave's share of K
 // (then every chunk is requested up front and at most one request per wave is redundant), else the deepest ring.
-template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U>
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8>
 __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using WC = WChunk<W8>;
     constexpr int RL = NarrowCfg<NCH>::RL;
     constexpr bool FULL = NCH != 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -711,9 +763,10 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
 #pragma unroll
         for (int t = 0; t < NT; ++t) tile[t] = g * NT + t;
     }
-    const kr_bf16* wp[NT];
+    const char* wp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = a.wp + ((int64_t)min(tile[t], ntiles - 1) * nchunks) * 1024 + lane * 8;
+    for (int t = 0; t < NT; ++t)
+        wp[t] = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(tile[t], ntiles - 1) * nchunks) * WC::BYTES + lane * 16;
     const int rb = fr < M ? fr : 0;  // batch row of this lane's accumulator column
 
     // ---- 1. the oldest loads of every wave: what the prologue and the epilogue wait for
@@ -725,7 +778,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     bf16x8 xv[NORM ? RL : 1], nwv[NORM ? RL : 1];
     f32x4 pv[PKS ? PKS : 1][NORM ? RL : 1][2];
     bf16x8 xf[NORM ? 1 : U][2];
-    const kr_bf16* xg = a.x + (int64_t)rb * a.ldx + fg * 8;
+    const char* xg = reinterpret_cast<const char*>(a.x + (int64_t)rb * a.ldx);   // x fragments: + c*128 + WC::x_byte(h, fg)
     if (NORM) {
         const int b = wave < M ? wave : 0;
 #pragma unroll
@@ -746,20 +799,17 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = min(max(min(c0 + u, c1 - 1), cb0), nchunks - 1);
-            xf[u][0] = ld8(xg + c * 64);
-            xf[u][1] = ld8(xg + c * 64 + 32);
+            xf[u][0] = *reinterpret_cast<const bf16x8*>(xg + c * 128 + WC::x_byte(0, fg));
+            xf[u][1] = *reinterpret_cast<const bf16x8*>(xg + c * 128 + WC::x_byte(1, fg));
         }
     }
     // ---- 2. the weight ring (clamped, not branched: short waves re-request their last chunk)
-    bf16x8 wbuf[U][NT][2];
+    WC wbuf[U][NT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = min(max(min(c0 + u, c1 - 1), cb0), nchunks - 1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)c * 1024);
-            wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)c * 1024 + 512);
-        }
+        for (int t = 0; t < NT; ++t) wbuf[u][t].load(wp[t], c);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -852,7 +902,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     }
 
     // ---- 5. K loop of this wave
-    const char* xl = smem + rb * xrow + fg * 16;
+    const char* xl = smem + rb * xrow;
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -863,28 +913,25 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
             if (c < c1) {
                 bf16x8 x0, x1;
                 if (NORM) {
-                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128);
-                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + 64);
+                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + WC::x_byte(0, fg));
+                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + WC::x_byte(1, fg));
                 } else {
                     x0 = xf[u][0];
                     x1 = xf[u][1];
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][0], x0, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t][1], x1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t].frag(0), x0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t].frag(1), x1, acc[t], 0, 0, 0);
                 }
                 const int cn = c + U;
                 if (cn < c1) {
                     if (!NORM) {
-                        xf[u][0] = ld8(xg + cn * 64);
-                        xf[u][1] = ld8(xg + cn * 64 + 32);
+                        xf[u][0] = *reinterpret_cast<const bf16x8*>(xg + cn * 128 + WC::x_byte(0, fg));
+                        xf[u][1] = *reinterpret_cast<const bf16x8*>(xg + cn * 128 + WC::x_byte(1, fg));
                     }
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        wbuf[u][t][0] = ld8_nt(wp[t] + (int64_t)cn * 1024);
-                        wbuf[u][t][1] = ld8_nt(wp[t] + (int64_t)cn * 1024 + 512);
-                    }
+                    for (int t = 0; t < NT; ++t) wbuf[u][t].load(wp[t], cn);
                 }
             }
         }
@@ -907,6 +954,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     }
     const int b = fr;
     if (b >= M) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) apply_w_scale(a.w_scale, min(tile[t], ntiles - 1) * 16 + fg * 4, sum[t]);
     if (EPI == DEPI_ROPE_KV) {
         const int hh = tile[0] >> 3;                   // global head index in [q heads | k heads | v heads]
         const int i0 = (tile[0] & 7) * 16 + fg * 4;    // channel in [0, 64)
@@ -971,13 +1020,13 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     }
 }
 
-template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U>
-int launch_narrow_u(DecLinArgs& a, int groups, kr_stream s) {
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8>
+int launch_narrow_w(DecLinArgs& a, int groups, kr_stream s) {
     const int nchunks = a.K >> 6, cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const size_t xbytes = NORM ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
     const size_t lds = xbytes + (size_t)WAVES * NT * 256 * 4;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_narrow: needs %zu bytes of LDS", lds);
-    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM, U>;
+    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM, U, W8>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -986,6 +1035,12 @@ int launch_narrow_u(DecLinArgs& a, int groups, kr_stream s) {
     fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U>
+int launch_narrow_u(DecLinArgs& a, int groups, kr_stream s) {
+    return a.w_scale ? launch_narrow_w<NT, EPI, WAVES, NCH, PKS, NORM, U, true>(a, groups, s)
+                     : launch_narrow_w<NT, EPI, WAVES, NCH, PKS, NORM, U, false>(a, groups, s);
 }
 
 // chunks of K the busiest wave of a workgroup owns
@@ -1466,10 +1521,10 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
     }
 }
 
-extern "C" int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
-                                     const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
-                                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
-                                     float* amax_val, int32_t* amax_idx, kr_stream s) {
+static int wide_impl(int mode, const kr_bf16* x, int64_t ldx, const void* w_packed, const float* w_scale, const kr_bf16* bias,
+                     const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
+                     float* amax_val, int32_t* amax_idx, kr_stream s) {
     KR_CHECK_ARG(x && w_packed, "kr_linear_decode_wide: null pointer");
     KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode_wide: M=%d must be in 1..16", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 512 == 0 && K <= 4096,
@@ -1477,7 +1532,8 @@ extern "C" int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, co
     KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_wide: ldx");
     KR_CHECK_ARG(blocks > 0 && waves >= 1 && waves <= 8, "kr_linear_decode_wide: blocks=%d waves=%d", blocks, waves);
     DecLinArgs a{};
-    a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.x = x; a.ldx = ldx; a.wp = reinterpret_cast<const kr_bf16*>(w_packed); a.w_scale = w_scale; a.bias = bias;
+    a.norm_w = norm_w; a.norm_eps = norm_eps;
     a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.ksplit = 1; a.amax_val = amax_val; a.amax_idx = amax_idx;
     a.wide_blocks = blocks; a.wide_waves = waves;
@@ -1497,8 +1553,26 @@ extern "C" int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, co
     }
 }
 
-extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
-                                       kr_bf16* x_out, int64_t ldxo, const kr_bf16* w_packed, const kr_bf16* bias,
+extern "C" int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
+                                     const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                                     kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
+                                     float* amax_val, int32_t* amax_idx, kr_stream s) {
+    return wide_impl(mode, x, ldx, w_packed, nullptr, bias, norm_w, norm_eps, residual, ldr, out, out_f32, ldc, M, N, K, blocks,
+                     waves, amax_val, amax_idx, s);
+}
+
+extern "C" int kr_linear_decode_wide_fp8(int mode, const kr_bf16* x, int64_t ldx, const uint8_t* w_packed_fp8,
+                                         const float* w_scale, const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps,
+                                         const kr_bf16* residual, int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc,
+                                         int M, int N, int K, int blocks, int waves, float* amax_val, int32_t* amax_idx,
+                                         kr_stream s) {
+    KR_CHECK_ARG(w_scale, "kr_linear_decode_wide_fp8: w_scale is NULL");
+    return wide_impl(mode, x, ldx, w_packed_fp8, w_scale, bias, norm_w, norm_eps, residual, ldr, out, out_f32, ldc, M, N, K,
+                     blocks, waves, amax_val, amax_idx, s);
+}
+
+static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                       kr_bf16* x_out, int64_t ldxo, const void* w_packed, const float* w_scale, const kr_bf16* bias,
                                        const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                                        kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
                                        const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
@@ -1514,7 +1588,8 @@ extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, 
     KR_CHECK_ARG(!part_in || (norm_w && n_part_in == 2 && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0),
                  "kr_linear_decode_narrow: partial sums need the norm prologue, 2 slabs and a separate x_out");
     DecLinArgs a{};
-    a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.x = x; a.ldx = ldx; a.wp = reinterpret_cast<const kr_bf16*>(w_packed); a.w_scale = w_scale; a.bias = bias;
+    a.norm_w = norm_w; a.norm_eps = norm_eps;
     a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.ksplit = ksplit;
     a.part_in = part_in; a.x_out = x_out; a.ldxo = ldxo;
@@ -1545,6 +1620,31 @@ extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, 
             kr_set_error("kr_linear_decode_narrow: mode %d not supported (PLAIN, ROPE_KV)", mode);
             return KR_ERR_ARG;
     }
+}
+
+extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                       kr_bf16* x_out, int64_t ldxo, const kr_bf16* w_packed, const kr_bf16* bias,
+                                       const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
+                                       kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
+                                       const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
+                                       kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
+                                       kr_stream s) {
+    return narrow_impl(mode, x, ldx, part_in, n_part_in, x_out, ldxo, w_packed, nullptr, bias, norm_w, norm_eps, residual, ldr, out,
+                       out_f32, ldc, M, N, K, waves, ksplit, cs_table, cs_stride, prompt_len, ctx_len, q_out, kcache, vtcache,
+                       heads, kv_heads, s_max, s);
+}
+
+extern "C" int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                           kr_bf16* x_out, int64_t ldxo, const uint8_t* w_packed_fp8, const float* w_scale,
+                                           const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual,
+                                           int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves,
+                                           int ksplit, const float* cs_table, int cs_stride, const int32_t* prompt_len,
+                                           const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads,
+                                           int kv_heads, int s_max, kr_stream s) {
+    KR_CHECK_ARG(w_scale, "kr_linear_decode_narrow_fp8: w_scale is NULL");
+    return narrow_impl(mode, x, ldx, part_in, n_part_in, x_out, ldxo, w_packed_fp8, w_scale, bias, norm_w, norm_eps, residual, ldr,
+                       out, out_f32, ldc, M, N, K, waves, ksplit, cs_table, cs_stride, prompt_len, ctx_len, q_out, kcache, vtcache,
+                       heads, kv_heads, s_max, s);
 }
 
 extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,

@@ -149,3 +149,24 @@ extern "C" int kr_prefetch(const void* ptr_, size_t bytes, int blocks, kr_stream
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
+
+
+// ---- fp8 e4m3fn -> bf16 through the instruction the decode kernels use (pins the hardware's number format)
+namespace {
+__global__ void fp8_to_bf16_kernel(const uint8_t* __restrict__ src, kr_bf16* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const int w = (int)src[i] | (i + 1 < n ? (int)src[i + 1] << 8 : 0);
+    const unsigned v = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+    dst[i] = (kr_bf16)(v & 0xffffu);
+    if (i + 1 < n) dst[i + 1] = (kr_bf16)(v >> 16);
+}
+}  // namespace
+
+extern "C" int kr_fp8_to_bf16(const uint8_t* src, kr_bf16* dst, int64_t n, kr_stream s) {
+    KR_CHECK_ARG(src && dst && n >= 0, "kr_fp8_to_bf16: bad args");
+    if (n == 0) return KR_OK;
+    fp8_to_bf16_kernel<<<(unsigned)((n / 2 + 256) / 256), 256, 0, kr_hs(s)>>>(src, dst, n);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}

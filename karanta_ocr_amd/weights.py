@@ -199,6 +199,81 @@ def pack_w16x64(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(w.reshape(n // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)).reshape(n, k)
 
 
+# ----------------------------------------------------------------------------- fp8 (OCP e4m3fn) weight-only quantisation
+# BASELINE.json config 5: decoder Linears in fp8 with one fp32 scale per output channel, activations / lm_head / ViT in
+# bf16.  gfx950 converts OCP e4m3fn (4 exponent bits, bias 7, 3 mantissa bits, max 448, no infinities) in hardware
+# (v_cvt_scalef32_pk_bf16_fp8); every e4m3 value is exact in bf16.
+def _e4m3_table() -> np.ndarray:
+    codes = np.arange(256, dtype=np.int64)
+    sign = np.where(codes & 0x80, -1.0, 1.0)
+    e, m = (codes >> 3) & 0xF, codes & 0x7
+    val = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * 2.0 ** (e - 7.0))
+    val = sign * val
+    val[(codes & 0x7F) == 0x7F] = np.nan          # the two NaN encodings
+    return val.astype(np.float32)
+
+
+E4M3 = _e4m3_table()
+E4M3_MAX = 448.0
+
+
+def fp8_e4m3_to_f32(q: np.ndarray) -> np.ndarray:
+    return E4M3[np.asarray(q, np.uint8)]
+
+
+def f32_to_fp8_e4m3(x: np.ndarray) -> np.ndarray:
+    """Round to nearest e4m3fn code, ties to the even mantissa, saturating at +-448 (finite input)."""
+    x = np.asarray(x, np.float32)
+    mag = np.minimum(np.abs(x).astype(np.float64), E4M3_MAX)
+    pos = E4M3[:0x7F].astype(np.float64)           # codes 0x00..0x7E: increasing, 0 .. 448
+    hi = np.clip(np.searchsorted(pos, mag, side="left"), 0, 0x7E)
+    lo = np.clip(hi - 1, 0, 0x7E)
+    d_lo, d_hi = mag - pos[lo], pos[hi] - mag
+    pick_hi = (d_hi < d_lo) | ((d_hi == d_lo) & ((hi & 1) == 0))
+    code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    return (code | np.where(np.signbit(x), 0x80, 0).astype(np.uint8)).astype(np.uint8)
+
+
+def quantize_fp8_rows(w: np.ndarray) -> tuple:
+    """[N, K] fp32 -> (codes uint8 [N, K], scale fp32 [N]) with w ~ scale[:, None] * e4m3(codes): per output channel,
+    scale = max|row| / 448 (1 for an all-zero row)."""
+    w = np.asarray(w, np.float32)
+    amax = np.abs(w).max(axis=1)
+    scale = np.where(amax > 0, amax / np.float32(E4M3_MAX), np.float32(1.0)).astype(np.float32)
+    return f32_to_fp8_e4m3(w / scale[:, None]), scale
+
+
+def pack_w16x64_fp8(q: np.ndarray) -> np.ndarray:
+    """Row-major uint8 ``[N, K]`` -> ``[N/16][K/64][4][16][16]``: one (16-row, 64-column) block is 1 KiB in lane order,
+    lane ``l = 16*g + r`` holding row ``r``, columns ``16g .. 16g+15`` — one 16-byte load per lane feeds two
+    ``v_mfma_f32_16x16x32_bf16`` k-steps (columns 16g..16g+7, then 16g+8..16g+15; x is read in the same order)."""
+    n, k = q.shape
+    if n % 16 or k % 64:
+        raise ValueError(f"pack_w16x64_fp8: shape {q.shape} is not a multiple of (16, 64)")
+    return np.ascontiguousarray(q.reshape(n // 16, 16, k // 64, 4, 16).transpose(0, 2, 3, 1, 4)).reshape(n, k)
+
+
+def unpack_w16x64_fp8(p: np.ndarray) -> np.ndarray:
+    n, k = p.shape
+    return np.ascontiguousarray(p.reshape(n // 16, k // 64, 4, 16, 16).transpose(0, 3, 1, 2, 4)).reshape(n, k)
+
+
+FP8_LINEARS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+               "mlp.down_proj")
+
+
+def fp8_dequantized_weights(weights: Dict[str, np.ndarray], cfg: ModelConfig) -> Dict[str, np.ndarray]:
+    """The state dict with every decoder Linear replaced by scale * e4m3(codes) (fp32): the model the fp8 engine
+    computes with, for the oracle and for loading.  Biases, norms, embeddings, lm_head and the ViT are untouched."""
+    out = dict(weights)
+    for i in range(cfg.text.num_layers):
+        for n in FP8_LINEARS:
+            key = f"model.language_model.layers.{i}.{n}.weight"
+            q, s = quantize_fp8_rows(as_f32(weights[key]))
+            out[key] = (fp8_e4m3_to_f32(q) * s[:, None]).astype(np.float32)
+    return out
+
+
 def unpack_w16x64(p: np.ndarray) -> np.ndarray:
     n, k = p.shape
     return np.ascontiguousarray(p.reshape(n // 16, k // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4)).reshape(n, k)

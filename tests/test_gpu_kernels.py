@@ -1071,6 +1071,84 @@ def test_image_front_end_rejects_bad_geometry(L):
         L.kr_image_resize_bicubic_u8(ptr(x), 56, 56, ptr(x), 28, 28, 0, 0, 0, 0, 0, 0, 0, 0)
 
 
+# ----------------------------------------------------------------------------- fp8 (e4m3fn) weights
+def test_fp8_hardware_conversion_is_ocp_e4m3fn(L):
+    """Every fp8 code through the conversion instruction the decode kernels use == the host's e4m3fn table
+    (bias 7, max 448, NaN at 0x7F / 0xFF): pins the number format the quantiser targets."""
+    from karanta_ocr_amd import weights as W
+    codes = torch.arange(256, dtype=torch.uint8, device=DEV)
+    out = torch.zeros(256, dtype=torch.bfloat16, device=DEV)
+    L.kr_fp8_to_bf16(ptr(codes), ptr(out), 256, 0)
+    got = out.float().cpu().numpy()
+    ok = ~np.isnan(W.E4M3)
+    np.testing.assert_array_equal(got[ok], W.E4M3[ok])
+    assert np.isnan(got[~ok]).all()
+
+
+def fp8_ref(x, Wf, bias=None, res=None, epi=EPI_NONE):
+    """Reference of an fp8 linear: weights replaced by scale * e4m3(codes), then the bf16 reference."""
+    from karanta_ocr_amd import weights as W
+    q, sc = W.quantize_fp8_rows(Wf)
+    return q, sc, ref_linear(x, (W.fp8_e4m3_to_f32(q) * sc[:, None]).astype(np.float32), bias, res, epi)
+
+
+@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("N,K,blocks,waves", [(16 * 37, 512, 3, 5), (16 * 37, 1536, 256, 4), (16 * 41, 3584, 5, 2), (16 * 45, 2048, 4, 3)])
+def test_linear_wide_fp8_exact_on_small_integers(L, M, N, K, blocks, waves):
+    """Integer weights in [-8, 8] are exact in e4m3; rows scaled by powers of two keep everything exact: a wrong k
+    permutation between the fp8 fragment and x, a wrong chunk stride or a missing scale shows as an integer error."""
+    from karanta_ocr_amd import weights as W
+    rng = np.random.default_rng(M + N + K)
+    x = ints(rng, M, K)
+    Wi = rng.integers(-8, 9, size=(N, K)).astype(np.float32)
+    Wi[:, K // 2 + 40:] = 0
+    Wi[::3, 100:300] = 1
+    Wi[:, 0] = 448                                    # every row's max is 448 -> the row scale is exactly its power of two
+    scale_pow = (2.0 ** rng.integers(-2, 3, size=N)).astype(np.float32)
+    q, sc = W.quantize_fp8_rows(Wi * scale_pow[:, None])
+    np.testing.assert_array_equal(W.fp8_e4m3_to_f32(q) * sc[:, None], Wi * scale_pow[:, None])    # exact by construction
+    xd, qd, sd = dev_bf16(x), torch.from_numpy(W.pack_w16x64_fp8(q)).to(DEV), torch.from_numpy(sc).to(DEV)
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    L.kr_linear_decode_wide_fp8(DEC_PLAIN, ptr(xd), K, ptr(qd), ptr(sd), 0, 0, 1e-6, 0, 0, 0, ptr(out), N, M, N, K, blocks, waves,
+                                0, 0, 0)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref_linear(x, Wi * scale_pow[:, None]))
+
+
+@pytest.mark.parametrize("M,K,blocks,waves", [(8, 1536, 256, 5), (16, 3584, 9, 8), (3, 512, 2, 3)])
+def test_linear_wide_fp8_silu8_norm(L, M, K, blocks, waves):
+    from karanta_ocr_amd import weights as W
+    rng = np.random.default_rng(262 + M)
+    ff = 1016
+    x, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x, nw, 1e-6, O._Policy("bf16")))
+    q, sc, ref = fp8_ref(xn, Wp, epi=EPI_SILU_MUL8)
+    xd, qd, sd, nd = dev_bf16(x), torch.from_numpy(W.pack_w16x64_fp8(q)).to(DEV), torch.from_numpy(sc).to(DEV), dev_bf16(nw)
+    out = torch.zeros(M, ff, dtype=torch.bfloat16, device=DEV)
+    L.kr_linear_decode_wide_fp8(DEC_SILU8, ptr(xd), K, ptr(qd), ptr(sd), 0, ptr(nd), 1e-6, 0, 0, ptr(out), 0, ff, M, 2 * ff, K, blocks,
+                                waves, 0, 0, 0)
+    assert_close_bf16(host(out), ref, what="wide fp8 silu8")
+
+
+@pytest.mark.parametrize("M,N,K,waves,ksplit", [(8, 1536, 8960, 16, 2), (16, 96, 8960, 8, 1), (3, 48, 256, 8, 1), (8, 1536, 1536, 8, 1)])
+def test_linear_narrow_fp8_plain_and_slabs(L, M, N, K, waves, ksplit):
+    from karanta_ocr_amd import weights as W
+    rng = np.random.default_rng(M + N + K + 5)
+    x, Wf = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    q, sc, ref = fp8_ref(x, Wf)
+    xd, qd, sd = dev_bf16(x), torch.from_numpy(W.pack_w16x64_fp8(q)).to(DEV), torch.from_numpy(sc).to(DEV)
+    if ksplit > 1:
+        slabs = torch.zeros(ksplit, M, N, dtype=torch.float32, device=DEV)
+        L.kr_linear_decode_narrow_fp8(DEC_PLAIN, ptr(xd), K, 0, 0, 0, 0, ptr(qd), ptr(sd), 0, 0, 1e-6, 0, 0, 0, ptr(slabs), N, M, N, K,
+                                      waves, ksplit, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+        got = slabs.sum(0).cpu().numpy()
+    else:
+        out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        L.kr_linear_decode_narrow_fp8(DEC_PLAIN, ptr(xd), K, 0, 0, 0, 0, ptr(qd), ptr(sd), 0, 0, 1e-6, 0, 0, 0, ptr(out), N, M, N, K,
+                                      waves, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+        got = out.cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
 def test_gumbel_argmax_matches_oracle_noise(L):
     """kr_gumbel_argmax partials against the oracle's sample_scores: same counter-based noise (integer hash bit-exact,
     the two logs within float rounding), T = 0 rows untouched, ties to the lowest index, sampled frequencies follow

@@ -233,3 +233,27 @@ def test_qwen2_5_config_from_hf_dict_and_weight_names():
     assert "model.visual.blocks.0.mlp.fc1.weight" not in names
     old = weight_shapes(CONFIGS["tiny"])
     assert "model.visual.blocks.0.norm1.bias" in old and "model.visual.blocks.0.mlp.fc1.weight" in old
+
+
+def test_fp8_e4m3_codec_and_packing():
+    """OCP e4m3fn: table values, round-to-nearest-even encoding, saturation, per-row scales, the decode layout."""
+    from karanta_ocr_amd import weights as W
+    t = W.E4M3
+    assert t[0x00] == 0 and t[0x01] == 2.0 ** -9 and t[0x08] == 2.0 ** -6 and t[0x38] == 1.0 and t[0x7E] == 448.0
+    assert t[0xB8] == -1.0 and np.isnan(t[0x7F]) and np.isnan(t[0xFF])
+    codes = np.asarray([c for c in range(256) if (c & 0x7F) != 0x7F], np.uint8)
+    np.testing.assert_array_equal(W.f32_to_fp8_e4m3(W.fp8_e4m3_to_f32(codes)) & 0x7F | (codes & 0x80), codes | 0)   # -0 keeps its sign bit
+    # ties to even: 1.0625 is halfway between 1.0 (0x38) and 1.125 (0x39) -> 0x38; 1.1875 between 0x39 and 0x3A -> 0x3A
+    np.testing.assert_array_equal(W.f32_to_fp8_e4m3(np.asarray([1.0625, 1.1875, 1000.0, -1000.0, 1e-10], np.float32)),
+                                  np.asarray([0x38, 0x3A, 0x7E, 0xFE, 0x00], np.uint8))
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((32, 128)).astype(np.float32) * rng.uniform(0.01, 5, (32, 1)).astype(np.float32)
+    w[7] = 0
+    q, s = W.quantize_fp8_rows(w)
+    deq = W.fp8_e4m3_to_f32(q) * s[:, None]
+    assert s[7] == 1 and not deq[7].any()
+    assert np.abs(deq - w).max() <= np.abs(w).max(1, keepdims=True).max() * 2.0 ** -4    # 3 mantissa bits
+    assert (np.abs(q.astype(np.int64) & 0x7F).max(1)[np.arange(32) != 7] == 0x7E).all()      # every row uses the full range
+    np.testing.assert_array_equal(W.unpack_w16x64_fp8(W.pack_w16x64_fp8(q)), q)
+    p = W.pack_w16x64_fp8(q).reshape(2, 2, 4, 16, 16)                    # [tile][chunk][g][r][16]
+    np.testing.assert_array_equal(p[1, 1, 2, 5], q[16 + 5, 64 + 32:64 + 48])
