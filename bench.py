@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--decode-splits", type=int, default=8)
+    ap.add_argument("--weights", default="bf16", choices=("bf16", "fp8"),
+                    help="fp8: decoder Linears as e4m3fn codes + per-row scales (BASELINE.json config 5); activations stay bf16")
     args = ap.parse_args()
 
     import torch
@@ -187,7 +189,7 @@ def main():
 
     s_max = (max(P) + T_out + 63) // 64 * 64
     eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(len(p) for p in pvs),
-                 max_prompt_tokens=sum(P), decode_splits=args.decode_splits)
+                 max_prompt_tokens=sum(P), decode_splits=args.decode_splits, weight_dtype=args.weights)
     pix_dev = torch.from_numpy(np.concatenate(pvs, 0)).to(dev)
 
     # ---------------- weights: rank 0 materialises them, the others receive the arena over RCCL
@@ -266,7 +268,7 @@ def main():
         value = pages_total / elapsed
         # decode roofline: bytes/step = W_dec + sum_seq ctx*kv_B at mean ctx = P + T_out/2
         kvb = cfg.text.kv_bytes_per_token
-        bytes_step = cfg.decoder_weight_bytes() + sum(p + T_out / 2 for p in P) * kvb
+        bytes_step = cfg.decoder_weight_bytes(args.weights) + sum(p + T_out / 2 for p in P) * kvb
         t_step_roof = bytes_step / (HBM_PEAK_GBS * 1e9)
         decode_step_s = phase["decode_s"] / max(T_out - 1, 1)
         traffic = pmc_traffic()   # the committed PMC pass is of the default workload: not quoted for other shapes
@@ -277,7 +279,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": f"{cfg.name} bf16 greedy, batch={B} synthetic {args.page}x{args.page} pages per GPU, "
+                "workload": f"{cfg.name} {'bf16' if args.weights == 'bf16' else 'fp8-weight / bf16-activation'} greedy, batch={B} synthetic {args.page}x{args.page} pages per GPU, "
                             f"max_pixels={args.max_pixels} (grid {grids[0][1]}x{grids[0][2]}, {n_img_tok[0]} image tokens), "
                             f"prompt P={P[0]} tokens, T_out={T_out} (ignore_eos), random-init weights",
                 "global_batch": world * B, "parallelism": f"dp{world}", "decode": "hipGraph replay" if not args.no_graph else "eager",

@@ -109,19 +109,19 @@ class ModelConfig:
     eos_token_ids: Tuple[int, ...] = (151645, 151643)
     pad_token_id: int = 151643
 
-    def decoder_weight_bytes(self) -> int:
-        """Bytes of decoder weights read once per decode step in bf16
+    def decoder_weight_bytes(self, weight_dtype: str = "bf16") -> int:
+        """Bytes of decoder weights read once per decode step
         (all layer Linears + biases + norms + final norm + lm_head): the ``W_dec``
-        of SURVEY.md §8(d) / BASELINE.md §3."""
+        of SURVEY.md §8(d) / BASELINE.md §3.  ``fp8``: the layer Linears at one byte per weight plus one f32 scale per
+        output row; biases, norms and the lm_head stay bf16 (BASELINE.json config 5)."""
         t = self.text
-        per_layer = (
-            t.hidden_size * t.qkv_dim + t.qkv_dim  # qkv weight + bias
-            + t.q_dim * t.hidden_size  # o_proj
-            + 3 * t.hidden_size * t.intermediate_size  # gate, up, down
-            + 2 * t.hidden_size  # two RMSNorm weights
-        )
-        total = t.num_layers * per_layer + t.hidden_size + t.vocab_size * t.hidden_size
-        return 2 * total
+        linear = t.hidden_size * t.qkv_dim + t.q_dim * t.hidden_size + 3 * t.hidden_size * t.intermediate_size
+        rows = t.qkv_dim + t.hidden_size + 2 * t.intermediate_size + t.hidden_size       # output rows of the four matrices
+        small = t.qkv_dim + 2 * t.hidden_size                                            # qkv bias, two RMSNorm weights
+        head = t.hidden_size + t.vocab_size * t.hidden_size
+        if weight_dtype == "fp8":
+            return t.num_layers * (linear + 4 * rows + 2 * small) + 2 * head
+        return 2 * (t.num_layers * (linear + small) + head)
 
 
 QWEN2_VL_2B = ModelConfig(
@@ -206,8 +206,16 @@ TINY_25 = replace(
                         window_size=56, fullatt_block_indexes=(1, 3)),
 )
 
+# Test size with a decoder width the wide decode kernel takes (K % 512 == 0): the fp8-weight engine tests.
+TINY_W512 = replace(
+    TINY,
+    name="tiny-w512",
+    vision=replace(TINY.vision, hidden_size=512),
+    text=replace(TINY.text, hidden_size=512, intermediate_size=1024, num_heads=4, num_kv_heads=1),
+)
+
 CONFIGS: Dict[str, ModelConfig] = {
-    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, QWEN2_5_VL_3B, QWEN2_5_VL_7B, TINY, TINY_GQA, TINY_25)
+    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, QWEN2_5_VL_3B, QWEN2_5_VL_7B, TINY, TINY_GQA, TINY_25, TINY_W512)
 }
 
 

@@ -55,17 +55,23 @@ class DeviceWeights:
     * the patch-embed kernel matrix is zero-padded from K=1176 to 1216 (GEMM BK=64).
     """
 
-    def __init__(self, cfg: ModelConfig, device: torch.device):
+    def __init__(self, cfg: ModelConfig, device: torch.device, weight_dtype: str = "bf16"):
+        if weight_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"weight_dtype {weight_dtype!r} (bf16 or fp8)")
         self.cfg = cfg
         self.device = device
+        # fp8 (BASELINE.json config 5): the decoder Linears are ALSO kept as e4m3fn codes + one f32 scale per output
+        # row for the decode kernels (half the bytes per step); the bf16 entries then hold the dequantised values
+        # (what the prefill GEMMs read).  lm_head, embeddings, norms, biases and the ViT stay bf16.
+        self.weight_dtype = weight_dtype
         self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         self.nbytes = 0
         self.arena: Optional[torch.Tensor] = None
         self._plan()
 
-    def _add(self, name: str, shape: Tuple[int, ...]):
+    def _add(self, name: str, shape: Tuple[int, ...], itemsize: int = 2):
         self.layout[name] = (self.nbytes, tuple(shape))
-        self.nbytes = _align(self.nbytes + 2 * int(np.prod(shape)))
+        self.nbytes = _align(self.nbytes + itemsize * int(np.prod(shape)))
 
     def _plan(self):
         v, t = self.cfg.vision, self.cfg.text
@@ -101,6 +107,11 @@ class DeviceWeights:
             self._add(p + "ln2.w", (t.hidden_size,))
             self._add(p + "gate_up.w", (2 * t.intermediate_size, t.hidden_size))
             self._add(p + "down.w", (t.hidden_size, t.intermediate_size))
+            if self.weight_dtype == "fp8":
+                for n, shape in (("qkv", (t.qkv_dim, t.hidden_size)), ("o", (t.hidden_size, t.q_dim)),
+                                 ("gate_up", (2 * t.intermediate_size, t.hidden_size)), ("down", (t.hidden_size, t.intermediate_size))):
+                    self._add(p + n + ".w8", shape, itemsize=1)
+                    self._add(p + n + ".s", (shape[0],), itemsize=4)
         self._add("llm.norm.w", (t.hidden_size,))
         self._add("llm.lm_head", (t.vocab_size, t.hidden_size))
 
@@ -111,6 +122,17 @@ class DeviceWeights:
         off, shape = self.layout[name]
         n = int(np.prod(shape))
         return self.arena[off:off + 2 * n].view(BF16).view(*shape)
+
+    def view_u8(self, name: str) -> torch.Tensor:
+        off, shape = self.layout[name]
+        return self.arena[off:off + int(np.prod(shape))].view(*shape)
+
+    def view_f32(self, name: str) -> torch.Tensor:
+        off, shape = self.layout[name]
+        return self.arena[off:off + 4 * int(np.prod(shape))].view(torch.float32).view(*shape)
+
+    def has(self, name: str) -> bool:
+        return name in self.layout
 
     def _put(self, name: str, bits: np.ndarray):
         off, shape = self.layout[name]
@@ -164,12 +186,35 @@ class DeviceWeights:
         ff = t.intermediate_size
         if ff % 8:
             raise KarantaHipError(f"intermediate_size {ff} must be a multiple of 8")
+        fp8 = self.weight_dtype == "fp8"
         for i in range(t.num_layers):
             s, d = f"{Lm}layers.{i}.", f"llm.{i}."
             self._put(d + "ln1.w", _bits(w[s + "input_layernorm.weight"]))
             self._put(d + "ln2.w", _bits(w[s + "post_attention_layernorm.weight"]))
-            self._put(d + "qkv.w", pack_w16x64(np.concatenate([_bits(w[s + f"self_attn.{n}_proj.weight"]) for n in "qkv"], 0)))
             self._put(d + "qkv.b", np.concatenate([_bits(w[s + f"self_attn.{n}_proj.bias"]) for n in "qkv"], 0))
+            if fp8:
+                # quantise every original matrix row-wise (scale = max|row| / 448), then fuse / interleave codes,
+                # scales and the dequantised bf16 copy alike
+                from .weights import as_f32, fp8_e4m3_to_f32, pack_w16x64_fp8, quantize_fp8_rows
+                qs = {n: quantize_fp8_rows(as_f32(w[s + n + ".weight"])) for n in
+                      ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
+                       "mlp.up_proj", "mlp.down_proj")}
+                il = lambda a, b: np.stack([a.reshape((ff // 8, 8) + a.shape[1:]), b.reshape((ff // 8, 8) + b.shape[1:])], 1) \
+                    .reshape((2 * ff,) + a.shape[1:])
+                fused = {"qkv": tuple(np.concatenate([qs[f"self_attn.{n}_proj"][k] for n in "qkv"], 0) for k in (0, 1)),
+                         "o": qs["self_attn.o_proj"],
+                         "gate_up": (il(qs["mlp.gate_proj"][0], qs["mlp.up_proj"][0]), il(qs["mlp.gate_proj"][1], qs["mlp.up_proj"][1])),
+                         "down": qs["mlp.down_proj"]}
+                for n, (q, sc) in fused.items():
+                    off8, _ = self.layout[d + n + ".w8"]
+                    src = torch.from_numpy(np.ascontiguousarray(pack_w16x64_fp8(q)).reshape(-1))
+                    self.arena[off8:off8 + src.numel()].copy_(src, non_blocking=False)
+                    offs, _ = self.layout[d + n + ".s"]
+                    srcs = torch.from_numpy(np.ascontiguousarray(sc, np.float32).view(np.uint8).reshape(-1))
+                    self.arena[offs:offs + srcs.numel()].copy_(srcs, non_blocking=False)
+                    self._put(d + n + ".w", pack_w16x64(to_bf16_bits(fp8_e4m3_to_f32(q) * sc[:, None])))
+                continue
+            self._put(d + "qkv.w", pack_w16x64(np.concatenate([_bits(w[s + f"self_attn.{n}_proj.weight"]) for n in "qkv"], 0)))
             self._put(d + "o.w", pack_w16x64(_bits(w[s + "self_attn.o_proj.weight"])))
             g = _bits(w[s + "mlp.gate_proj.weight"]).reshape(ff // 8, 8, -1)   # 8-row interleave: KR_EPI_SILU_MUL8
             u = _bits(w[s + "mlp.up_proj.weight"]).reshape(ff // 8, 8, -1)
@@ -206,7 +251,8 @@ class GenerateResult:
 
 class Engine:
     def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
-                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 4):
+                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 4,
+                 weight_dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
         self.L = lib()
@@ -232,7 +278,8 @@ class Engine:
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
             raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
-        self.w = DeviceWeights(cfg, self.device)
+        self.w = DeviceWeights(cfg, self.device, weight_dtype)
+        self.fp8 = weight_dtype == "fp8"
         self._graphs: Dict[Tuple[int, bool], int] = {}
         self._prof_on = False
         self._prof_events: List[Tuple[C.c_void_p, C.c_void_p]] = []
@@ -309,6 +356,8 @@ class Engine:
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
         self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
+        if self.fp8 and not (self.wide_mode and self.narrow_mode):
+            raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
         wb, ww = self._wide_geometry(t.vocab_size)
         self.n_amax = wb * ww if self.wide_mode else (t.vocab_size // 16 + 1) // 2  # one argmax partial per wave
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
@@ -355,18 +404,32 @@ class Engine:
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _dec_narrow(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=8, ksplit=1,
-                    part_in=None, x_out=None, kc=0, vc=0):
-        """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32."""
+                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None):
+        """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32.
+        w8 / w_scale: the fp8 copy of W and its row scales (kr_linear_decode_narrow_fp8)."""
         t = self.cfg.text
         N, K = W.shape
         o = out if out is not None else out_f32
         ldc = o.stride(-2) if o is not None else 0  # slabs of the deferred split are [ksplit][M][ldc] with the CURRENT M, packed in d_part
-        self.L.kr_linear_decode_narrow(mode, ptr(x), x.stride(0), ptr(part_in), 2 if part_in is not None else 0, ptr(x_out),
-                                       x_out.stride(0) if x_out is not None else 0, ptr(W), ptr(bias), ptr(norm_w),
-                                       t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
-                                       ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs), self.max_new,
-                                       ptr(self.d_plen), ptr(self.d_ctx), ptr(self.d_q), kc, vc, t.num_heads,
-                                       t.num_kv_heads, self.s_max, self.s)
+        head = (mode, ptr(x), x.stride(0), ptr(part_in), 2 if part_in is not None else 0, ptr(x_out),
+                x_out.stride(0) if x_out is not None else 0)
+        tail = (ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
+                ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs), self.max_new, ptr(self.d_plen), ptr(self.d_ctx),
+                ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max, self.s)
+        if w8 is not None:
+            self.L.kr_linear_decode_narrow_fp8(*head, ptr(w8), ptr(w_scale), *tail)
+        else:
+            self.L.kr_linear_decode_narrow(*head, ptr(W), *tail)
+
+    def _w8kw(self, name: str) -> dict:
+        w8, sc = self._w8(name)
+        return {} if w8 is None else {"w8": w8, "w_scale": sc}
+
+    def _w8(self, name: str):
+        """(fp8 codes, row scales) of a decoder Linear when the engine runs on fp8 weights, else (None, None)."""
+        if self.fp8 and self.w.has(name + "8"):
+            return self.w.view_u8(name + "8"), self.w.view_f32(name[:-1] + "s")
+        return None, None
 
     def _wide_geometry(self, N: int):
         """(workgroups, waves) of a wide launch.  No idle waves: W = tiles per CU (at most 8), then just enough
@@ -376,14 +439,17 @@ class Engine:
         waves = self.wide_waves or min(8, -(-tiles // self.wide_blocks))
         return min(self.wide_blocks, -(-tiles // waves)), waves
 
-    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None):
+    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None):
         """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
         N, K = W.shape
         blocks, waves = self._wide_geometry(N)
         o = out if out is not None else out_f32
-        self.L.kr_linear_decode_wide(mode, ptr(x), x.stride(0), ptr(W), 0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0,
-                                     ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0, M, N, K, blocks, waves,
-                                     ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
+        tail = (0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0, ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0,
+                M, N, K, blocks, waves, ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
+        if w8 is not None:
+            self.L.kr_linear_decode_wide_fp8(mode, ptr(x), x.stride(0), ptr(w8), ptr(w_scale), *tail)
+        else:
+            self.L.kr_linear_decode_wide(mode, ptr(x), x.stride(0), ptr(W), *tail)
 
     def _h2d(self, dst: torch.Tensor, arr: np.ndarray):
         src = torch.from_numpy(np.ascontiguousarray(arr))
@@ -766,12 +832,13 @@ class Engine:
             if self.narrow_mode:
                 if pending:
                     self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
-                                     norm_w=w.view(p + "ln1.w"), part_in=self.d_part, x_out=x_other, kc=kc, vc=vc)
+                                     norm_w=w.view(p + "ln1.w"), part_in=self.d_part, x_out=x_other, kc=kc, vc=vc,
+                                     **self._w8kw(p + "qkv.w"))
                     x, x_other = x_other, x
                     pending = False
                 else:
                     self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
-                                     norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc)
+                                     norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, **self._w8kw(p + "qkv.w"))
             else:
                 self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                           waves=self.wv_qkv, kc=kc, vc=vc)
@@ -783,7 +850,7 @@ class Engine:
                                        self.s_max, self.n_split, hd ** -0.5, s)
             if self.attn_fused_merge:
                 if self.narrow_o:
-                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8)
+                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8, **self._w8kw(p + "o.w"))
                 else:
                     self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
             elif self.merge_in_o_proj:
@@ -792,7 +859,7 @@ class Engine:
             else:
                 L.kr_attn_decode_merge(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
                 if self.narrow_o:
-                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8)
+                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8, **self._w8kw(p + "o.w"))
                 else:
                     self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
             if self._prof_on:
@@ -802,7 +869,8 @@ class Engine:
                 L.kr_event_record(e0, s)
                 L.kr_event_record(e1, s)
             if self.wide_mode:
-                self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+                self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                               **self._w8kw(p + "gate_up.w"))
             else:
                 self._dec(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                           waves=self.wv_wide)
@@ -810,10 +878,11 @@ class Engine:
                 L.kr_event_record(e2, s)
             if self.defer_down and i + 1 < nl:
                 # 2 workgroups per tile; the slabs are added to x by the next layer's qkv prologue
-                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=16, ksplit=2)
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=16, ksplit=2,
+                                 **self._w8kw(p + "down.w"))
                 pending = True
             elif self.narrow_mode:
-                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=16)
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=16, **self._w8kw(p + "down.w"))
             else:
                 self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self.wv_down)
             for _ in range(self._extra_nulls):  # diagnostic: price of one more (empty) launch in the chain
@@ -867,7 +936,8 @@ class Engine:
                 for i in range(t.num_layers):
                     p = f"llm.{i}."
                     if self.wide_mode:
-                        self._dec_wide(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"))
+                        self._dec_wide(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                                       **self._w8kw(p + "gate_up.w"))
                     else:
                         self._dec(DEC_SILU8, self.d_x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                                   waves=self.wv_wide)
@@ -890,7 +960,8 @@ class Engine:
         L.kr_graph_destroy(g)
         ms.value = best
         n = reps * t.num_layers
-        nbytes = 2 * (2 * t.intermediate_size * t.hidden_size + t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
+        wbytes = 2 * t.intermediate_size * t.hidden_size * (1 if self.fp8 else 2) + (8 * t.intermediate_size if self.fp8 else 0)
+        nbytes = wbytes + 2 * (t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
         return {"launches": n, "avg_us": ms.value * 1e3 / n, "bytes_per_launch": nbytes}
 
     def _graph_for(self, B: int) -> int:

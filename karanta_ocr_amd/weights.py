@@ -221,6 +221,25 @@ def fp8_e4m3_to_f32(q: np.ndarray) -> np.ndarray:
     return E4M3[np.asarray(q, np.uint8)]
 
 
+def f32_to_fp8_e4m3_fast(x: np.ndarray) -> np.ndarray:
+    """`f32_to_fp8_e4m3` by integer arithmetic on the float32 bit patterns (a dozen vectorised passes instead of a
+    binary search per element: the 6.5 G weights of a 7B decoder quantise in minutes, not hours)."""
+    x = np.ascontiguousarray(x, np.float32)
+    bits = x.view(np.uint32)
+    sign = ((bits >> np.uint32(24)) & np.uint32(0x80)).astype(np.uint8)
+    u = bits & np.uint32(0x7FFFFFFF)
+    # normal e4m3 range (|x| >= 2^-6): rebias the exponent 127 -> 7, round the 23-bit mantissa to 3 bits, ties to even;
+    # a mantissa carry walks into the exponent by itself
+    r = u - np.uint32((127 - 7) << 23)
+    r = (r + np.uint32(0x7FFFF) + ((r >> np.uint32(20)) & np.uint32(1))) >> np.uint32(20)
+    # subnormal range (|x| < 2^-6): the code is round_half_even(|x| * 2^9), 0 .. 8 (8 = the smallest normal)
+    sub = np.rint(np.minimum(np.abs(x), np.float32(1.0)) * np.float32(512.0)).astype(np.uint32)
+    is_sub = u < np.uint32((127 - 6) << 23)
+    code = np.where(is_sub, sub, r)
+    code = np.minimum(code, np.uint32(0x7E)).astype(np.uint8)        # saturate (also tames the rebias wrap of tiny values)
+    return code | sign
+
+
 def f32_to_fp8_e4m3(x: np.ndarray) -> np.ndarray:
     """Round to nearest e4m3fn code, ties to the even mantissa, saturating at +-448 (finite input)."""
     x = np.asarray(x, np.float32)
@@ -240,7 +259,7 @@ def quantize_fp8_rows(w: np.ndarray) -> tuple:
     w = np.asarray(w, np.float32)
     amax = np.abs(w).max(axis=1)
     scale = np.where(amax > 0, amax / np.float32(E4M3_MAX), np.float32(1.0)).astype(np.float32)
-    return f32_to_fp8_e4m3(w / scale[:, None]), scale
+    return f32_to_fp8_e4m3_fast(w / scale[:, None]), scale
 
 
 def pack_w16x64_fp8(q: np.ndarray) -> np.ndarray:

@@ -274,3 +274,43 @@ def test_gpu_image_front_end_end_to_end(engines, tiny_models):
     from karanta_ocr_amd._lib import KarantaHipError
     with pytest.raises(KarantaHipError, match="images but"):
         eng.generate([PageRequest(pages_dev[0].input_ids, None, pages_dev[0].grids, images=[imgs[0], imgs[1]])], 2)
+
+
+@pytest.mark.gpu
+def test_fp8_weight_engine_matches_oracle_on_dequantised_weights():
+    """weight_dtype="fp8" (BASELINE.json config 5): decode streams e4m3fn codes + per-row scales, prefill reads their
+    dequantised bf16 copy.  Reference: the oracle on the state dict with every decoder Linear replaced by
+    scale * e4m3(codes) — the same model, so the usual logit tolerance and token rule apply; the fp8 engine differs
+    from the bf16 engine (the quantisation is really in the path), and half the decode bytes are gone."""
+    from karanta_ocr_amd.config import CONFIGS
+    from karanta_ocr_amd.weights import fp8_dequantized_weights, random_weights
+    cfg = CONFIGS["tiny-w512"]
+    w = random_weights(cfg, 808)
+    pv, grid = IP.image_to_patches(IP.synthetic_page(70, 84, 112))
+    T = grid[1] * grid[2] // 4
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([rng.integers(0, 400, 5), [cfg.vision_start_token_id], [cfg.image_token_id] * T,
+                          [cfg.vision_end_token_id], rng.integers(0, 400, 4)]).astype(np.int64)
+    page = PageRequest(ids, pv, [grid])
+    n_new = 12
+    eng8 = Engine(cfg, max_batch=2, s_max=512, max_patches=1024, max_prompt_tokens=1024, decode_splits=2, weight_dtype="fp8")
+    eng8.load_weights(w)
+    assert eng8.fp8 and eng8.wide_mode and eng8.narrow_mode
+    res = eng8.generate([page], n_new, ignore_eos=True, return_logits=True)
+    wq = fp8_dequantized_weights(w, cfg)
+    o_tok, o_log = O.generate_greedy(cfg, wq, ids[None], pv, [grid], n_new, policy="bf16", ignore_eos=True, return_logits=True)
+    tol = 0.02 * np.abs(o_log[0, 0]).max()
+    assert np.abs(res.logits[0, 0] - o_log[0, 0]).max() < tol, "prefill logits vs the oracle on dequantised weights"
+    n1 = compare_tokens(res.tokens[0], o_tok[0], o_log[0], tol)
+    for i in range(1, n1):
+        assert np.abs(res.logits[0, i] - o_log[0, i]).max() < 1.5 * tol, f"decode step {i}"
+    # graph replay and a batch of two agree with the eager single run
+    g = eng8.generate([page, page], n_new, ignore_eos=True)
+    np.testing.assert_array_equal(g.tokens[0], res.tokens[0]); np.testing.assert_array_equal(g.tokens[1], res.tokens[0])
+    # the quantisation is really there: the bf16 engine on the original weights gives other logits
+    eng16 = Engine(cfg, max_batch=2, s_max=512, max_patches=1024, max_prompt_tokens=1024, decode_splits=2)
+    eng16.load_weights(w)
+    r16 = eng16.generate([page], 2, ignore_eos=True, return_logits=True)
+    assert np.abs(r16.logits[0, 0] - res.logits[0, 0]).max() > 1e-3
+    assert cfg.decoder_weight_bytes("fp8") < 0.75 * cfg.decoder_weight_bytes()
+    eng8.close(); eng16.close()
