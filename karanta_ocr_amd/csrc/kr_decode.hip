@@ -475,19 +475,24 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
 // chain of launches over rotating copies): launch 1.7 us + body 1.1 + stores 0.6 + x staging 1.8 + weight
 // stream 7.5 (= 7.4 TB/s) were purely additive with the weights-first order.
 // Wave (block b, wave w) walks tiles b + gridDim.x * (w + W * i).
-template <int NCH> struct WideCfg { static constexpr int U = 8, RL = 8; };   // generic: K <= 4096, K % 512 == 0
-template <> struct WideCfg<24> { static constexpr int U = 12, RL = 3; };     // K = 1536 (Qwen2-VL-2B)
-template <> struct WideCfg<32> { static constexpr int U = 16, RL = 4; };     // K = 2048 (Qwen2.5-VL-3B)
-template <> struct WideCfg<56> { static constexpr int U = 8, RL = 7; };      // K = 3584 (Qwen2-VL-7B): 2 x rows + norm = 84 VGPRs
+// MT = 16-row column tiles of the batch: 1 for M <= 16, 2 for M <= 32 (x of 32 rows must fit the LDS: K <= 2048).
+// With MT = 2 every weight fragment feeds two MFMAs and the prologue holds 4 x rows per wave, so the ring is shorter.
+template <int NCH, int MT> struct WideCfg { static constexpr int U = 8, RL = 8; };   // generic: K <= 4096, K % 512 == 0
+template <> struct WideCfg<24, 1> { static constexpr int U = 12, RL = 3; };     // K = 1536 (Qwen2-VL-2B)
+template <> struct WideCfg<32, 1> { static constexpr int U = 16, RL = 4; };     // K = 2048 (Qwen2.5-VL-3B)
+template <> struct WideCfg<56, 1> { static constexpr int U = 8, RL = 7; };      // K = 3584 (Qwen2-VL-7B): 2 x rows + norm = 84 VGPRs
+template <> struct WideCfg<24, 2> { static constexpr int U = 12, RL = 3; };
+template <> struct WideCfg<32, 2> { static constexpr int U = 8, RL = 4; };
 
 // ACTIVE = this wave owns at least one tile.  The two cases are separate instantiations selected by ONE
 // wave-uniform branch at the top of the kernel (each contains the workgroup's single barrier): a branch around
 // the weight loads inside a common body would make the compiler's s_waitcnt bookkeeping assume the shorter
 // path, and the wait for x would become a wait for the weights.
-template <int EPI, int NCH, bool ACTIVE, bool W8>
+template <int EPI, int NCH, bool ACTIVE, bool W8, int MT>
 __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     using WC = WChunk<W8>;
-    constexpr int U = WideCfg<NCH>::U, RL = WideCfg<NCH>::RL;
+    constexpr int U = WideCfg<NCH, MT>::U, RL = WideCfg<NCH, MT>::RL;
+    constexpr int NR = 2 * MT;  // x rows a wave stages in the branch-free prologue (8 waves x NR rows = 16 MT)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = a.wide_waves, nblk = a.wide_blocks;
     const int fr = lane & 15, fg = lane >> 4;
@@ -499,10 +504,10 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     // ---- issue: x rows `wave` and `wave + W` and the norm weight first (branch-free when K is a template
     // constant: s_waitcnt bookkeeping does not survive divergent control flow) ...
     constexpr bool FULL = NCH != 0;  // RL * 64 == K / 8 exactly
-    bf16x8 xv[2][RL], nwv[RL];
+    bf16x8 xv[NR][RL], nwv[RL];
     const bool has_norm = a.norm_w != nullptr;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int b = wave + r * W;
         const kr_bf16* xp = a.x + (int64_t)(b < M ? b : 0) * a.ldx;
 #pragma unroll
@@ -530,7 +535,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     __builtin_amdgcn_sched_barrier(0);  // everything above is issued before any of the norm arithmetic below
     // ---- x -> LDS, RMS-normalised when norm_w is given
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int b = wave + r * W;
         float ss = 0.f;
 #pragma unroll
@@ -557,7 +562,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
             }
         }
     }
-    for (int b = wave + 2 * W; b < M; b += W) {  // fewer than M/2 waves: the remaining rows, the slow way
+    for (int b = wave + NR * W; b < M; b += W) {  // fewer waves than that: the remaining rows, the slow way
         bf16x8 v[RL];
         float ss = 0.f;
 #pragma unroll
@@ -586,35 +591,53 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
         }
     }
     __syncthreads();
-    const int b = fr;
     if (!ACTIVE) {
-        if (EPI == DEPI_ARGMAX && fg == 0 && b < M) {  // the sampler reads every wave's partial
-            a.amax_val[(int64_t)b * stride + t] = -INFINITY;
-            a.amax_idx[(int64_t)b * stride + t] = 0x7fffffff;
+        if (EPI == DEPI_ARGMAX && fg == 0) {  // the sampler reads every wave's partial
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int b = fr + 16 * mt;
+                if (b < M) {
+                    a.amax_val[(int64_t)b * stride + t] = -INFINITY;
+                    a.amax_idx[(int64_t)b * stride + t] = 0x7fffffff;
+                }
+            }
         }
         return;
     }
-    const char* xl = smem + (fr < M ? fr : 0) * xrow;
+    const char* xl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xl[mt] = smem + min(fr + 16 * mt, M - 1) * xrow;
     const int pidx = t;  // this wave's partial-argmax slot: blockIdx.x + blocks * wave
-    float rbv = -INFINITY;
-    int rbi = 0x7fffffff;
+    float rbv[MT];
+    int rbi[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        rbv[mt] = -INFINITY;
+        rbi[mt] = 0x7fffffff;
+    }
 
     for (; t < ntiles; t += stride) {
         const int tn = t + stride;
         const bool more = tn < ntiles;
         const char* wpn = wbase + ((int64_t)(more ? tn : t) * nchunks) * WC::BYTES;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int cc = 0; cc < nchunks; cc += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = cc + u;
                 // keep the scheduler from hoisting every chunk's LDS reads to the top (their registers would
                 // not fit next to a whole-tile ring)
-                if ((u & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + WC::x_byte(0, fg));
-                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + WC::x_byte(1, fg));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u].frag(0), x0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u].frag(1), x1, acc, 0, 0, 0);
+                if ((u & (MT == 1 ? 3 : 1)) == 0) __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 w0 = wbuf[u].frag(0), w1 = wbuf[u].frag(1);   // converted once, used by every column tile
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl[mt] + c * 128 + WC::x_byte(0, fg));
+                    const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl[mt] + c * 128 + WC::x_byte(1, fg));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc[mt], 0, 0, 0);
+                }
                 const int cn = c + U;
                 if (cn < nchunks) {
                     wbuf[u].load(wp, cn);
@@ -624,75 +647,83 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
             }
         }
         wp = wpn;
-        // ---- epilogue of this wave's tile: lane = (row b, features 4*fg .. 4*fg+3)
-        apply_w_scale(a.w_scale, t * 16 + fg * 4, acc);
-        if (EPI == DEPI_SILU8) {
-            float u4[4];
+        // ---- epilogue of this wave's tile: lane = (row b, features 4*fg .. 4*fg+3), once per column tile
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u4[j] = __shfl_xor(acc[j], 32, 64);
-            if (b < M && fg < 2) {
-                bf16x4 o;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int b = fr + 16 * mt;
+            apply_w_scale(a.w_scale, t * 16 + fg * 4, acc[mt]);
+            if (EPI == DEPI_SILU8) {
+                float u4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[j]) * u4[j]);
-                *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
-            }
-        } else if (EPI == DEPI_ARGMAX) {  // running argmax over this wave's tiles, written once after the loop
-            const int n = t * 16 + fg * 4;
+                for (int j = 0; j < 4; ++j) u4[j] = __shfl_xor(acc[mt][j], 32, 64);
+                if (b < M && fg < 2) {
+                    bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) better(rbv, rbi, acc[j], n + j);
-            if (a.out_f32 && b < M) *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = acc;
-        } else if (b < M) {  // PLAIN
-            const int n = t * 16 + fg * 4;
-            float v[4];
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[mt][j]) * u4[j]);
+                    *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
+                }
+            } else if (EPI == DEPI_ARGMAX) {  // running argmax over this wave's tiles, written once after the loop
+                const int n = t * 16 + fg * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[j];
-            if (a.bias) {
-                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+                for (int j = 0; j < 4; ++j) better(rbv[mt], rbi[mt], acc[mt][j], n + j);
+                if (a.out_f32 && b < M) *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = acc[mt];
+            } else if (b < M) {  // PLAIN
+                const int n = t * 16 + fg * 4;
+                float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
-            }
-            if (a.residual) {
-                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+                for (int j = 0; j < 4; ++j) v[j] = acc[mt][j];
+                if (a.bias) {
+                    const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
-            }
-            if (a.out_f32) {
-                *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
-            } else {
-                bf16x4 o;
+                    for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
+                }
+                if (a.residual) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-                *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
+                    for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
+                }
+                if (a.out_f32) {
+                    *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+                    *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
+                }
             }
         }
     }
     if (EPI == DEPI_ARGMAX) {
 #pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
-            const float ov = __shfl_xor(rbv, o, 64);
-            const int oi = __shfl_xor(rbi, o, 64);
-            better(rbv, rbi, ov, oi);
-        }
-        if (fg == 0 && b < M) {
-            a.amax_val[(int64_t)b * stride + pidx] = rbv;
-            a.amax_idx[(int64_t)b * stride + pidx] = rbi;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int b = fr + 16 * mt;
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                const float ov = __shfl_xor(rbv[mt], o, 64);
+                const int oi = __shfl_xor(rbi[mt], o, 64);
+                better(rbv[mt], rbi[mt], ov, oi);
+            }
+            if (fg == 0 && b < M) {
+                a.amax_val[(int64_t)b * stride + pidx] = rbv[mt];
+                a.amax_idx[(int64_t)b * stride + pidx] = rbi[mt];
+            }
         }
     }
 }
 
-template <int EPI, int NCH, bool W8>
+template <int EPI, int NCH, bool W8, int MT>
 __global__ void __launch_bounds__(512) dec_wide_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x + a.wide_blocks * wave < (a.N >> 4)) dec_wide_body<EPI, NCH, true, W8>(a, smem);
-    else dec_wide_body<EPI, NCH, false, W8>(a, smem);
+    if ((int)blockIdx.x + a.wide_blocks * wave < (a.N >> 4)) dec_wide_body<EPI, NCH, true, W8, MT>(a, smem);
+    else dec_wide_body<EPI, NCH, false, W8, MT>(a, smem);
 }
 
-template <int EPI, int NCH, bool W8>
-int launch_wide_w(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+template <int EPI, int NCH, bool W8, int MT>
+int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     const size_t lds = (size_t)a.M * (a.K * 2 + 16);
-    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_wide: x needs %zu bytes of LDS", lds);
-    auto fn = &dec_wide_kernel<EPI, NCH, W8>;
+    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_wide: x (%d rows, K=%d) needs %zu bytes of LDS", a.M, a.K, lds);
+    auto fn = &dec_wide_kernel<EPI, NCH, W8, MT>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -701,6 +732,19 @@ int launch_wide_w(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+template <int EPI, int NCH, bool W8>
+int launch_wide_w(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+    if (a.M > 16) {  // two column tiles: only instantiated where 32 rows of x fit the LDS
+        if constexpr (NCH == 56) {
+            kr_set_error("kr_linear_decode_wide: M=%d > 16 needs K <= 2048 (K=%d)", a.M, a.K);
+            return KR_ERR_ARG;
+        } else {
+            return launch_wide_m<EPI, NCH, W8, 2>(a, blocks, waves, s);
+        }
+    }
+    return launch_wide_m<EPI, NCH, W8, 1>(a, blocks, waves, s);
 }
 
 template <int EPI, int NCH>
@@ -736,7 +780,7 @@ constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 
 // U = ring depth in 64-wide K chunks: the host picks the smallest instantiated U that covers a wave's share of K
 // (then every chunk is requested up front and at most one request per wave is redundant), else the deepest ring.
-template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8>
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8, int MT>
 __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WC = WChunk<W8>;
@@ -753,7 +797,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     const int nblk = cb1 - cb0;
     const int c0 = cb0 + (wave * nblk) / WAVES, c1 = cb0 + ((wave + 1) * nblk) / WAVES;  // even shares, contiguous
     const int xrow = nblk * 128 + 16;
-    float* red = reinterpret_cast<float*>(smem + (NORM ? ((M * xrow + 127) & ~127) : 0));  // [WAVES][NT][64][4]
+    // [WAVES][NT][64][4]; with two batch column tiles (MT = 2) it is used twice, one tile after the other
+    float* red = reinterpret_cast<float*>(smem + (NORM ? ((M * xrow + 127) & ~127) : 0));
 
     int tile[NT];
     if (EPI == DEPI_ROPE_KV) {
@@ -767,18 +812,26 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         wp[t] = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(tile[t], ntiles - 1) * nchunks) * WC::BYTES + lane * 16;
-    const int rb = fr < M ? fr : 0;  // batch row of this lane's accumulator column
+    int rb[MT];  // batch rows of this lane's accumulator columns (one per column tile)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rb[mt] = min(fr + 16 * mt, M - 1);
 
     // ---- 1. the oldest loads of every wave: what the prologue and the epilogue wait for
-    int pos = 0, plen = 0;
-    if (EPI == DEPI_ROPE_KV) {
-        pos = a.ctx_len[rb];
-        plen = a.prompt_len[rb];
+    int pos[MT], plen[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pos[mt] = plen[mt] = 0;
+        if (EPI == DEPI_ROPE_KV) {
+            pos[mt] = a.ctx_len[rb[mt]];
+            plen[mt] = a.prompt_len[rb[mt]];
+        }
     }
     bf16x8 xv[NORM ? RL : 1], nwv[NORM ? RL : 1];
     f32x4 pv[PKS ? PKS : 1][NORM ? RL : 1][2];
-    bf16x8 xf[NORM ? 1 : U][2];
-    const char* xg = reinterpret_cast<const char*>(a.x + (int64_t)rb * a.ldx);   // x fragments: + c*128 + WC::x_byte(h, fg)
+    bf16x8 xf[NORM ? 1 : U][MT][2];
+    const char* xg[MT];   // x fragments: + c*128 + WC::x_byte(h, fg)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xg[mt] = reinterpret_cast<const char*>(a.x + (int64_t)rb[mt] * a.ldx);
     if (NORM) {
         const int b = wave < M ? wave : 0;
 #pragma unroll
@@ -799,8 +852,11 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = min(max(min(c0 + u, c1 - 1), cb0), nchunks - 1);
-            xf[u][0] = *reinterpret_cast<const bf16x8*>(xg + c * 128 + WC::x_byte(0, fg));
-            xf[u][1] = *reinterpret_cast<const bf16x8*>(xg + c * 128 + WC::x_byte(1, fg));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[u][mt][0] = *reinterpret_cast<const bf16x8*>(xg[mt] + c * 128 + WC::x_byte(0, fg));
+                xf[u][mt][1] = *reinterpret_cast<const bf16x8*>(xg[mt] + c * 128 + WC::x_byte(1, fg));
+            }
         }
     }
     // ---- 2. the weight ring (clamped, not branched: short waves re-request their last chunk)
@@ -886,49 +942,70 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
         __syncthreads();
     }
     // ---- 4. epilogue operands of the rotary modes: in flight during the K loop
-    float csv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float csv[MT][8];
     bf16x4 bias0 = {}, bias1 = {};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csv[mt][j] = 0.f;
     if (EPI == DEPI_ROPE_KV) {
         const int i0 = (tile[0] & 7) * 16 + fg * 4;
-        const float* cs = a.cs_table + ((int64_t)rb * a.cs_stride + (pos - plen)) * 128;
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + i0), sv = *reinterpret_cast<const f32x4*>(cs + 64 + i0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            csv[j] = cv[j];
-            csv[4 + j] = sv[j];
+        for (int mt = 0; mt < MT; ++mt) {
+            const float* cs = a.cs_table + ((int64_t)rb[mt] * a.cs_stride + (pos[mt] - plen[mt])) * 128;
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + i0), sv = *reinterpret_cast<const f32x4*>(cs + 64 + i0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                csv[mt][j] = cv[j];
+                csv[mt][4 + j] = sv[j];
+            }
         }
         bias0 = *reinterpret_cast<const bf16x4*>(a.bias + tile[0] * 16 + fg * 4);
         bias1 = *reinterpret_cast<const bf16x4*>(a.bias + tile[NT - 1] * 16 + fg * 4);
     }
 
     // ---- 5. K loop of this wave
-    const char* xl = smem + rb * xrow;
-    f32x4 acc[NT];
+    const char* xl[MT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) xl[mt] = smem + rb[mt] * xrow;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int cc = c0; cc < c1; cc += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = cc + u;
             if (c < c1) {
-                bf16x8 x0, x1;
-                if (NORM) {
-                    x0 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + WC::x_byte(0, fg));
-                    x1 = *reinterpret_cast<const bf16x8*>(xl + (c - cb0) * 128 + WC::x_byte(1, fg));
-                } else {
-                    x0 = xf[u][0];
-                    x1 = xf[u][1];
+                bf16x8 x0[MT], x1[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (NORM) {
+                        x0[mt] = *reinterpret_cast<const bf16x8*>(xl[mt] + (c - cb0) * 128 + WC::x_byte(0, fg));
+                        x1[mt] = *reinterpret_cast<const bf16x8*>(xl[mt] + (c - cb0) * 128 + WC::x_byte(1, fg));
+                    } else {
+                        x0[mt] = xf[u][mt][0];
+                        x1[mt] = xf[u][mt][1];
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t].frag(0), x0, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[u][t].frag(1), x1, acc[t], 0, 0, 0);
+                    const bf16x8 w0 = wbuf[u][t].frag(0), w1 = wbuf[u][t].frag(1);   // converted once per column tile pair
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0[mt], acc[mt][t], 0, 0, 0);
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[mt], acc[mt][t], 0, 0, 0);
+                    }
                 }
                 const int cn = c + U;
                 if (cn < c1) {
                     if (!NORM) {
-                        xf[u][0] = *reinterpret_cast<const bf16x8*>(xg + cn * 128 + WC::x_byte(0, fg));
-                        xf[u][1] = *reinterpret_cast<const bf16x8*>(xg + cn * 128 + WC::x_byte(1, fg));
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            xf[u][mt][0] = *reinterpret_cast<const bf16x8*>(xg[mt] + cn * 128 + WC::x_byte(0, fg));
+                            xf[u][mt][1] = *reinterpret_cast<const bf16x8*>(xg[mt] + cn * 128 + WC::x_byte(1, fg));
+                        }
                     }
 #pragma unroll
                     for (int t = 0; t < NT; ++t) wbuf[u][t].load(wp[t], cn);
@@ -936,97 +1013,105 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
             }
         }
     }
-    // ---- 6. cross-wave sum, epilogue by wave 0
+    // ---- 6. cross-wave sum, epilogue by wave 0 (one batch column tile after the other through the same buffer)
+    auto epilogue = [&](const int mt, f32x4 (&sum)[NT]) {
+        const int b = fr + 16 * mt;
+        if (b >= M) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
-    __syncthreads();
-    if (wave != 0) return;
-    f32x4 sum[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
-        }
-    }
-    const int b = fr;
-    if (b >= M) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) apply_w_scale(a.w_scale, min(tile[t], ntiles - 1) * 16 + fg * 4, sum[t]);
-    if (EPI == DEPI_ROPE_KV) {
-        const int hh = tile[0] >> 3;                   // global head index in [q heads | k heads | v heads]
-        const int i0 = (tile[0] & 7) * 16 + fg * 4;    // channel in [0, 64)
-        float lo[4], hi[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lo[j] = bfround(sum[0][j] + bf2f(bias0[j]));       // the projection output is a bf16 tensor
-            hi[j] = bfround(sum[NT - 1][j] + bf2f(bias1[j]));
-        }
-        if (hh < a.heads + a.kv_heads) {
-            bf16x4 o0, o1;
+        for (int t = 0; t < NT; ++t) apply_w_scale(a.w_scale, min(tile[t], ntiles - 1) * 16 + fg * 4, sum[t]);
+        if (EPI == DEPI_ROPE_KV) {
+            const int hh = tile[0] >> 3;                   // global head index in [q heads | k heads | v heads]
+            const int i0 = (tile[0] & 7) * 16 + fg * 4;    // channel in [0, 64)
+            float lo[4], hi[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o0[j] = f2bf(lo[j] * csv[j] - hi[j] * csv[4 + j]);
-                o1[j] = f2bf(hi[j] * csv[j] + lo[j] * csv[4 + j]);
+                lo[j] = bfround(sum[0][j] + bf2f(bias0[j]));       // the projection output is a bf16 tensor
+                hi[j] = bfround(sum[NT - 1][j] + bf2f(bias1[j]));
             }
-            kr_bf16* dst = hh < a.heads
-                               ? a.q_out + ((int64_t)b * a.heads + hh) * 128
-                               : a.kcache + (((int64_t)b * a.kv_heads + (hh - a.heads)) * a.s_max + pos) * 128;
-            *reinterpret_cast<bf16x4*>(dst + i0) = o0;
-            *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
-        } else {
-            const int kvh = hh - a.heads - a.kv_heads;
-            kr_bf16* vt = a.vtcache + ((((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * 128) * 64 + (pos & 63);
+            if (hh < a.heads + a.kv_heads) {
+                bf16x4 o0, o1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
-                vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+                for (int j = 0; j < 4; ++j) {
+                    o0[j] = f2bf(lo[j] * csv[mt][j] - hi[j] * csv[mt][4 + j]);
+                    o1[j] = f2bf(hi[j] * csv[mt][j] + lo[j] * csv[mt][4 + j]);
+                }
+                kr_bf16* dst = hh < a.heads
+                                   ? a.q_out + ((int64_t)b * a.heads + hh) * 128
+                                   : a.kcache + (((int64_t)b * a.kv_heads + (hh - a.heads)) * a.s_max + pos[mt]) * 128;
+                *reinterpret_cast<bf16x4*>(dst + i0) = o0;
+                *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
+            } else {
+                const int kvh = hh - a.heads - a.kv_heads;
+                kr_bf16* vt = a.vtcache + ((((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos[mt] >> 6)) * 128) * 64 + (pos[mt] & 63);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
+                    vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (tile[t] >= ntiles) continue;
+            const int n = tile[t] * 16 + fg * 4;
+            if (EPI == DEPI_PARTIAL) {
+                *reinterpret_cast<f32x4*>(a.out_f32 + ((int64_t)ks * M + b) * a.ldc + n) = sum[t];
+                continue;
+            }
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = sum[t][j];
+            if (a.bias) {
+                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
+            }
+            if (a.residual) {
+                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
+            }
+            if (a.out_f32) {
+                *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+                *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
             }
         }
-        return;
-    }
+    };
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (tile[t] >= ntiles) continue;
-        const int n = tile[t] * 16 + fg * 4;
-        if (EPI == DEPI_PARTIAL) {
-            *reinterpret_cast<f32x4*>(a.out_f32 + ((int64_t)ks * M + b) * a.ldc + n) = sum[t];
-            continue;
-        }
-        float v[4];
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt > 0) __syncthreads();   // wave 0 has read the previous column tile's partial sums
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sum[t][j];
-        if (a.bias) {
-            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[mt][t];
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 sum[NT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
-        }
-        if (a.residual) {
-            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+            for (int t = 0; t < NT; ++t) {
+                sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
-        }
-        if (a.out_f32) {
-            *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-            bf16x4 o;
+                for (int w = 0; w < WAVES; ++w) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-            *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + n) = o;
+                    for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
+                }
+            }
+            epilogue(mt, sum);
         }
     }
 }
 
-template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8>
-int launch_narrow_w(DecLinArgs& a, int groups, kr_stream s) {
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8, int MT>
+int launch_narrow_m(DecLinArgs& a, int groups, kr_stream s) {
     const int nchunks = a.K >> 6, cpb = (nchunks + a.ksplit - 1) / a.ksplit;
     const size_t xbytes = NORM ? (((size_t)a.M * (cpb * 128 + 16) + 127) & ~(size_t)127) : 0;
     const size_t lds = xbytes + (size_t)WAVES * NT * 256 * 4;
-    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_narrow: needs %zu bytes of LDS", lds);
-    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM, U, W8>;
+    KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_narrow: M=%d K=%d needs %zu bytes of LDS", a.M, a.K, lds);
+    auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM, U, W8, MT>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1035,6 +1120,21 @@ int launch_narrow_w(DecLinArgs& a, int groups, kr_stream s) {
     fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+// M > 16: two batch column tiles.  Only on 8-wave workgroups (the x fragments of the direct path double) and not
+// with the K = 3584 row registers; the engine sizes its batches accordingly.
+template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8>
+int launch_narrow_w(DecLinArgs& a, int groups, kr_stream s) {
+    if (a.M > 16) {
+        if constexpr (WAVES == 8 && NCH != 56) {
+            return launch_narrow_m<NT, EPI, WAVES, NCH, PKS, NORM, U, W8, 2>(a, groups, s);
+        } else {
+            kr_set_error("kr_linear_decode_narrow: M=%d > 16 needs 8-wave workgroups and K != 3584", a.M);
+            return KR_ERR_ARG;
+        }
+    }
+    return launch_narrow_m<NT, EPI, WAVES, NCH, PKS, NORM, U, W8, 1>(a, groups, s);
 }
 
 template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U>
@@ -1526,7 +1626,7 @@ static int wide_impl(int mode, const kr_bf16* x, int64_t ldx, const void* w_pack
                      kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
                      float* amax_val, int32_t* amax_idx, kr_stream s) {
     KR_CHECK_ARG(x && w_packed, "kr_linear_decode_wide: null pointer");
-    KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode_wide: M=%d must be in 1..16", M);
+    KR_CHECK_ARG(M >= 1 && M <= 32, "kr_linear_decode_wide: M=%d must be in 1..32", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 512 == 0 && K <= 4096,
                  "kr_linear_decode_wide: N=%d K=%d (N%%16, K%%512, K<=4096)", N, K);
     KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_wide: ldx");
@@ -1579,7 +1679,7 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
                                        kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
                                        kr_stream s) {
     KR_CHECK_ARG(x && w_packed, "kr_linear_decode_narrow: null pointer");
-    KR_CHECK_ARG(M >= 1 && M <= 16, "kr_linear_decode_narrow: M=%d must be in 1..16", M);
+    KR_CHECK_ARG(M >= 1 && M <= 32, "kr_linear_decode_narrow: M=%d must be in 1..32", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 64 == 0, "kr_linear_decode_narrow: N=%d K=%d (N%%16, K%%64)", N, K);
     KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_narrow: ldx");
     KR_CHECK_ARG(waves == 8 || waves == 16, "kr_linear_decode_narrow: waves=%d (8 or 16)", waves);

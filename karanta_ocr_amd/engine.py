@@ -262,8 +262,8 @@ class Engine:
         self.stream = torch.cuda.Stream(device=self.device)
         self.s = self.stream.cuda_stream
         self.B = max_batch
-        if max_batch > 16:
-            raise KarantaHipError("max_batch > 16 needs the batched-GEMM decode path (not built yet)")
+        if max_batch > 32:
+            raise KarantaHipError("max_batch > 32: the decode kernels take at most two 16-row column tiles")
         self.s_max = _align(s_max, 64)
         self.max_patches = max_patches
         self.max_tokens = max_prompt_tokens
@@ -356,6 +356,10 @@ class Engine:
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
         self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
+        if self.B > 16 and not (self.wide_mode and self.narrow_mode and self.narrow_o and t.hidden_size <= 2048
+                                and t.intermediate_size % 64 == 0):
+            raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels with 32 rows of x in LDS: "
+                                  "hidden_size % 512 == 0 and <= 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B)")
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
         wb, ww = self._wide_geometry(t.vocab_size)
@@ -420,6 +424,10 @@ class Engine:
             self.L.kr_linear_decode_narrow_fp8(*head, ptr(w8), ptr(w_scale), *tail)
         else:
             self.L.kr_linear_decode_narrow(*head, ptr(W), *tail)
+
+    @staticmethod
+    def _down_waves(B: int) -> int:
+        return 16 if B <= 16 else 8   # two batch column tiles double the x fragments: 8-wave workgroups only
 
     def _w8kw(self, name: str) -> dict:
         w8, sc = self._w8(name)
@@ -878,11 +886,12 @@ class Engine:
                 L.kr_event_record(e2, s)
             if self.defer_down and i + 1 < nl:
                 # 2 workgroups per tile; the slabs are added to x by the next layer's qkv prologue
-                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=16, ksplit=2,
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=self._down_waves(B), ksplit=2,
                                  **self._w8kw(p + "down.w"))
                 pending = True
             elif self.narrow_mode:
-                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=16, **self._w8kw(p + "down.w"))
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self._down_waves(B),
+                                 **self._w8kw(p + "down.w"))
             else:
                 self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self.wv_down)
             for _ in range(self._extra_nulls):  # diagnostic: price of one more (empty) launch in the chain

@@ -314,3 +314,41 @@ def test_fp8_weight_engine_matches_oracle_on_dequantised_weights():
     assert np.abs(r16.logits[0, 0] - res.logits[0, 0]).max() > 1e-3
     assert cfg.decoder_weight_bytes("fp8") < 0.75 * cfg.decoder_weight_bytes()
     eng8.close(); eng16.close()
+
+
+@pytest.mark.gpu
+def test_batches_above_16_rows_equal_solo_generation():
+    """max_batch up to 32 (two 16-row column tiles in the decode linears; hidden_size <= 2048): 21 ragged pages decoded
+    together give each page the tokens it gets alone; the slot scheduler runs 20 slots; wider models are refused."""
+    from karanta_ocr_amd._lib import KarantaHipError
+    from karanta_ocr_amd.config import CONFIGS
+    from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
+    from karanta_ocr_amd.weights import random_weights
+    cfg = CONFIGS["tiny-w512"]
+    w = random_weights(cfg, 909)
+    eng = Engine(cfg, max_batch=21, s_max=512, max_patches=4096, max_prompt_tokens=4096, decode_splits=2)
+    eng.load_weights(w)
+    rng = np.random.default_rng(77)
+    pages = []
+    for i in range(21):
+        h, wd = [(56, 84), (84, 56), (56, 56), (112, 84)][i % 4]
+        pv, grid = IP.image_to_patches(IP.synthetic_page(100 + i, h, wd))
+        T = grid[1] * grid[2] // 4
+        ids = np.concatenate([rng.integers(0, 400, 1 + i % 5), [cfg.vision_start_token_id], [cfg.image_token_id] * T,
+                              [cfg.vision_end_token_id], rng.integers(0, 400, 2)]).astype(np.int64)
+        pages.append(PageRequest(ids, pv, [grid]))
+    together = eng.generate(pages, 10, ignore_eos=True)
+    for i in (0, 7, 15, 16, 17, 20):
+        alone = eng.generate([pages[i]], 10, ignore_eos=True)
+        np.testing.assert_array_equal(alone.tokens[0], together.tokens[i])
+    sch = SlotScheduler(eng, max_tokens_cap=10, chunk=3)
+    res = sch.run([SlotRequest(p, 4 + i % 7, tag=i) for i, p in enumerate(pages)])
+    for i in (0, 3, 8, 16, 19, 20):        # EOS-aware solo runs (the tiny vocabulary hits an EOS id now and then)
+        solo = eng.generate([pages[i]], 4 + i % 7)
+        np.testing.assert_array_equal(res[i].tokens, solo.tokens[0])
+        assert res[i].finish_reason == solo.finish_reasons[0]
+    eng.close()
+    with pytest.raises(KarantaHipError, match="max_batch > 16"):
+        Engine(CONFIGS["tiny"], max_batch=17, s_max=256, max_patches=256, max_prompt_tokens=256)   # hidden 256: no wide kernel
+    with pytest.raises(KarantaHipError, match="max_batch > 32"):
+        Engine(cfg, max_batch=33, s_max=256, max_patches=256, max_prompt_tokens=256)

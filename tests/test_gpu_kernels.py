@@ -851,6 +851,41 @@ def test_linear_wide_silu8_norm_bias_residual(L, M, K, blocks, waves):
                       what="wide plain")
 
 
+@pytest.mark.parametrize("M", [17, 24, 32])
+@pytest.mark.parametrize("N,K,blocks,waves", [(16 * 37, 512, 3, 5), (16 * 37, 1536, 256, 4), (16 * 45, 2048, 4, 3), (16 * 300, 1024, 7, 8)])
+def test_linear_wide_two_column_tiles(L, M, N, K, blocks, waves):
+    """M > 16: two 16-row column tiles of the batch per weight fragment (exact on integers), and the fused norm +
+    SiLU*mul and per-wave argmax epilogues on both tiles."""
+    rng = np.random.default_rng(M + N + K + blocks)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    W[:, K // 2 + 40:] = 0
+    W[::3, 100:300] = 1
+    np.testing.assert_array_equal(run_wide(L, DEC_PLAIN, x, W, blocks, waves), ref_linear(x, W))
+    ff = N // 2 - (N // 2) % 8
+    x2, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x2, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(run_wide(L, DEC_SILU8, x2, Wp, blocks, waves, norm_w=nw), ref_linear(xn, Wp, epi=EPI_SILU_MUL8),
+                      what="wide silu8, 2 column tiles")
+    # argmax partials of every row
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    n_part = blocks * waves
+    av = torch.zeros(M, n_part, device=DEV); ai = torch.zeros(M, n_part, dtype=torch.int32, device=DEV)
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), K, ptr(Wd), 0, 0, 1e-6, 0, 0, 0, 0, 0, M, N, K, blocks, waves, ptr(av), ptr(ai), 0)
+    torch.cuda.synchronize()
+    ref = ref_linear(x, W)
+    a_, i_ = av.cpu().numpy(), ai.cpu().numpy()
+    for b in range(M):
+        assert i_[b, int(np.lexsort((i_[b], -a_[b]))[0])] == int(ref[b].argmax()) and a_[b].max() == ref[b].max()
+
+
+def test_linear_wide_rejects_33_rows_and_k3584_above_16(L):
+    x = torch.zeros(33, 3584, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(KarantaHipError):
+        L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 512, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 33, 16, 512, 1, 4, 0, 0, 0)
+    with pytest.raises(KarantaHipError):     # 17 rows of K = 3584 do not go with the row registers / LDS
+        L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 3584, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 17, 16, 3584, 1, 4, 0, 0, 0)
+
+
 def test_linear_wide_argmax_and_sample(L):
     rng = np.random.default_rng(81)
     B, V, d = 3, 16 * 83, 512
@@ -909,10 +944,16 @@ def narrow_call(L, mode, x, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_w=
                               kv_heads, s_max, 0)
 
 
-@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("M", [1, 8, 16, 23, 32])
 @pytest.mark.parametrize("N,K,waves", [(16, 64, 8), (48, 256, 8), (1536, 1536, 8), (96, 8960, 16), (96, 8960, 8),
                                        (16 * 5, 64 * 19, 16), (32, 3584, 8)])
 def test_linear_narrow_plain_exact_on_integers(L, M, N, K, waves):
+    if M > 16 and waves == 16:
+        with pytest.raises(KarantaHipError):       # two column tiles: 8-wave workgroups only
+            narrow_call(L, DEC_PLAIN, ptr(torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)),
+                        ptr(torch.zeros(N, K, dtype=torch.bfloat16, device=DEV)), M, N, K,
+                        out=ptr(torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)), ldc=N, waves=waves)
+        return
     """K split over the waves of one workgroup (uneven chunk counts, waves without any chunk), x fragments straight
     from global memory; the zeroed K tail makes a wrong chunk order visible."""
     rng = np.random.default_rng(M + N + K + waves)
@@ -930,7 +971,7 @@ def test_linear_narrow_plain_exact_on_integers(L, M, N, K, waves):
 
 
 @pytest.mark.parametrize("M,N,K,ksplit,waves", [(8, 1536, 8960, 2, 16), (16, 96, 8960, 3, 8), (3, 48, 256, 2, 8),
-                                                (8, 64, 64 * 9, 8, 8)])
+                                                (8, 64, 64 * 9, 8, 8), (32, 1536, 8960, 2, 8), (19, 96, 8960, 3, 8)])
 def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
     """ksplit > 1 writes f32 slabs [ksplit][M][N]; their sum is the product (exact on integers)."""
     rng = np.random.default_rng(M + N + ksplit)
@@ -949,7 +990,7 @@ def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
 
 
 @pytest.mark.parametrize("M,K,parts", [(8, 1536, True), (8, 1536, False), (16, 3584, True), (3, 256, False), (11, 1536, True),
-                                       (8, 2048, True), (5, 2048, False)])
+                                       (8, 2048, True), (5, 2048, False), (32, 1536, True), (27, 2048, True), (20, 512, False)])
 def test_linear_narrow_norm_with_deferred_partials(L, M, K, parts):
     """x_new = bf16(x + slab0 + slab1) -> x_out (written once, by workgroup 0), RMSNorm(x_new) @ W^T + bias."""
     rng = np.random.default_rng(300 + M + K)
@@ -983,13 +1024,17 @@ def test_linear_narrow_partials_reject_unsupported_k(L):
 
 @pytest.mark.parametrize("H,KVH,K,parts", [(2, 1, 1024, False), (12, 2, 1536, True), (3, 1, 1536, False), (28, 4, 3584, True),
                                            (16, 2, 2048, True)])
-def test_linear_narrow_rope_kv(L, H, KVH, K, parts):
-    """Fused (partial sums +) RMSNorm + qkv projection + bias + M-RoPE + q / K-cache / V^T-cache writes."""
+@pytest.mark.parametrize("B", [5, 21])
+def test_linear_narrow_rope_kv(L, H, KVH, K, parts, B):
+    """Fused (partial sums +) RMSNorm + qkv projection + bias + M-RoPE + q / K-cache / V^T-cache writes; B = 21: two batch
+    column tiles."""
+    if B > 16 and K == 3584:
+        pytest.skip("two column tiles need K <= 2048")
     rng = np.random.default_rng(170 + H)
-    hd, B, s_max, T = 128, 5, 256, 7
+    hd, s_max, T = 128, 256, 7
     N = (H + 2 * KVH) * hd
-    plen = np.asarray([0, 3, 60, 64, 198], np.int32)
-    step = np.asarray([0, 2, 3, 0, 6], np.int32)
+    plen = np.asarray([0, 3, 60, 64, 198] + list(rng.integers(0, 190, size=B - 5)), np.int32)
+    step = np.asarray([0, 2, 3, 0, 6] + list(rng.integers(0, T, size=B - 5)), np.int32)
     ctxs = plen + step
     x, W = rnd(rng, B, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
     bias, nw = rnd(rng, N, scale=0.1), bf16_round(1 + 0.1 * rnd(rng, K))
