@@ -33,7 +33,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--served-model-name", default=None)
     ap.add_argument("--max-model-len", type=int, default=16384)
-    ap.add_argument("--max-num-seqs", type=int, default=8, help="decode slots (<= 16)")
+    ap.add_argument("--max-num-seqs", type=int, default=8, help="decode slots (<= 32; above 16 only for hidden_size <= 2048)")
     ap.add_argument("--tensor-parallel-size", type=int, default=1)
     ap.add_argument("--data-parallel-size", type=int, default=1)
     ap.add_argument("--gpu-memory-utilization", type=float, default=None)
@@ -68,8 +68,8 @@ def parse_args(argv: Optional[List[str]] = None):
     if args.tensor_parallel_size != 1 or args.data_parallel_size != 1:
         ap.error("one process serves one GPU: run one server per GPU (HIP_VISIBLE_DEVICES=i), as "
                  "scripts/start_multiple_vllm_servers.sh does; tensor / data parallel sizes must be 1")
-    if not 1 <= args.max_num_seqs <= 16:
-        ap.error("--max-num-seqs must be in 1..16")
+    if not 1 <= args.max_num_seqs <= 32:
+        ap.error("--max-num-seqs must be in 1..32 (above 16: models up to hidden_size 2048)")
     args.model_dir = model
     args.served_model_name = args.served_model_name or os.path.basename(os.path.normpath(model))
     args.ignored = unknown
