@@ -329,6 +329,46 @@ int kr_gumbel_argmax(const float* logits, int64_t ld_logits, int vocab, const fl
                      const uint32_t* seed, const int32_t* ctx_len, const int32_t* prompt_len, float* amax_val,
                      int32_t* amax_idx, int n_part, int batch, kr_stream s);
 
+/* ------------------------------------------------------------------ guided decoding + log-probabilities
+ * Replaces vLLM's guided-decoding logits processor and its logprobs output for the requests the reference sends:
+ * `guided_regex` (/root/reference/karanta/pipeline.py:304-307), `response_format` json_schema
+ * (/root/reference/karanta/data/utils.py:322-440, bulk_processing/workers/vllm_client.py:196), `logprobs` /
+ * `top_logprobs` (/root/reference/karanta/data/create_batch_data_prompts.py:117-118).  The host compiles the pattern
+ * to a byte DFA (state 0 = dead; karanta_ocr_amd/guided.py); per token everything stays on the device.
+ *
+ * kr_guide_build_masks: masks[s][w] bit j = token 32*w+j allowed in DFA state s <=> the token has bytes and walking
+ * them from s through trans[state][byte] (uint16, [n_states][256]) never reaches state 0; a token listed in eos is
+ * allowed exactly where accept[s] != 0.  vocab_off [vocab+1] / vocab_bytes: the byte string of every token id.
+ * mask_words: words per row, even, mask_words * 32 >= vocab. */
+int kr_guide_build_masks(const uint16_t* trans, const uint8_t* accept, int n_states, const int32_t* vocab_off,
+                         const uint8_t* vocab_bytes, int vocab, const int32_t* eos, int n_eos, uint32_t* masks,
+                         int mask_words, kr_stream s);
+
+/* kr_gumbel_argmax with a token mask per row: guide_masks[b] = device address (as an integer) of the mask table of
+ * row b's pattern (0: row unconstrained), guide_state[b] its current DFA state; tokens whose bit is clear do not
+ * take part.  guide_masks == NULL: identical to kr_gumbel_argmax.  fallback_token: what a row with no allowed token
+ * yields (cannot happen in a live state; keeps the token id valid). */
+int kr_gumbel_argmax_guided(const float* logits, int64_t ld_logits, int vocab, const float* temperature,
+                            const uint32_t* seed, const int32_t* ctx_len, const int32_t* prompt_len, float* amax_val,
+                            int32_t* amax_idx, int n_part, int batch, const uint64_t* guide_masks,
+                            const int32_t* guide_state, int mask_words, int fallback_token, kr_stream s);
+
+/* After the sampler: guide_state[b] <- walk(guide_state[b], bytes(tokens[b])) through the table at device address
+ * guide_trans[b] (0: row unconstrained); rows with finished[b] != 0 keep their state. */
+int kr_guide_advance(const int32_t* tokens, const int32_t* finished, const uint64_t* guide_trans, int32_t* guide_state,
+                     const int32_t* vocab_off, const uint8_t* vocab_bytes, int vocab, int batch, kr_stream s);
+
+/* Log-probabilities of one decode step from the fp32 logits [batch][ld_logits] (log-softmax over the vocabulary,
+ * unscaled and unmasked): out_lp[h][b][0] = log p(tokens[b]), out_lp[h][b][1 + j] / out_idx[h][b][j] = the j-th most
+ * probable token (ties: lowest id), j < k <= 20, rows strided by hist_batch * (1 + k_stride) / hist_batch * k_stride;
+ * h = ctx_len[b] - prompt_len[b] as left by kr_sample_greedy (the token-history index); rows with finished[b] != 0
+ * record nothing.  part_val / part_idx [batch][n_part][k] and part_ms [batch][n_part][2] are scratch;
+ * ceil(vocab / n_part) <= 4096. */
+int kr_logprobs_topk(const float* logits, int64_t ld_logits, int vocab, int k, int n_part, float* part_val,
+                     int32_t* part_idx, float* part_ms, const int32_t* tokens, const int32_t* ctx_len,
+                     const int32_t* prompt_len, const int32_t* finished, float* out_lp, int32_t* out_idx, int hist_len,
+                     int hist_batch, int k_stride, int batch, kr_stream s);
+
 /* Greedy sampling from the ARGMAX partials + per-step bookkeeping: token -> tokens_out[b] and
  * history[(ctx_len[b] + 1 - prompt_len[b]) * hist_stride + b] (= this sequence's generated-token
  * index), EOS / pad handling as kr_argmax_embed, ctx_len[b] += 1, embedding gather into x_next.

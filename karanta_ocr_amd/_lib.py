@@ -64,6 +64,10 @@ SIGNATURES = {
                                     i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
     "kr_fp8_to_bf16": [c_p, c_p, i64, c_p],
     "kr_gumbel_argmax": [c_p, i64, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p],
+    "kr_gumbel_argmax_guided": [c_p, i64, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p, c_p, i32, i32, c_p],
+    "kr_guide_build_masks": [c_p, c_p, i32, c_p, c_p, i32, c_p, i32, c_p, i32, c_p],
+    "kr_guide_advance": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p],
+    "kr_logprobs_topk": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_linear_decode_narrow": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                 i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],

@@ -1425,7 +1425,10 @@ __global__ void __launch_bounds__(256) gumbel_argmax_kernel(const float* __restr
                                                             const unsigned* __restrict__ seed,
                                                             const int32_t* __restrict__ ctx_len,
                                                             const int32_t* __restrict__ prompt_len,
-                                                            float* __restrict__ amax_val, int32_t* __restrict__ amax_idx) {
+                                                            float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
+                                                            const uint64_t* __restrict__ guide_masks,
+                                                            const int32_t* __restrict__ guide_state, int mask_words,
+                                                            int fallback_token) {
     __shared__ float s_v[4];
     __shared__ int s_i[4];
     const int p = blockIdx.x, n_part = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1435,9 +1438,14 @@ __global__ void __launch_bounds__(256) gumbel_argmax_kernel(const float* __restr
     const float inv_t = T > 0.f ? 1.0f / T : 1.0f;
     const unsigned base = kr_mix32(seed[b] ^ ((unsigned)(ctx_len[b] + 1 - prompt_len[b]) * 0x9E3779B1u));
     const float* row = logits + (int64_t)b * ld;
+    // guided slot: allowed-token bits of its DFA state (kr_guide_build_masks); 0 pointer = unconstrained
+    const uint32_t* allow = nullptr;
+    if (guide_masks != nullptr && guide_masks[b] != 0)
+        allow = reinterpret_cast<const uint32_t*>(guide_masks[b]) + (int64_t)guide_state[b] * mask_words;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = i0 + tid; i < i1; i += 256) {
+        if (allow != nullptr && !((allow[i >> 5] >> (i & 31)) & 1u)) continue;
         float v = row[i] * inv_t;
         if (T > 0.f) {
             const unsigned h = kr_mix32(base + (unsigned)i);
@@ -1460,6 +1468,8 @@ __global__ void __launch_bounds__(256) gumbel_argmax_kernel(const float* __restr
     if (tid == 0) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) better(bv, bi, s_v[w], s_i[w]);
+        // a row whose mask allows nothing (cannot happen for a live DFA state) must still yield a valid token id
+        if (p == 0 && bi == 0x7fffffff) bi = fallback_token;
         amax_val[(int64_t)b * n_part + p] = bv;
         amax_idx[(int64_t)b * n_part + p] = bi;
     }
@@ -1781,15 +1791,28 @@ extern "C" int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int ba
     return KR_OK;
 }
 
+extern "C" int kr_gumbel_argmax_guided(const float* logits, int64_t ld_logits, int vocab, const float* temperature,
+                                       const uint32_t* seed, const int32_t* ctx_len, const int32_t* prompt_len,
+                                       float* amax_val, int32_t* amax_idx, int n_part, int batch,
+                                       const uint64_t* guide_masks, const int32_t* guide_state, int mask_words,
+                                       int fallback_token, kr_stream s) {
+    KR_CHECK_ARG(logits && temperature && seed && ctx_len && prompt_len && amax_val && amax_idx, "kr_gumbel_argmax: null pointer");
+    KR_CHECK_ARG(vocab > 0 && ld_logits >= vocab && n_part > 0 && n_part <= 65535 && batch > 0, "kr_gumbel_argmax: bad sizes");
+    KR_CHECK_ARG(guide_masks == nullptr || (guide_state != nullptr && (int64_t)mask_words * 32 >= vocab),
+                 "kr_gumbel_argmax_guided: guide_state missing or mask_words * 32 < vocab");
+    KR_CHECK_ARG(fallback_token >= 0 && fallback_token < vocab, "kr_gumbel_argmax_guided: fallback_token out of vocabulary");
+    gumbel_argmax_kernel<<<dim3(n_part, batch), 256, 0, kr_hs(s)>>>(logits, ld_logits, vocab, temperature, seed, ctx_len, prompt_len,
+                                                                    amax_val, amax_idx, guide_masks, guide_state, mask_words,
+                                                                    fallback_token);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
 extern "C" int kr_gumbel_argmax(const float* logits, int64_t ld_logits, int vocab, const float* temperature,
                                 const uint32_t* seed, const int32_t* ctx_len, const int32_t* prompt_len, float* amax_val,
                                 int32_t* amax_idx, int n_part, int batch, kr_stream s) {
-    KR_CHECK_ARG(logits && temperature && seed && ctx_len && prompt_len && amax_val && amax_idx, "kr_gumbel_argmax: null pointer");
-    KR_CHECK_ARG(vocab > 0 && ld_logits >= vocab && n_part > 0 && n_part <= 65535 && batch > 0, "kr_gumbel_argmax: bad sizes");
-    gumbel_argmax_kernel<<<dim3(n_part, batch), 256, 0, kr_hs(s)>>>(logits, ld_logits, vocab, temperature, seed, ctx_len, prompt_len,
-                                                                    amax_val, amax_idx);
-    KR_CHECK_LAUNCH();
-    return KR_OK;
+    return kr_gumbel_argmax_guided(logits, ld_logits, vocab, temperature, seed, ctx_len, prompt_len, amax_val, amax_idx, n_part,
+                                   batch, nullptr, nullptr, 0, 0, s);
 }
 
 extern "C" int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part, const kr_bf16* embed_table,

@@ -16,7 +16,7 @@ import math
 import os
 import time
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -238,6 +238,8 @@ class PageRequest:
     temperature: float = 0.0                   # 0: greedy; > 0: Gumbel-max sampling (kr_gumbel_argmax)
     seed: int = 0                              # the sampler is counter-based: (seed, token index) fixes every draw
     images: Optional[List[np.ndarray]] = None  # instead of pixel_values: HWC uint8 RGB pages for the GPU front end
+    guide: Any = None                          # guided.Guide / DeviceGuide: the output must match this pattern
+    logprobs: Optional[int] = None             # None: off; k >= 0: log-prob of every token + the k most probable (<= 20)
 
 
 @dataclass
@@ -247,6 +249,17 @@ class GenerateResult:
     prompt_tokens: List[int]
     timings: Dict[str, float]
     logits: Optional[np.ndarray] = None  # [B, steps, V] when return_logits
+    logprobs: Optional[List[Optional[Dict[str, np.ndarray]]]] = None   # per page (None where not asked): "token" [n],
+    #                                                                    "top_ids" [n, k], "top" [n, k]
+
+
+class DeviceGuide:
+    """A compiled pattern resident in HBM: DFA transitions [S, 256] uint16 and one allowed-token bit row per state
+    (kr_guide_build_masks).  Built by :meth:`Engine.compile_guide`."""
+
+    def __init__(self, guide, trans: torch.Tensor, masks: torch.Tensor):
+        self.guide, self.trans, self.masks = guide, trans, masks
+        self.start = int(guide.start)
 
 
 class Engine:
@@ -269,6 +282,8 @@ class Engine:
         self.max_tokens = max_prompt_tokens
         self.n_split = decode_splits
         self._ignore_eos = self._freeze_finished = self._want_logits = self._sampling = False
+        self._guided = False          # the decode graph masks logits by the slots' DFA states and advances them
+        self._logprobs = None         # None or k: the decode graph records log-probabilities (kr_logprobs_topk)
         self._adm_stream = None                          # second stream of the overlapped admission (slot mode)
         self._resample_cache: Dict[tuple, tuple] = {}   # (h, w, rh, rw) -> device tables of the GPU image front end
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
@@ -374,6 +389,20 @@ class Engine:
         self.d_fin = z(B, dtype=torch.int32)
         self.d_temp = z(B, dtype=torch.float32)   # per-slot sampling temperature and seed
         self.d_seed = z(B, dtype=torch.int32)
+        # guided decoding: per slot the device addresses of its pattern's tables (0 = unconstrained) + its DFA state
+        self.d_gtrans = z(B, dtype=torch.int64)
+        self.d_gmasks = z(B, dtype=torch.int64)
+        self.d_gstate = z(B, dtype=torch.int32)
+        self.mask_words = 2 * ((t.vocab_size + 63) // 64)
+        self.d_voc_off = self.d_voc_bytes = None   # set_vocab()
+        self._guides: Dict[str, DeviceGuide] = {}
+        self._slot_guides: Dict[int, DeviceGuide] = {}   # keeps the tables of the running requests alive
+        # log-probabilities: [hist][B][1 + 20] / [hist][B][20], allocated with the token history when asked for
+        self.lp_part = max(64 if t.vocab_size > 4096 else 1, -(-t.vocab_size // 4096))   # slices of <= 4096 logits
+        self.d_lp = self.d_lpi = None
+        self.d_lp_pv = z(B, self.lp_part, 20, dtype=torch.float32)
+        self.d_lp_pi = z(B, self.lp_part, 20, dtype=torch.int32)
+        self.d_lp_ms = z(B, self.lp_part, 2, dtype=torch.float32)
         self.max_new = 0
         self.d_hist = None
         self.d_eos = torch.tensor(list(self.cfg.eos_token_ids), dtype=torch.int32, device=dev)
@@ -661,6 +690,83 @@ class Engine:
         return self.img_embeds[:T]
 
     # ------------------------------------------------------------------ prefill
+    # ------------------------------------------------------------------ guided decoding
+    def set_vocab(self, token_bytes: Sequence[bytes]):
+        """Byte string of every token id (b"" for special tokens) — what a pattern is matched against.  Needed once
+        before any guided request (serving.ChatFrontend hands over its tokenizer's table)."""
+        from .guided import pack_vocab
+        V = self.cfg.text.vocab_size
+        tb = list(token_bytes)[:V] + [b""] * max(0, V - len(token_bytes))
+        off, flat = pack_vocab(tb)
+        self.d_voc_off = torch.from_numpy(off).to(self.device)
+        self.d_voc_bytes = torch.from_numpy(flat).to(self.device)
+        self._guides.clear()
+
+    def compile_guide(self, guide) -> DeviceGuide:
+        """guided.Guide (or a regex string) -> device tables; cached by pattern."""
+        from .guided import Guide, compile_regex
+        if isinstance(guide, DeviceGuide):
+            return guide
+        if isinstance(guide, str):
+            hit = self._guides.get(guide)
+            if hit is not None:
+                return hit
+            guide = compile_regex(guide)
+        if not isinstance(guide, Guide):
+            raise KarantaHipError(f"not a guide: {type(guide).__name__}")
+        if guide.pattern and guide.pattern in self._guides:
+            return self._guides[guide.pattern]
+        if self.d_voc_off is None:
+            raise KarantaHipError("guided decoding needs the vocabulary's byte strings: call Engine.set_vocab() first")
+        S = guide.n_states
+        trans = torch.from_numpy(np.ascontiguousarray(guide.trans).view(np.int16)).to(self.device)
+        accept = torch.from_numpy(np.ascontiguousarray(guide.accept).astype(np.uint8)).to(self.device)
+        masks = torch.empty(S, self.mask_words, dtype=torch.int32, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        with torch.cuda.stream(self.stream):
+            self.L.kr_guide_build_masks(ptr(trans), ptr(accept), S, ptr(self.d_voc_off), ptr(self.d_voc_bytes),
+                                        self.cfg.text.vocab_size, ptr(self.d_eos), self.d_eos.numel(), ptr(masks),
+                                        self.mask_words, self.s)
+        self.stream.synchronize()
+        dg = DeviceGuide(guide, trans, masks)
+        if guide.pattern:
+            if len(self._guides) >= 64:           # bounded cache: drop the oldest pattern
+                self._guides.pop(next(iter(self._guides)))
+            self._guides[guide.pattern] = dg
+        return dg
+
+    def _guide_rows(self, pages):
+        """Per page: (trans address, masks address, start state, DeviceGuide | None)."""
+        rows = []
+        for p in pages:
+            g = getattr(p, "guide", None)
+            if g is None:
+                rows.append((0, 0, 0, None))
+                continue
+            if not self._guided:
+                raise KarantaHipError("a page carries a guide but the engine is not in its guided configuration "
+                                      "(generate() decides from its pages; begin_slots(guided=True) for slot mode)")
+            dg = self.compile_guide(g)
+            rows.append((dg.trans.data_ptr(), dg.masks.data_ptr(), dg.start, dg))
+        return rows
+
+    def _ensure_history(self, max_new_tokens: int):
+        """Token history, rotary table and (when asked for) log-prob history sized for max_new_tokens; their
+        addresses are baked into captured graphs, so a reallocation drops the graphs."""
+        grow = self.d_hist is None or self.max_new < max_new_tokens
+        if grow:
+            self.max_new = max_new_tokens
+            self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
+            self.d_cs = torch.zeros(self.B, max_new_tokens, self.cfg.text.head_dim, dtype=torch.float32, device=self.device)
+        if self._logprobs is not None and (self.d_lp is None or self.d_lp.shape[0] < self.max_new + 1):
+            self.d_lp = torch.zeros(self.max_new + 1, self.B, 21, dtype=torch.float32, device=self.device)
+            self.d_lpi = torch.zeros(self.max_new + 1, self.B, 20, dtype=torch.int32, device=self.device)
+            grow = True
+        if grow:
+            for g in self._graphs.values():
+                self.L.kr_graph_destroy(g)
+            self._graphs.clear()
+
     def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int,
                 slots: Optional[Sequence[int]] = None, defer_activation: bool = False):
         """embed+scatter, M-RoPE, 28 x decoder layer over the flattened prompts (causal varlen
@@ -725,11 +831,19 @@ class Engine:
             if temps.max(initial=0.0) > 0 and not self._sampling:
                 raise KarantaHipError("a page asks for temperature > 0 but the engine is in its greedy configuration "
                                       "(generate() decides from its pages; begin_slots(sampling=True) for slot mode)")
+            grows = self._guide_rows(pages)
             if whole_batch:
                 tb, sb = np.zeros(self.B, np.float32), np.zeros(self.B, np.int32)
                 tb[:B], sb[:B] = temps, seeds
                 self._h2d(self.d_temp, tb)
                 self._h2d(self.d_seed, sb)
+                gt, gm, gs = np.zeros(self.B, np.int64), np.zeros(self.B, np.int64), np.zeros(self.B, np.int32)
+                for b, (a_t, a_m, st, dg) in enumerate(grows):
+                    gt[b], gm[b], gs[b] = a_t, a_m, st
+                self._slot_guides = {b: r[3] for b, r in enumerate(grows) if r[3] is not None}
+                self._h2d(self.d_gtrans, gt)
+                self._h2d(self.d_gmasks, gm)
+                self._h2d(self.d_gstate, gs)
                 ctx0 = np.zeros(self.B, np.int32)
                 ctx0[:B] = np.asarray(lens, np.int32) - 1  # kr_sample_greedy adds 1 -> number of cached tokens
                 plen = np.zeros(self.B, np.int32)
@@ -740,7 +854,7 @@ class Engine:
                 self._h2d(self.d_cs, cs)
                 self.d_fin.zero_()
             elif not defer_activation:
-                self._write_slot_state(slots, lens, deltas, cs, temps, seeds)
+                self._write_slot_state(slots, lens, deltas, cs, temps, seeds, grows)
             self._h2d(self.d_last, last_rows)
             t_ = lambda a: torch.from_numpy(a).to(dev)
             blk_tok0, blk_ntok, blk_kr, blk_vb = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
@@ -772,11 +886,19 @@ class Engine:
             elif not defer_activation:
                 self._first_tokens(slots)
         if defer_activation:
-            return {"slots": slots, "lens": lens, "deltas": deltas, "cs": cs, "temps": temps, "seeds": seeds}
+            return {"slots": slots, "lens": lens, "deltas": deltas, "cs": cs, "temps": temps, "seeds": seeds, "guides": grows}
         return lens
 
-    def _write_slot_state(self, slots, lens, deltas, cs, temps, seeds):
+    def _write_slot_state(self, slots, lens, deltas, cs, temps, seeds, guides=None):
         for b, j in enumerate(slots):
+            a_t, a_m, st, dg = guides[b] if guides is not None else (0, 0, 0, None)
+            self._h2d(self.d_gtrans[j:j + 1], np.asarray([a_t], np.int64))
+            self._h2d(self.d_gmasks[j:j + 1], np.asarray([a_m], np.int64))
+            self._h2d(self.d_gstate[j:j + 1], np.asarray([st], np.int32))
+            if dg is None:
+                self._slot_guides.pop(j, None)
+            else:
+                self._slot_guides[j] = dg
             self._h2d(self.d_delta[j:j + 1], deltas[b:b + 1])
             self._h2d(self.d_ctx[j:j + 1], np.asarray([lens[b] - 1], np.int32))
             self._h2d(self.d_plen[j:j + 1], np.asarray([lens[b]], np.int32))
@@ -800,7 +922,7 @@ class Engine:
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         x = self.d_x if x is None else x
         j = slot0  # rows j .. j+B-1 of every per-sequence array (the slot scheduler prefills single slots)
-        logits = self.d_logits[j:] if (self._want_logits or self._sampling) else None
+        logits = self.d_logits[j:] if (self._want_logits or self._sampling or self._logprobs is not None) else None
         if self.wide_mode:
             self._dec_wide(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits)
         else:
@@ -811,13 +933,27 @@ class Engine:
             # temperature > 0 somewhere in the batch: the partial argmax is redone on logits / T + Gumbel noise
             # (rows with T = 0 get their plain argmax back)
             n_part = min(64, self.n_amax)
-            L.kr_gumbel_argmax(ptr(logits), self.d_logits.stride(0), t.vocab_size, ptr(self.d_temp[j:]), ptr(self.d_seed[j:]),
-                               ptr(self.d_ctx[j:]), ptr(self.d_plen[j:]), ptr(self.d_amax_v), ptr(self.d_amax_i), n_part, B, s)
+            if self._guided:   # guided slots: only the tokens their DFA state allows take part
+                L.kr_gumbel_argmax_guided(ptr(logits), self.d_logits.stride(0), t.vocab_size, ptr(self.d_temp[j:]),
+                                          ptr(self.d_seed[j:]), ptr(self.d_ctx[j:]), ptr(self.d_plen[j:]), ptr(self.d_amax_v),
+                                          ptr(self.d_amax_i), n_part, B, ptr(self.d_gmasks[j:]), ptr(self.d_gstate[j:]),
+                                          self.mask_words, int(self.cfg.eos_token_ids[0]), s)
+            else:
+                L.kr_gumbel_argmax(ptr(logits), self.d_logits.stride(0), t.vocab_size, ptr(self.d_temp[j:]), ptr(self.d_seed[j:]),
+                                   ptr(self.d_ctx[j:]), ptr(self.d_plen[j:]), ptr(self.d_amax_v), ptr(self.d_amax_i), n_part, B, s)
         flags = (1 if self._ignore_eos else 0) | (2 if self._freeze_finished else 0)
         L.kr_sample_greedy(ptr(self.d_amax_v), ptr(self.d_amax_i), n_part, ptr(w.view("llm.embed")), t.hidden_size,
                            ptr(self.d_tok[j:]), ptr(self.d_hist[:, j:]), self.d_hist.stride(0), ptr(self.d_plen[j:]),
                            ptr(self.d_ctx[j:]), ptr(self.d_fin[j:]), ptr(self.d_eos), self.d_eos.numel(),
                            self.cfg.pad_token_id, flags, ptr(self.d_x[j:]), B, s)
+        if self._guided:
+            L.kr_guide_advance(ptr(self.d_tok[j:]), ptr(self.d_fin[j:]), ptr(self.d_gtrans[j:]), ptr(self.d_gstate[j:]),
+                               ptr(self.d_voc_off), ptr(self.d_voc_bytes), t.vocab_size, B, s)
+        if self._logprobs is not None:
+            L.kr_logprobs_topk(ptr(logits), self.d_logits.stride(0), t.vocab_size, int(self._logprobs), self.lp_part,
+                               ptr(self.d_lp_pv), ptr(self.d_lp_pi), ptr(self.d_lp_ms), ptr(self.d_tok[j:]), ptr(self.d_ctx[j:]),
+                               ptr(self.d_plen[j:]), ptr(self.d_fin[j:]), ptr(self.d_lp[:, j:]), ptr(self.d_lpi[:, j:]),
+                               self.d_lp.shape[0], self.B, 20, B, s)
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
@@ -973,8 +1109,11 @@ class Engine:
         nbytes = wbytes + 2 * (t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
         return {"launches": n, "avg_us": ms.value * 1e3 / n, "bytes_per_launch": nbytes}
 
+    def _graph_key(self, B: int):
+        return (B, self._ignore_eos, self._freeze_finished, self._sampling, self._guided, self._logprobs)
+
     def _graph_for(self, B: int) -> int:
-        key = (B, self._ignore_eos, self._freeze_finished, self._sampling)
+        key = self._graph_key(B)
         assert not self._want_logits
         g = self._graphs.get(key)
         if g is None:
@@ -1008,16 +1147,15 @@ class Engine:
         self._ignore_eos = bool(ignore_eos)
         self._freeze_finished = False
         self._want_logits = bool(return_logits)
-        self._sampling = any(float(getattr(p, "temperature", 0.0) or 0.0) > 0 for p in pages)
+        self._guided = any(getattr(p, "guide", None) is not None for p in pages)
+        # a guided row is masked in the sampling pass, so that pass runs (rows with T = 0 stay a plain argmax)
+        self._sampling = self._guided or any(float(getattr(p, "temperature", 0.0) or 0.0) > 0 for p in pages)
+        ks = [int(p.logprobs) for p in pages if getattr(p, "logprobs", None) is not None]
+        if ks and not 0 <= max(ks) <= 20:
+            raise KarantaHipError("logprobs must be in 0..20")
+        self._logprobs = max(ks) if ks else None
         self._last_batch = B
-        if self.d_hist is None or self.max_new < max_new_tokens:
-            self.max_new = max_new_tokens
-            self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
-            self.d_cs = torch.zeros(self.B, max_new_tokens, self.cfg.text.head_dim, dtype=torch.float32, device=self.device)
-            # history pointer is baked into captured graphs
-            for g in self._graphs.values():
-                self.L.kr_graph_destroy(g)
-            self._graphs.clear()
+        self._ensure_history(max_new_tokens)
         grids = [g for p in pages for g in p.grids]
         n_img_tok = 0
         pix = self._pixels_for(pages, pixel_values_device)
@@ -1035,7 +1173,7 @@ class Engine:
         steps_done = 1
         with torch.cuda.stream(self.stream):
             want_graph = use_graph and not return_logits
-            graph = self._graphs.get((B, self._ignore_eos, False, self._sampling)) if want_graph else None
+            graph = self._graphs.get(self._graph_key(B)) if want_graph else None
             while steps_done < max_new_tokens:
                 if graph is not None and profile_every and steps_done % profile_every == 0:
                     self._prof_on = True
@@ -1071,32 +1209,48 @@ class Engine:
                     cut, reason = int(hit[0]) + 1, "stop"
             toks.append(row[:cut].astype(np.int64))
             reasons.append(reason)
+        lps = None
+        if self._logprobs is not None:
+            lp = self.d_lp[:steps_done, :B].cpu().numpy()
+            li = self.d_lpi[:steps_done, :B].cpu().numpy()
+            lps = []
+            for b, p in enumerate(pages):
+                k = getattr(p, "logprobs", None)
+                n = len(toks[b]) - (1 if reasons[b] == "stop" else 0)   # the EOS step records nothing
+                lps.append(None if k is None else {"token": lp[:n, b, 0].copy(), "top": lp[:n, b, 1:1 + int(k)].copy(),
+                                                   "top_ids": li[:n, b, :int(k)].astype(np.int64)})
         return GenerateResult(
             tokens=toks, finish_reasons=reasons, prompt_tokens=lens,
             timings={"vit_s": t1 - t0, "prefill_s": t2 - t1, "decode_s": t3 - t2, "total_s": t3 - t0,
                      "decode_steps": steps_done - 1},
-            logits=np.stack(logits_steps, 1) if return_logits else None)
+            logits=np.stack(logits_steps, 1) if return_logits else None, logprobs=lps)
 
     # ------------------------------------------------------------------ slot scheduler API (continuous batching)
     # The decode graph always runs all `max_batch` slots; a slot whose sequence has finished idles in place
     # (kr_sample_greedy freeze bit) until `admit` prefills a new request into it.  See scheduler.SlotScheduler.
-    def begin_slots(self, max_new_tokens: int, sampling: bool = False):
+    def begin_slots(self, max_new_tokens: int, sampling: bool = False, guided: bool = False, logprobs: Optional[int] = None):
         """Enter slot mode: every slot idle, per-slot history / rotary tables sized for `max_new_tokens`.
-        sampling=True: the decode graph carries the Gumbel-max pass, so requests may ask for temperature > 0."""
+        sampling=True: the decode graph carries the Gumbel-max pass, so requests may ask for temperature > 0.
+        guided=True: that pass masks the logits of slots that carry a guide and their DFA state advances in the graph
+        (needs set_vocab()).  logprobs=k: every step records log-probabilities of the token and of the k most probable."""
         if max_new_tokens < 1:
             raise ValueError("max_new_tokens must be >= 1")
-        self._ignore_eos, self._freeze_finished, self._want_logits, self._sampling = False, True, False, bool(sampling)
+        if logprobs is not None and not 0 <= int(logprobs) <= 20:
+            raise KarantaHipError("logprobs must be in 0..20")
+        if guided and self.d_voc_off is None:
+            raise KarantaHipError("guided decoding needs the vocabulary's byte strings: call Engine.set_vocab() first")
+        self._ignore_eos, self._freeze_finished, self._want_logits = False, True, False
+        self._guided = bool(guided)
+        self._sampling = bool(sampling) or self._guided
+        self._logprobs = None if logprobs is None else int(logprobs)
         self._last_batch = self.B
-        if self.d_hist is None or self.max_new < max_new_tokens:
-            self.max_new = max_new_tokens
-            self.d_hist = torch.zeros(max_new_tokens + 1, self.B, dtype=torch.int32, device=self.device)
-            self.d_cs = torch.zeros(self.B, max_new_tokens, self.cfg.text.head_dim, dtype=torch.float32, device=self.device)
-            for g in self._graphs.values():
-                self.L.kr_graph_destroy(g)
-            self._graphs.clear()
+        self._ensure_history(max_new_tokens)
         with torch.cuda.stream(self.stream):
             self.d_fin.fill_(1)
             self.d_temp.zero_()
+            self.d_gtrans.zero_()
+            self.d_gmasks.zero_()
+            self._slot_guides = {}
             self.d_ctx.zero_()
             self.d_plen.zero_()
             self.d_x.zero_()
@@ -1150,7 +1304,8 @@ class Engine:
         rec = handle["rec"]
         self.stream.wait_event(handle["done"])
         with torch.cuda.stream(self.stream):
-            self._write_slot_state(rec["slots"], rec["lens"], rec["deltas"], rec["cs"], rec["temps"], rec["seeds"])
+            self._write_slot_state(rec["slots"], rec["lens"], rec["deltas"], rec["cs"], rec["temps"], rec["seeds"],
+                                   rec.get("guides"))
             self._first_tokens(rec["slots"])
         return rec["lens"]
 
@@ -1158,7 +1313,7 @@ class Engine:
         """n decode steps over all slots (asynchronous on the engine's stream)."""
         with torch.cuda.stream(self.stream):
             for _ in range(n):
-                graph = self._graphs.get((self.B, False, True, self._sampling))
+                graph = self._graphs.get(self._graph_key(self.B))
                 if graph is not None:
                     self.L.kr_graph_launch(graph, self.s)
                 else:  # first step eager (kernel attributes), then captured
@@ -1174,6 +1329,15 @@ class Engine:
 
     def slot_tokens(self, slot: int, n: int) -> np.ndarray:
         return self.d_hist[:n, slot].cpu().numpy().astype(np.int64)
+
+    def slot_logprobs(self, slot: int, n: int, k: int) -> Dict[str, np.ndarray]:
+        """Log-probabilities of the first n generated tokens of a slot (begin_slots(logprobs=...))."""
+        if self.d_lp is None or self._logprobs is None:
+            raise KarantaHipError("log-probabilities were not recorded: begin_slots(logprobs=k)")
+        k = min(int(k), int(self._logprobs))
+        lp = self.d_lp[:n, slot].cpu().numpy()
+        return {"token": lp[:, 0].copy(), "top": lp[:, 1:1 + k].copy(),
+                "top_ids": self.d_lpi[:n, slot, :k].cpu().numpy().astype(np.int64)}
 
     def retire(self, slot: int):
         """Host-side stop (length limit): the slot idles from the next step on."""

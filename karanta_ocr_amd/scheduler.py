@@ -33,6 +33,7 @@ class SlotResult:
     prompt_tokens: int
     error: Optional[str] = None
     request: Optional[SlotRequest] = None   # the request this answers
+    logprobs: Optional[Dict[str, np.ndarray]] = None   # when the page asked for them (Engine.slot_logprobs)
 
 
 class SlotScheduler:
@@ -41,7 +42,7 @@ class SlotScheduler:
 
     def __init__(self, engine, max_tokens_cap: int, chunk: int = 16, eos_token_ids: Optional[Sequence[int]] = None,
                  max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False,
-                 overlap: bool = False):
+                 overlap: bool = False, guided: bool = False, logprobs: Optional[int] = None):
         if max_tokens_cap < 1 or chunk < 1:
             raise ValueError("max_tokens_cap and chunk must be >= 1")
         self.engine = engine
@@ -61,10 +62,17 @@ class SlotScheduler:
         self.slot_steps_busy = 0                     # sum over steps of occupied slots (utilisation numerator)
         # a slot may run up to chunk - 1 steps past its limit before the host looks: size the history for that
         # sampling: pages may carry temperature > 0 (the decode graph then includes the Gumbel-max pass)
+        # guided: pages may carry a pattern (masked sampling pass + DFA advance in the graph); logprobs = k: every step
+        # records log-probabilities (top-k alternatives) for the pages that ask
+        self.logprobs = logprobs
+        kw = {}
         if sampling:
-            engine.begin_slots(self.cap + self.chunk, sampling=True)
-        else:
-            engine.begin_slots(self.cap + self.chunk)
+            kw["sampling"] = True
+        if guided:
+            kw["guided"] = True
+        if logprobs is not None:
+            kw["logprobs"] = int(logprobs)
+        engine.begin_slots(self.cap + self.chunk, **kw)
 
     # ------------------------------------------------------------------ public
     def submit(self, req: SlotRequest) -> None:
@@ -199,6 +207,11 @@ class SlotScheduler:
                 toks, reason = toks[: int(hit[0]) + 1], "stop"
             if not fin[j]:
                 self.engine.retire(j)
-            out.append(SlotResult(r.tag, toks, reason, self.prompt_len.pop(j), request=r))
+            lps = None
+            k = getattr(r.page, "logprobs", None)
+            if k is not None and self.logprobs is not None:
+                n_lp = len(toks) - (1 if reason == "stop" else 0)     # the EOS step records nothing
+                lps = self.engine.slot_logprobs(j, n_lp, int(k))
+            out.append(SlotResult(r.tag, toks, reason, self.prompt_len.pop(j), request=r, logprobs=lps))
             del self.active[j]
         return out

@@ -54,6 +54,12 @@ class ByteTokenizer:
         special = set(self.cfg.eos_token_ids) | {self.im_start, self.cfg.pad_token_id}
         return bytes(int(i) for i in ids if 0 <= int(i) < 256 and int(i) not in special).decode("utf-8", "replace")
 
+    def token_bytes(self) -> List[bytes]:
+        """Byte string of every token id (guided decoding matches patterns against these); b"" = never allowed."""
+        special = set(self.cfg.eos_token_ids) | {self.im_start, self.cfg.pad_token_id}
+        V = self.cfg.text.vocab_size
+        return [bytes([i]) if i < 256 and i not in special else b"" for i in range(V)]
+
 
 class HFTokenizer:
     """``tokenizer.json`` of a real Qwen2-VL checkpoint through the `tokenizers` library."""
@@ -73,6 +79,10 @@ class HFTokenizer:
     def decode(self, ids: Sequence[int]) -> str:
         return self.tk.decode([int(i) for i in ids], skip_special_tokens=True)
 
+    def token_bytes(self) -> List[bytes]:
+        from .guided import vocab_bytes_from_hf
+        return vocab_bytes_from_hf(self.tk, self.cfg.text.vocab_size)
+
 
 # ----------------------------------------------------------------------------- request parsing
 class BadRequest(ValueError):
@@ -89,6 +99,8 @@ class ParsedRequest:
     temperature: float = 0.0
     seed: Optional[int] = None      # None: the server draws one per request
     images: Optional[List[np.ndarray]] = None   # device_images front end: decoded HWC uint8 pages instead of pixel_values
+    guide: Any = None               # guided.Guide compiled from guided_regex / response_format (None: unconstrained)
+    logprobs: Optional[int] = None  # None: not asked; k: log-prob of every token + top_logprobs = k alternatives
 
 
 class ChatFrontend:
@@ -107,6 +119,24 @@ class ChatFrontend:
         # (Engine.patches_from_images, bit-identical to the host path) and 3 bytes per pixel cross PCIe
         self.device_images = bool(device_images)
         self.max_model_len = max_model_len  # reference --max_model_len default (pipeline.py:1225-1230)
+        self._guide_cache: Dict[str, Any] = {}   # regex -> guided.Guide (the pipeline sends one pattern for every page)
+
+    def _guide_for(self, req: Dict[str, Any]):
+        """guided_regex (pipeline.py:304-307) / response_format (vllm_client.py:196) -> byte DFA, or None."""
+        from .guided import GuideError, compile_regex, regex_for_request
+        try:
+            rx = regex_for_request(req.get("guided_regex"), req.get("response_format"))
+            if rx is None:
+                return None
+            g = self._guide_cache.get(rx)
+            if g is None:
+                g = compile_regex(rx)
+                if len(self._guide_cache) >= 64:
+                    self._guide_cache.pop(next(iter(self._guide_cache)))
+                self._guide_cache[rx] = g
+            return g
+        except GuideError as e:
+            raise BadRequest(f"guided decoding: {e}") from e
 
     def _turn(self, role: str, body: List[int]) -> List[int]:
         t = self.tok
@@ -169,8 +199,17 @@ class ChatFrontend:
             raise BadRequest(f"temperature / seed: {e}") from e
         if not (0.0 <= temperature <= 100.0):   # NaN fails both comparisons
             raise BadRequest("temperature must be in [0, 100]")
+        logprobs = None
+        if req.get("logprobs"):
+            try:
+                logprobs = int(req.get("top_logprobs") or 0)
+            except (TypeError, ValueError) as e:
+                raise BadRequest(f"top_logprobs: {e}") from e
+            if not 0 <= logprobs <= 20:
+                raise BadRequest("top_logprobs must be in 0..20")
         return ParsedRequest(np.asarray(ids, np.int64), np.concatenate(pvs, 0) if pvs else None, grids, max_tokens,
-                             str(req.get("model", "karantaocr")), temperature, seed, images or None)
+                             str(req.get("model", "karantaocr")), temperature, seed, images or None,
+                             self._guide_for(req), logprobs)
 
 
 # ----------------------------------------------------------------------------- in-process server
@@ -186,9 +225,17 @@ class LocalServer:
 
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
                  batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
-                 chunk: int = 16, honor_temperature: bool = True):
+                 chunk: int = 16, honor_temperature: bool = True, max_logprobs: Optional[int] = None):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
         self.honor_temperature = bool(honor_temperature)   # False: every request is served greedy
+        # guided decoding needs the tokenizer's byte strings on the device; engines without set_vocab (test fakes)
+        # answer guided requests with 400
+        self.guided = hasattr(engine, "set_vocab") and hasattr(frontend.tok, "token_bytes")
+        if self.guided:
+            engine.set_vocab(frontend.tok.token_bytes())
+        # continuous mode: the decode graph records log-probabilities only when this is set (top_logprobs bound,
+        # vLLM's --max-logprobs); static mode decides per batch
+        self.max_logprobs = None if max_logprobs is None else int(max_logprobs)
         self.batch_wait_s, self.log = batch_wait_s, log
         self.continuous, self.max_tokens_cap, self.chunk = bool(continuous), int(max_tokens_cap), int(chunk)
         self._q: "queue.Queue" = queue.Queue()
@@ -226,6 +273,11 @@ class LocalServer:
             return 400, {"error": {"message": str(e), "type": "BadRequestError", "code": 400}}
         except Exception as e:  # malformed beyond recognition
             return 400, {"error": {"message": f"malformed request: {e}", "type": "BadRequestError", "code": 400}}
+        if parsed.guide is not None and not self.guided:
+            return 400, {"error": {"message": "guided decoding is not available on this server", "type": "BadRequestError", "code": 400}}
+        if parsed.logprobs is not None and self.continuous and (self.max_logprobs is None or parsed.logprobs > self.max_logprobs):
+            return 400, {"error": {"message": f"logprobs: this server records at most {self.max_logprobs} top_logprobs "
+                                              "(start it with --max-logprobs)", "type": "BadRequestError", "code": 400}}
         slot: Dict[str, Any] = {"req": parsed, "done": threading.Event()}
         self._q.put(slot)
         slot["done"].wait()
@@ -235,12 +287,27 @@ class LocalServer:
         text = self.frontend.tok.decode(toks)
         self.latencies.append(time.time() - t0)
         n_in, n_out = int(len(parsed.input_ids)), int(len(toks))
+        choice: Dict[str, Any] = {"index": 0, "message": {"role": "assistant", "content": text}, "finish_reason": reason}
+        if parsed.logprobs is not None:
+            choice["logprobs"] = self._logprobs_json(toks, slot.get("logprobs"), parsed.logprobs)
         return 200, {
             "id": "chatcmpl-" + uuid.uuid4().hex, "object": "chat.completion", "created": int(time.time()),
             "model": req.get("model", self.name),
-            "choices": [{"index": 0, "message": {"role": "assistant", "content": text}, "finish_reason": reason}],
+            "choices": [choice],
             "usage": {"prompt_tokens": n_in, "completion_tokens": n_out, "total_tokens": n_in + n_out},
         }
+
+    def _logprobs_json(self, toks, lp, k: int) -> Optional[dict]:
+        """OpenAI chat `logprobs` object: per generated token its text, log-prob, bytes and the top-k alternatives."""
+        if lp is None:
+            return None
+        tok = self.frontend.tok
+        piece = lambda i: tok.decode([int(i)])
+        item = lambda i, v: {"token": piece(i), "logprob": float(v), "bytes": list(piece(i).encode("utf-8"))}
+        n = min(len(toks), len(lp["token"]))
+        return {"content": [dict(item(toks[i], lp["token"][i]),
+                                 top_logprobs=[item(lp["top_ids"][i][j], lp["top"][i][j]) for j in range(min(k, lp["top"].shape[1]))])
+                            for i in range(n)]}
 
     def close(self):
         self._stop = True
@@ -272,7 +339,9 @@ class LocalServer:
             try:
                 pages = [self._page(s["req"]) for s in batch]
                 res = self.engine.generate(pages, max(s["req"].max_tokens for s in batch))
-                for s, toks, reason in zip(batch, res.tokens, res.finish_reasons):
+                for i, (s, toks, reason) in enumerate(zip(batch, res.tokens, res.finish_reasons)):
+                    if getattr(res, "logprobs", None) is not None:
+                        s["logprobs"] = res.logprobs[i]
                     self._finish(s, toks, reason)
             except Exception as e:  # engine failure -> 500 for every request of the batch
                 for s in batch:
@@ -287,6 +356,10 @@ class LocalServer:
         from .engine import PageRequest
         import random
         page = PageRequest(r.input_ids, r.pixel_values, r.grids, images=getattr(r, "images", None))
+        if getattr(r, "guide", None) is not None:
+            page.guide = r.guide
+        if getattr(r, "logprobs", None) is not None:
+            page.logprobs = r.logprobs
         if self.honor_temperature and r.temperature > 0:
             page.temperature = r.temperature
             page.seed = r.seed if r.seed is not None else random.getrandbits(32)
@@ -306,7 +379,8 @@ class LocalServer:
         from .scheduler import SlotRequest, SlotScheduler
 
         try:
-            sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature)
+            sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature,
+                                guided=self.guided, logprobs=self.max_logprobs)
         except Exception as e:  # cannot enter slot mode: every request gets a 500
             sch, boot_error = None, f"{type(e).__name__}: {e}"
         last = (-1, -1)
@@ -342,7 +416,8 @@ class LocalServer:
                     r.tag["done"].set()
                 self.pages_done += len(sch.active) + len(sch.waiting)
                 try:
-                    sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature)
+                    sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature,
+                                guided=self.guided, logprobs=self.max_logprobs)
                 except Exception as e2:
                     sch, boot_error = None, f"{type(e2).__name__}: {e2}"
                 continue
@@ -356,6 +431,8 @@ class LocalServer:
                 if res.error:
                     s["error"] = res.error
                 else:
+                    if res.logprobs is not None:
+                        s["logprobs"] = res.logprobs
                     self._finish(s, res.tokens, res.finish_reason)
                 self.pages_done += 1
                 s["done"].set()

@@ -604,17 +604,60 @@ def sample_scores(logits: np.ndarray, temperature: float, seed: int, n: int) -> 
     return logits * np.float32(1.0 / np.float32(temperature)) + gumbel_noise(seed, n, logits.shape[-1])
 
 
+# ----------------------------------------------------------------------------- guided decoding + log-probabilities
+# What vLLM's guided-decoding logits processor and its `logprobs` output compute for the requests the reference
+# sends (guided_regex: /root/reference/karanta/pipeline.py:304-307; response_format:
+# /root/reference/bulk_processing/workers/vllm_client.py:196; logprobs / top_logprobs:
+# /root/reference/karanta/data/create_batch_data_prompts.py:117-118), restated over a byte DFA given as data
+# (trans [S, 256], accept [S], state 0 = dead): a token is allowed iff it has bytes and they keep the automaton
+# alive; EOS is allowed iff the state accepts.  Plain loops: this is the checker, not the product.
+def guide_walk(trans: np.ndarray, state: int, data: bytes) -> int:
+    for byte in data:
+        if state == 0:
+            break
+        state = int(trans[state, byte])
+    return state
+
+
+def guide_token_mask(trans: np.ndarray, accept: np.ndarray, state: int, token_bytes: Sequence[bytes],
+                     eos_ids: Sequence[int]) -> np.ndarray:
+    allowed = np.zeros(len(token_bytes), dtype=bool)
+    for i, tb in enumerate(token_bytes):
+        allowed[i] = state != 0 and len(tb) > 0 and guide_walk(trans, state, tb) != 0
+    for e in eos_ids:
+        if 0 <= e < len(token_bytes):
+            allowed[e] = state != 0 and bool(accept[state])
+    return allowed
+
+
+def log_softmax(logits: np.ndarray) -> np.ndarray:
+    x = np.asarray(logits, dtype=np.float64)
+    m = x.max(axis=-1, keepdims=True)
+    return x - m - np.log(np.exp(x - m).sum(axis=-1, keepdims=True))
+
+
+def top_logprobs(logits: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(ids [k], log-probs [k]) of the k most probable tokens of one row, ties to the lowest id."""
+    lp = log_softmax(logits)
+    order = np.argsort(-np.asarray(logits, dtype=np.float64), kind="stable")[:k]
+    return order.astype(np.int64), lp[order]
+
+
 def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[np.ndarray],
                     image_grid_thw: Optional[Sequence[Sequence[int]]], max_new_tokens: int,
                     policy: str = "fp32", ignore_eos: bool = False,
-                    return_logits: bool = False, temperature: float = 0.0, seed: int = 0):
+                    return_logits: bool = False, temperature: float = 0.0, seed: int = 0,
+                    guide=None, token_bytes: Optional[Sequence[bytes]] = None, return_raw_logits: bool = False):
     """The call sequence of /root/reference/karanta/training/test_trained_model.py:76-99
     (``model.generate(**inputs, max_new_tokens=N)`` with ``do_sample=False``), i.e. what a
     ``temperature=0`` request to the reference's vLLM server computes
     (/root/reference/karanta/pipeline.py:166-171): ViT → scatter → prefill → greedy decode,
     stopping at EOS.  Single-sequence or equal-length batch (no padding).
     temperature > 0 (the reference's first attempt sends 0.1, pipeline.py:281,301): Gumbel-max sampling with the
-    build's counter-based noise (`sample_scores`); the returned "logits" are then the noisy scores."""
+    build's counter-based noise (`sample_scores`); the returned "logits" are then the noisy scores.
+    guide = (trans, accept, start) with token_bytes: scores of tokens the automaton forbids become -inf before the
+    argmax (after temperature / noise), the state follows the chosen token's bytes.  return_raw_logits: also the
+    model's own logits per step (what log-probabilities are taken from)."""
     input_ids = np.asarray(input_ids)
     B, P = input_ids.shape
     img = None
@@ -627,14 +670,29 @@ def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[
         pos = np.tile(np.arange(P)[None, None, :], (3, B, 1))
         delta = np.zeros((B,), dtype=np.int64)
     cache = KVCache.empty(cfg.text.num_layers)
-    noisy = lambda lg, n: np.stack([sample_scores(lg[b], temperature, seed, n) for b in range(B)])
-    logits = noisy(decoder_forward(emb, pos, weights, cfg.text, cache, policy), 0)
+    gstate = [guide[2]] * B if guide is not None else None
+
+    def noisy(lg, n):
+        sc = np.stack([sample_scores(lg[b], temperature, seed, n) for b in range(B)])
+        if guide is not None:
+            for b in range(B):
+                ok = guide_token_mask(guide[0], guide[1], gstate[b], token_bytes, cfg.eos_token_ids)
+                sc[b] = np.where(ok, sc[b], -np.inf)
+        return sc
+
+    raw = decoder_forward(emb, pos, weights, cfg.text, cache, policy)
+    raw_logits = [raw]
+    logits = noisy(raw, 0)
     all_logits = [logits]
     out = np.zeros((B, 0), dtype=np.int64)
     done = np.zeros((B,), dtype=bool)
     for step in range(max_new_tokens):
         nxt = logits.argmax(axis=-1)
         nxt = np.where(done, cfg.pad_token_id, nxt)
+        if guide is not None:
+            for b in range(B):
+                if not done[b] and int(nxt[b]) not in cfg.eos_token_ids:
+                    gstate[b] = guide_walk(guide[0], gstate[b], token_bytes[int(nxt[b])])
         out = np.concatenate([out, nxt[:, None]], axis=1)
         if not ignore_eos:
             done |= np.isin(nxt, cfg.eos_token_ids)
@@ -644,8 +702,12 @@ def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[
             break
         e = embed_and_scatter(nxt[:, None], None, weights, cfg)
         ppos = np.tile((P + step + delta)[None, :, None], (3, 1, 1))
-        logits = noisy(decoder_forward(e, ppos, weights, cfg.text, cache, policy), step + 1)
+        raw = decoder_forward(e, ppos, weights, cfg.text, cache, policy)
+        raw_logits.append(raw)
+        logits = noisy(raw, step + 1)
         all_logits.append(logits)
+    if return_raw_logits:
+        return out, np.stack(all_logits, axis=1), np.stack(raw_logits, axis=1)
     if return_logits:
         return out, np.stack(all_logits, axis=1)
     return out

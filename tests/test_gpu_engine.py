@@ -352,3 +352,176 @@ def test_batches_above_16_rows_equal_solo_generation():
         Engine(CONFIGS["tiny"], max_batch=17, s_max=256, max_patches=256, max_prompt_tokens=256)   # hidden 256: no wide kernel
     with pytest.raises(KarantaHipError, match="max_batch > 32"):
         Engine(cfg, max_batch=33, s_max=256, max_patches=256, max_prompt_tokens=256)
+
+
+GUIDE_PATTERN = r"[a-f]{3}-[0-9]{2}(?:;[a-z ]{2,5})?"
+
+
+def _guided_pages(cfg, temp):
+    pv, grid = IP.image_to_patches(IP.synthetic_page(71, 84, 112))
+    T = grid[1] * grid[2] // 4
+    ids = np.concatenate([[5, 6, cfg.vision_start_token_id], [cfg.image_token_id] * T, [cfg.vision_end_token_id, 7, 8]]).astype(np.int64)
+    pv2, grid2 = IP.image_to_patches(IP.synthetic_page(72, 56, 84))
+    ids2 = np.concatenate([[9, cfg.vision_start_token_id], [cfg.image_token_id] * (grid2[1] * grid2[2] // 4),
+                           [cfg.vision_end_token_id, 3]]).astype(np.int64)
+    return (ids, pv, grid), (ids2, pv2, grid2), temp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "tiny-gqa"])
+def test_guided_generation_and_logprobs_match_oracle(engines, tiny_models, name):
+    """guided_regex (karanta/pipeline.py:304-307) and logprobs / top_logprobs on the device: guided rows (greedy and
+    sampled) produce text that matches the pattern and stop by themselves, and equal the oracle's masked argmax up to
+    the first low-margin step; an unguided row of the same batch is untouched; log-probabilities equal the log-softmax
+    of the engine's own logits (ids exact) and the oracle's within the logit tolerance."""
+    import re
+    from karanta_ocr_amd import guided as G
+    from karanta_ocr_amd.serving import ByteTokenizer
+    cfg, w, P = tiny_models[name]
+    eng = engines[name]
+    voc = ByteTokenizer(cfg).token_bytes()
+    eng.set_vocab(voc)
+    g = G.compile_regex(GUIDE_PATTERN)
+    (ids, pv, grid), (ids2, pv2, grid2), _ = _guided_pages(cfg, 0)
+    _, lg0 = O.generate_greedy(cfg, w, ids[None], pv, [grid], 1, policy="bf16", ignore_eos=True, return_logits=True)
+    rng_ = float(np.abs(lg0[0, 0]).max())
+    temp = max(0.9, 0.3 * rng_)
+    pages = [PageRequest(ids, pv, [grid], guide=g, logprobs=3),
+             PageRequest(ids, pv, [grid], guide=GUIDE_PATTERN, temperature=temp, seed=77),
+             PageRequest(ids2, pv2, [grid2], logprobs=5),
+             PageRequest(ids2, pv2, [grid2], guide=g)]
+    steps = 16
+    res = eng.generate(pages, steps)
+    eos = set(cfg.eos_token_ids)
+    for b in (0, 1, 3):
+        toks = res.tokens[b]
+        assert res.finish_reasons[b] == "stop" and int(toks[-1]) in eos, (b, toks)
+        text = b"".join(voc[int(t)] for t in toks[:-1]).decode()
+        assert re.fullmatch(GUIDE_PATTERN, text), (b, text)
+    plain = eng.generate([PageRequest(ids2, pv2, [grid2])], steps)
+    np.testing.assert_array_equal(res.tokens[2], plain.tokens[0])                   # unguided row of a guided batch
+    assert res.logprobs[1] is None and res.logprobs[3] is None
+    # oracle: masked argmax with the same DFA (as data), greedy and sampled
+    tol = 0.02 * rng_
+    for b, (i_, p_, g_), T_, seed in ((0, (ids, pv, grid), 0.0, 0), (1, (ids, pv, grid), temp, 77), (3, (ids2, pv2, grid2), 0.0, 0)):
+        ref_tok, ref_sc = O.generate_greedy(cfg, w, i_[None], p_, [g_], steps, policy="bf16", return_logits=True, temperature=T_,
+                                            seed=seed, guide=(g.trans, g.accept, g.start), token_bytes=voc)
+        n = compare_tokens(res.tokens[b], ref_tok[0], ref_sc[0], tol / (T_ if T_ > 0 else 1.0))
+        assert n >= 2, f"row {b}: only {n} guided tokens could be checked"
+    # log-probabilities against the engine's own logits (eager run returning them) and against the oracle model
+    eager = eng.generate(pages, steps, return_logits=True)
+    for b, k in ((0, 3), (2, 5)):
+        np.testing.assert_array_equal(eager.tokens[b], res.tokens[b])
+        lp = res.logprobs[b]
+        n = len(res.tokens[b]) - (1 if res.finish_reasons[b] == "stop" else 0)
+        assert lp["token"].shape == (n,) and lp["top"].shape == (n, k) and lp["top_ids"].shape == (n, k)
+        for i in range(n):
+            ids_, vals = O.top_logprobs(eager.logits[b, i], k)
+            np.testing.assert_array_equal(lp["top_ids"][i], ids_)
+            np.testing.assert_allclose(lp["top"][i], vals, rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(lp["token"][i], O.log_softmax(eager.logits[b, i])[int(res.tokens[b][i])], rtol=1e-5, atol=1e-4)
+            np.testing.assert_array_equal(eager.logprobs[b]["top_ids"][i], ids_)
+    ref_tok, _, raw = O.generate_greedy(cfg, w, ids2[None], pv2, [grid2], steps, policy="bf16", return_raw_logits=True)
+    m = 0
+    while m < min(len(ref_tok[0]), len(res.tokens[2])) and ref_tok[0][m] == res.tokens[2][m]:
+        m += 1
+    m = min(m + 1, len(res.logprobs[2]["token"]))        # the logits of the first differing step still share their prefix
+    assert m >= 3
+    for i in range(m):
+        want = O.log_softmax(raw[0, i])[int(res.tokens[2][i])]
+        assert abs(res.logprobs[2]["token"][i] - want) <= 2 * tol, (i, res.logprobs[2]["token"][i], want)
+    # errors: a guide without the vocabulary table, logprobs out of range
+    from karanta_ocr_amd._lib import KarantaHipError
+    with pytest.raises(KarantaHipError, match="0..20"):
+        eng.generate([PageRequest(ids, pv, [grid], logprobs=21)], 2)
+    eng.d_voc_off = None
+    eng._guides.clear()
+    with pytest.raises(KarantaHipError, match="set_vocab"):
+        eng.generate([PageRequest(ids, pv, [grid], guide=r"zz+")], 2)
+    eng.set_vocab(voc)
+
+
+@pytest.mark.gpu
+def test_slot_scheduler_guided_and_logprobs_equal_solo(engines, tiny_models):
+    """Continuous batching with guides and log-probabilities: patterns, DFA states and log-prob histories are per slot
+    and reset on admission — every request equals its solo `generate`, whatever held its slot before."""
+    from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
+    from karanta_ocr_amd.serving import ByteTokenizer
+    cfg, w, P = tiny_models["tiny"]
+    eng = Engine(cfg, max_batch=2, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2)
+    eng.load_weights(w)
+    voc = ByteTokenizer(cfg).token_bytes()
+    eng.set_vocab(voc)
+    (ids, pv, grid), (ids2, pv2, grid2), _ = _guided_pages(cfg, 0)
+    pats = [GUIDE_PATTERN, None, r"(?:yes|no)\n", r"\{\"ok\": (?:true|false)\}", None, GUIDE_PATTERN]
+    pages = []
+    for i, pat in enumerate(pats):
+        src = (ids, pv, grid) if i % 2 == 0 else (ids2, pv2, grid2)
+        pages.append(PageRequest(src[0], src[1], [src[2]], guide=pat, logprobs=(4 if i in (0, 1, 3) else None),
+                                 temperature=(0.8 if i == 5 else 0.0), seed=5))
+    limits = [16, 7, 16, 16, 5, 16]
+    solo = [eng.generate([pg], mt) for pg, mt in zip(pages, limits)]
+    sch = SlotScheduler(eng, max_tokens_cap=16, chunk=3, sampling=True, guided=True, logprobs=4)
+    res = sch.run([SlotRequest(pg, mt, tag=i) for i, (pg, mt) in enumerate(zip(pages, limits))])
+    for i, (r, s) in enumerate(zip(res, solo)):
+        assert r.error is None
+        np.testing.assert_array_equal(r.tokens, s.tokens[0], err_msg=f"request {i}")
+        assert r.finish_reason == s.finish_reasons[0]
+        if pages[i].logprobs is None:
+            assert r.logprobs is None
+        else:
+            for key in ("token", "top", "top_ids"):
+                np.testing.assert_array_equal(r.logprobs[key], s.logprobs[0][key], err_msg=f"request {i} {key}")
+    assert {r.finish_reason for r in res} == {"stop", "length"}
+    assert b"".join(voc[int(t)] for t in res[2].tokens[:-1]) in (b"yes\n", b"no\n")
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_server_guided_json_and_logprobs(engines, tiny_models):
+    """The OpenAI surface: response_format json_schema -> parseable JSON of the schema's shape, guided_regex -> a match,
+    logprobs -> the `choices[0].logprobs.content` list; static and continuous servers agree."""
+    import json
+    import re
+    from karanta_ocr_amd import serving as S
+    cfg, w, P = tiny_models["tiny"]
+    eng = Engine(cfg, max_batch=2, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2)
+    eng.load_weights(w)
+    front = S.ChatFrontend(cfg, S.ByteTokenizer(cfg))
+    url = IP.encode_png_data_url(IP.synthetic_page(44, 56, 84))
+    msg = [{"role": "user", "content": [{"type": "text", "text": "page"}, {"type": "image_url", "image_url": {"url": url}}]}]
+    schema = {"type": "object", "properties": {"lang": {"type": ["string", "null"], "maxLength": 3}, "rot": {"enum": [0, 90]},
+                                               "tab": {"type": "boolean"}}, "required": ["lang", "rot", "tab"]}
+    reqs = [{"messages": msg, "max_tokens": 80, "temperature": 0.0,
+             "response_format": {"type": "json_schema", "json_schema": {"name": "p", "schema": schema, "strict": True}}},
+            {"messages": msg, "max_tokens": 30, "temperature": 0.0, "guided_regex": r"lang: (?:[a-z]{2}|null)\nrot: (?:0|90)\n",
+             "logprobs": True, "top_logprobs": 2},
+            {"messages": msg, "max_tokens": 4, "logprobs": True}]
+    out = {}
+    for mode in ("static", "continuous"):
+        srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=(mode == "continuous"), max_tokens_cap=96, chunk=4,
+                            max_logprobs=5)
+        out[mode] = [srv.chat_completions(r) for r in reqs]
+        if mode == "continuous":
+            st, body = srv.chat_completions({**reqs[2], "top_logprobs": 9})
+            assert st == 400 and "max-logprobs" in body["error"]["message"]
+        st, body = srv.chat_completions({**reqs[1], "guided_regex": "(?=x)y"})
+        assert st == 400 and "guided decoding" in body["error"]["message"]
+        srv.close()
+    for (s0, b0), (s1, b1) in zip(out["static"], out["continuous"]):
+        assert s0 == s1 == 200
+        assert b0["choices"][0]["message"]["content"] == b1["choices"][0]["message"]["content"]
+        assert b0["choices"][0]["finish_reason"] == b1["choices"][0]["finish_reason"]
+        assert b0["choices"][0].get("logprobs") == b1["choices"][0].get("logprobs")
+    doc = json.loads(out["static"][0][1]["choices"][0]["message"]["content"])
+    assert list(doc) == ["lang", "rot", "tab"] and doc["rot"] in (0, 90) and isinstance(doc["tab"], bool)
+    assert out["static"][0][1]["choices"][0]["finish_reason"] == "stop"
+    c1 = out["static"][1][1]["choices"][0]
+    assert re.fullmatch(reqs[1]["guided_regex"], c1["message"]["content"]) and c1["finish_reason"] == "stop"
+    items = c1["logprobs"]["content"]
+    assert "".join(i["token"] for i in items) == c1["message"]["content"]
+    assert all(len(i["top_logprobs"]) == 2 and i["logprob"] <= 0 and i["top_logprobs"][0]["logprob"] >= i["top_logprobs"][1]["logprob"]
+               for i in items)
+    c2 = out["static"][2][1]["choices"][0]
+    assert len(c2["logprobs"]["content"]) == 4 and all(i["top_logprobs"] == [] for i in c2["logprobs"]["content"])
+    eng.close()

@@ -1402,3 +1402,151 @@ def test_rccl_single_rank_broadcast(L):
     torch.cuda.synchronize()
     assert int(buf[12345].item()) == 12345
     L.kr_comm_destroy(comm)
+
+
+# ----------------------------------------------------------------------------- guided decoding + log-probabilities
+def _random_vocab(rng, V, eos):
+    """Token byte strings: all 256 single bytes first (as byte-level BPE has), then random 2..6 byte pieces over a small
+    alphabet so that many of them survive a pattern; a few specials (b"")."""
+    alphabet = b"abcdef0123456789-;: \n{}\",ntrue"
+    voc = [bytes([i]) for i in range(256)]
+    while len(voc) < V:
+        voc.append(bytes(rng.choice(list(alphabet)) for _ in range(int(rng.integers(2, 7)))))
+    for i in rng.integers(256, V, 20):
+        voc[int(i)] = b""
+    for e in eos:
+        voc[e] = b""
+    return voc
+
+
+@pytest.mark.parametrize("pattern", [r"[a-f]{3}-[0-9]{2}(?:;[a-z]+)?", r"\{\"n\": (?:true|null|-?[0-9]+)\}",
+                                     r"---\nab: (?:[a-z]{2}|null)\n(?:---|---\n[\s\S]+)"])
+def test_guide_masks_and_advance_match_oracle(L, pattern):
+    """kr_guide_build_masks against the oracle's token-by-token rule for EVERY state of the DFA (bit-exact), and
+    kr_guide_advance against guide_walk."""
+    from karanta_ocr_amd import guided as G
+    rng = np.random.default_rng(3)
+    V, eos = 3001, [2999, 3000]
+    voc = _random_vocab(rng, V, eos)
+    g = G.compile_regex(pattern)
+    S, mw = g.n_states, 2 * ((V + 63) // 64)
+    off, flat = G.pack_vocab(voc)
+    d_off, d_flat = torch.from_numpy(off).to(DEV), torch.from_numpy(flat).to(DEV)
+    d_trans = torch.from_numpy(g.trans.view(np.int16)).to(DEV)
+    d_acc = torch.from_numpy(g.accept.astype(np.uint8)).to(DEV)
+    d_eos = torch.tensor(eos, dtype=torch.int32, device=DEV)
+    masks = torch.full((S, mw), -1, dtype=torch.int32, device=DEV)
+    L.kr_guide_build_masks(ptr(d_trans), ptr(d_acc), S, ptr(d_off), ptr(d_flat), V, ptr(d_eos), len(eos), ptr(masks), mw, 0)
+    torch.cuda.synchronize()
+    bits = np.unpackbits(masks.cpu().numpy().view(np.uint8), axis=1, bitorder="little")
+    assert not bits[:, V:].any(), "bits beyond the vocabulary must be clear"
+    for s in range(S):
+        want = O.guide_token_mask(g.trans, g.accept, s, voc, eos)
+        np.testing.assert_array_equal(bits[s, :V].astype(bool), want, err_msg=f"state {s}")
+    assert bits[1:, :V].any(axis=1).all(), "every live state allows at least one token"
+    # advance: rows 0..5 guided from various states, row 6 unconstrained, row 7 finished
+    B = 8
+    states = rng.integers(1, S, B).astype(np.int32)
+    toks = np.zeros(B, np.int32)
+    for b in range(B):
+        ok = np.flatnonzero(O.guide_token_mask(g.trans, g.accept, int(states[b]), voc, []))
+        toks[b] = int(rng.choice(ok)) if ok.size else 0
+    fin = np.zeros(B, np.int32); fin[7] = 1
+    gt = np.full(B, d_trans.data_ptr(), np.int64); gt[6] = 0
+    d_st = torch.from_numpy(states.copy()).to(DEV)
+    d_tok, d_fin, d_gt = torch.from_numpy(toks).to(DEV), torch.from_numpy(fin).to(DEV), torch.from_numpy(gt).to(DEV)
+    L.kr_guide_advance(ptr(d_tok), ptr(d_fin), ptr(d_gt), ptr(d_st), ptr(d_off), ptr(d_flat), V, B, 0)
+    torch.cuda.synchronize()
+    got = d_st.cpu().numpy()
+    for b in range(B):
+        want = states[b] if b >= 6 else O.guide_walk(g.trans, int(states[b]), voc[int(toks[b])])
+        assert got[b] == want, (b, got[b], want)       # (a final state without continuation walks byte 0 to the dead state)
+    with pytest.raises(KarantaHipError):
+        L.kr_guide_build_masks(ptr(d_trans), ptr(d_acc), S, ptr(d_off), ptr(d_flat), V, ptr(d_eos), len(eos), ptr(masks), mw - 1, 0)
+
+
+def test_gumbel_argmax_guided_masks_rows(L):
+    """Masked rows pick the best ALLOWED token (greedy and sampled rows), unmasked rows are those of kr_gumbel_argmax,
+    an all-clear mask row yields the fallback token."""
+    rng = np.random.default_rng(23)
+    B, V, n_part = 5, 5003, 7
+    mw = 2 * ((V + 63) // 64)
+    logits = rng.standard_normal((B, V)).astype(np.float32) * 3
+    temps = np.asarray([0.0, 0.9, 0.0, 0.0, 0.7], np.float32)
+    seeds = np.asarray([1, 2, 3, 4, 5], np.uint32)
+    plen = np.asarray([4, 4, 4, 4, 4], np.int32); ctx = np.asarray([6, 9, 4, 5, 11], np.int32)
+    S = 3
+    allow = rng.random((S, V)) < 0.02
+    allow[2] = False                                              # a row that allows nothing
+    words = np.packbits(np.pad(allow, ((0, 0), (0, mw * 32 - V))), axis=1, bitorder="little").view(np.int32)
+    d_masks = torch.from_numpy(words.copy()).to(DEV)
+    gm = np.asarray([d_masks.data_ptr(), d_masks.data_ptr(), 0, d_masks.data_ptr(), 0], np.int64)
+    gs = np.asarray([0, 1, 0, 2, 1], np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    ld, td, sd, pd, cd = t(logits), t(temps), t(seeds.view(np.int32)), t(plen), t(ctx)
+    av = torch.zeros(B, n_part, device=DEV); ai = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
+    d_gm, d_gs = t(gm), t(gs)
+    L.kr_gumbel_argmax_guided(ptr(ld), V, V, ptr(td), ptr(sd), ptr(cd), ptr(pd), ptr(av), ptr(ai), n_part, B, ptr(d_gm), ptr(d_gs),
+                              mw, 77, 0)
+    av0 = torch.zeros(B, n_part, device=DEV); ai0 = torch.zeros(B, n_part, dtype=torch.int32, device=DEV)
+    L.kr_gumbel_argmax(ptr(ld), V, V, ptr(td), ptr(sd), ptr(cd), ptr(pd), ptr(av0), ptr(ai0), n_part, B, 0)
+    torch.cuda.synchronize()
+    avh, aih = av.cpu().numpy(), ai.cpu().numpy()
+    pick = lambda b: int(aih[b][np.lexsort((aih[b], -avh[b]))[0]])     # best value, ties to the lowest id (the sampler's rule)
+    for b, st in ((0, 0), (1, 1)):
+        sc = O.sample_scores(logits[b], float(temps[b]), int(seeds[b]), int(ctx[b] + 1 - plen[b]))
+        sc = np.where(allow[st], sc, -np.inf)
+        top2 = np.sort(sc)[-2:]
+        assert allow[st][pick(b)]
+        if top2[1] - top2[0] > 1e-4:
+            assert pick(b) == int(np.argmax(sc))
+    for b in (2, 4):
+        np.testing.assert_array_equal(aih[b], ai0.cpu().numpy()[b])
+        np.testing.assert_array_equal(avh[b], av0.cpu().numpy()[b])
+    assert pick(3) == 77 and np.isneginf(avh[3]).all()
+    with pytest.raises(KarantaHipError):
+        L.kr_gumbel_argmax_guided(ptr(ld), V, V, ptr(td), ptr(sd), ptr(cd), ptr(pd), ptr(av), ptr(ai), n_part, B, ptr(d_gm), ptr(d_gs),
+                                  mw, V, 0)
+
+
+@pytest.mark.parametrize("V,n_part,k", [(151936, 64, 5), (5003, 2, 20), (512, 1, 0), (300, 1, 20)])
+def test_logprobs_topk_matches_oracle(L, V, n_part, k):
+    """log-softmax of the chosen token and the k most probable tokens (ids exact, ties to the lowest id; values within
+    fp32 rounding of the float64 oracle), written at the history index ctx - prompt; finished rows record nothing."""
+    rng = np.random.default_rng(V + k)
+    B, HB, H, KS = 4, 6, 5, 20
+    logits = (rng.standard_normal((B, V)) * 4).astype(np.float32)
+    logits[1, 7] = logits[1, 3] = logits[1].max() + 1.0            # an exact tie at the top
+    logits[2] = np.round(logits[2])                                 # many ties further down
+    toks = rng.integers(0, V, B).astype(np.int32)
+    plen = np.asarray([3, 5, 2, 9], np.int32); ctx = np.asarray([3, 8, 6, 10], np.int32)   # history rows 0, 3, 4, (1)
+    fin = np.asarray([0, 0, 0, 1], np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    ld = t(logits)
+    pv = torch.zeros(B, n_part, max(k, 1), device=DEV); pi = torch.zeros(B, n_part, max(k, 1), dtype=torch.int32, device=DEV)
+    ms = torch.zeros(B, n_part, 2, device=DEV)
+    out = torch.full((H, HB, 1 + KS), 7.0, device=DEV); oi = torch.full((H, HB, KS), -3, dtype=torch.int32, device=DEV)
+    slot0 = 1                                                       # rows go to history columns 1..4 of 6
+    d_tok, d_ctx, d_plen, d_fin = t(toks), t(ctx), t(plen), t(fin)
+    L.kr_logprobs_topk(ptr(ld), V, V, k, n_part, ptr(pv), ptr(pi), ptr(ms), ptr(d_tok), ptr(d_ctx), ptr(d_plen), ptr(d_fin),
+                       ptr(out[:, slot0:]), ptr(oi[:, slot0:]), H, HB, KS, B, 0)
+    torch.cuda.synchronize()
+    oh, ih = out.cpu().numpy(), oi.cpu().numpy()
+    touched = np.zeros((H, HB), bool)
+    for b in range(3):
+        h = int(ctx[b] - plen[b])
+        touched[h, slot0 + b] = True
+        lp = O.log_softmax(logits[b])
+        np.testing.assert_allclose(oh[h, slot0 + b, 0], lp[toks[b]], rtol=1e-5, atol=5e-5)
+        ids, vals = O.top_logprobs(logits[b], k)
+        np.testing.assert_array_equal(ih[h, slot0 + b, :k], ids)
+        np.testing.assert_allclose(oh[h, slot0 + b, 1:1 + k], vals, rtol=1e-5, atol=5e-5)
+        assert (oh[h, slot0 + b, 1 + k:] == 7.0).all() and (ih[h, slot0 + b, k:] == -3).all()
+    assert (oh[~touched] == 7.0).all() and (ih[~touched] == -3).all(), "finished rows and other history rows stay untouched"
+    with pytest.raises(KarantaHipError):
+        L.kr_logprobs_topk(ptr(ld), V, V, 21, n_part, ptr(pv), ptr(pi), ptr(ms), ptr(d_tok), ptr(d_ctx), ptr(d_plen), ptr(d_fin),
+                           ptr(out), ptr(oi), H, HB, KS, B, 0)
+    if V > 4096 * 2:
+        with pytest.raises(KarantaHipError):
+            L.kr_logprobs_topk(ptr(ld), V, V, k, 2, ptr(pv), ptr(pi), ptr(ms), ptr(d_tok), ptr(d_ctx), ptr(d_plen), ptr(d_fin),
+                               ptr(out), ptr(oi), H, HB, KS, B, 0)
