@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--profile-every", type=int, default=512, help="one eager decode step with HIP events around the gate/up launch every N steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--guided", action="store_true",
+                    help="every page carries a (permissive) guide: times the masked sampling pass + DFA advance in the decode graph")
+    ap.add_argument("--logprobs", type=int, default=None, help="record top-k log-probabilities every step (0..20)")
     ap.add_argument("--decode-splits", type=int, default=8)
     ap.add_argument("--weights", default="bf16", choices=("bf16", "fp8"),
                     help="fp8: decoder Linears as e4m3fn codes + per-row scales (BASELINE.json config 5); activations stay bf16")
@@ -191,6 +194,15 @@ def main():
     eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(len(p) for p in pvs),
                  max_prompt_tokens=sum(P), decode_splits=args.decode_splits, weight_dtype=args.weights)
     pix_dev = torch.from_numpy(np.concatenate(pvs, 0)).to(dev)
+    if args.guided:
+        # no tokenizer ships with random-init weights: the byte tokens 0..255 carry their byte, the rest are specials;
+        # the pattern allows any text, so the mask / advance kernels do their full per-step work
+        eng.set_vocab([bytes([i]) for i in range(256)])
+        for pg in pages:
+            pg.guide = r"[\s\S]*"
+    if args.logprobs is not None:
+        for pg in pages:
+            pg.logprobs = args.logprobs
 
     # ---------------- weights: rank 0 materialises them, the others receive the arena over RCCL
     t0 = time.perf_counter()
@@ -283,6 +295,8 @@ def main():
                             f"max_pixels={args.max_pixels} (grid {grids[0][1]}x{grids[0][2]}, {n_img_tok[0]} image tokens), "
                             f"prompt P={P[0]} tokens, T_out={T_out} (ignore_eos), random-init weights",
                 "global_batch": world * B, "parallelism": f"dp{world}", "decode": "hipGraph replay" if not args.no_graph else "eager",
+                **({"guided": "every page, pattern [\\s\\S]*"} if args.guided else {}),
+                **({"logprobs": args.logprobs} if args.logprobs is not None else {}),
             },
             "p50_latency_s": round(float(np.median(step_times)), 4),
             "phases_s": {k: round(v, 4) for k, v in phase.items()},

@@ -51,6 +51,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU image front end")
     ap.add_argument("--max-pixels", type=int, default=None)
     ap.add_argument("--greedy", action="store_true", help="ignore request temperatures")
+    ap.add_argument("--max-logprobs", type=int, default=None,
+                    help="record log-probabilities in the decode graph: the largest top_logprobs a request may ask for (0..20)")
     return ap
 
 
@@ -68,6 +70,8 @@ def parse_args(argv: Optional[List[str]] = None):
     if args.tensor_parallel_size != 1 or args.data_parallel_size != 1:
         ap.error("one process serves one GPU: run one server per GPU (HIP_VISIBLE_DEVICES=i), as "
                  "scripts/start_multiple_vllm_servers.sh does; tensor / data parallel sizes must be 1")
+    if args.max_logprobs is not None and not 0 <= args.max_logprobs <= 20:
+        ap.error("--max-logprobs must be in 0..20")
     if not 1 <= args.max_num_seqs <= 32:
         ap.error("--max-num-seqs must be in 1..32 (above 16: models up to hidden_size 2048)")
     args.model_dir = model
@@ -92,7 +96,8 @@ def make_server(args, log=print):
     front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), max_pixels=max_pixels,
                          max_model_len=args.max_model_len, device_images=not args.host_images)
     return LocalServer(eng, front, served_model_name=args.served_model_name, log=log, continuous=not args.static_batching,
-                       max_tokens_cap=min(args.max_tokens_cap, args.max_model_len), honor_temperature=not args.greedy)
+                       max_tokens_cap=min(args.max_tokens_cap, args.max_model_len), honor_temperature=not args.greedy,
+                       max_logprobs=args.max_logprobs)
 
 
 def main(argv: Optional[List[str]] = None, make=make_server) -> int:
