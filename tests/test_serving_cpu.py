@@ -395,3 +395,56 @@ def test_cli_main_serves_until_signalled_and_metrics_endpoint():
         assert box.get("rc") == 0
     finally:
         cli.parse_args = orig
+
+
+class GuidedFakeEngine(FakeEngine):
+    """Has the guided surface (set_vocab) and returns log-probabilities when pages ask."""
+
+    def set_vocab(self, token_bytes):
+        self.vocab = list(token_bytes)
+
+    def generate(self, pages, max_new_tokens, **kw):
+        res = super().generate(pages, max_new_tokens, **kw)
+        self.pages = list(pages)
+        res.logprobs = [None if p.logprobs is None else
+                        {"token": np.asarray([-0.5, -1.5]), "top": np.asarray([[-0.5, -2.0], [-1.5, -1.75]])[:, :p.logprobs],
+                         "top_ids": np.asarray([[ord("O"), ord("x")], [ord("K"), ord("y")]])[:, :p.logprobs]} for p in pages]
+        return res
+
+
+def test_guided_and_logprobs_request_surface():
+    """guided_regex / response_format become a compiled guide on the page (pipeline.py:304-307, vllm_client.py:196);
+    logprobs / top_logprobs come back in the OpenAI shape; bad patterns and servers without the surface answer 400."""
+    eng = GuidedFakeEngine()
+    srv = S.LocalServer(eng, S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None)
+    try:
+        assert len(eng.vocab) == CFG.text.vocab_size and eng.vocab[65] == b"A" and eng.vocab[CFG.eos_token_ids[0]] == b""
+        st, body = srv.chat_completions({"messages": vision_message(), "max_tokens": 9, "guided_regex": r"O[KQ]", "logprobs": True,
+                                         "top_logprobs": 2})
+        assert st == 200 and body["choices"][0]["message"]["content"] == "OK"
+        pg = eng.pages[0]
+        assert pg.guide.fullmatch(b"OQ") and not pg.guide.viable(b"K") and pg.logprobs == 2
+        lp = body["choices"][0]["logprobs"]["content"]
+        assert [i["token"] for i in lp] == ["O", "K"] and lp[0]["logprob"] == -0.5 and lp[1]["bytes"] == [ord("K")]
+        assert [t["token"] for t in lp[1]["top_logprobs"]] == ["K", "y"] and lp[1]["top_logprobs"][1]["logprob"] == -1.75
+        # the same pattern compiles once
+        st, _ = srv.chat_completions({"messages": vision_message(), "max_tokens": 9, "guided_regex": r"O[KQ]"})
+        assert st == 200 and eng.pages[0].guide is pg.guide and eng.pages[0].logprobs is None
+        schema = {"type": "json_schema", "json_schema": {"name": "p", "schema": {"type": "object", "properties": {"a": {"type": "boolean"}},
+                                                                                "required": ["a"]}}}
+        st, body = srv.chat_completions({"messages": vision_message(), "max_tokens": 9, "response_format": schema})
+        assert st == 200 and "logprobs" not in body["choices"][0]
+        assert eng.pages[0].guide.fullmatch(b'{"a": true}') and not eng.pages[0].guide.fullmatch(b'{"a": 1}')
+        for bad in ({"guided_regex": r"(?<=a)b"}, {"guided_regex": ""}, {"response_format": {"type": "json_schema"}},
+                    {"logprobs": True, "top_logprobs": 21}, {"logprobs": True, "top_logprobs": "many"}):
+            st, body = srv.chat_completions({"messages": vision_message(), "max_tokens": 9, **bad})
+            assert st == 400, bad
+    finally:
+        srv.close()
+    plain = S.LocalServer(FakeEngine(), S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None)
+    try:
+        st, body = plain.chat_completions({"messages": vision_message(), "max_tokens": 9, "guided_regex": "OK"})
+        assert st == 400 and "not available" in body["error"]["message"]
+        assert plain.chat_completions({"messages": vision_message(), "max_tokens": 9})[0] == 200
+    finally:
+        plain.close()
