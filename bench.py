@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--t-out", type=int, default=1024)
     ap.add_argument("--page", type=int, default=1024, help="synthetic page side in pixels")
+    ap.add_argument("--page-width", type=int, default=None, help="page width when not square (config 5: --page 2200 --page-width 1700)")
     ap.add_argument("--max-pixels", type=int, default=1003520, help="grid A (transformers class default)")
     ap.add_argument("--profile-every", type=int, default=512, help="one eager decode step with HIP events around the gate/up launch every N steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,7 +182,7 @@ def main():
     t0 = time.perf_counter()
     pvs, grids = [], []
     for i in range(B):
-        pv, g = IP.image_to_patches(IP.synthetic_page(rank * B + i, args.page, args.page), max_pixels=args.max_pixels)
+        pv, g = IP.image_to_patches(IP.synthetic_page(rank * B + i, args.page, args.page_width or args.page), max_pixels=args.max_pixels)
         pvs.append(pv)
         grids.append(g)
     n_img_tok = [g[1] * g[2] // 4 for g in grids]
@@ -291,7 +292,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": f"{cfg.name} {'bf16' if args.weights == 'bf16' else 'fp8-weight / bf16-activation'} greedy, batch={B} synthetic {args.page}x{args.page} pages per GPU, "
+                "workload": f"{cfg.name} {'bf16' if args.weights == 'bf16' else 'fp8-weight / bf16-activation'} greedy, batch={B} synthetic {args.page_width or args.page}x{args.page} pages per GPU, "
                             f"max_pixels={args.max_pixels} (grid {grids[0][1]}x{grids[0][2]}, {n_img_tok[0]} image tokens), "
                             f"prompt P={P[0]} tokens, T_out={T_out} (ignore_eos), random-init weights",
                 "global_batch": world * B, "parallelism": f"dp{world}", "decode": "hipGraph replay" if not args.no_graph else "eager",
