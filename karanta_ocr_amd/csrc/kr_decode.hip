@@ -1188,8 +1188,8 @@ int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
 // =====================================================================================
 // decode attention with in-launch merge
 // =====================================================================================
-// grid = (n_split, kv_heads, batch); 4 waves; wave `part` = split*4 + wave walks 64-key blocks
-// part, part + 4*n_split, ...   Layouts as in kr_attention.hip (K rows, V^T 64-key blocks).
+// grid = (n_split, kv_heads, batch); WAVES waves; wave `part` = split*WAVES + wave walks 32-key units
+// part, part + WAVES*n_split, ...   Layouts as in kr_attention.hip (K rows, V^T 64-key blocks).
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
                                                                   const kr_bf16* __restrict__ vtcache,
@@ -1206,7 +1206,6 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
     const int group = heads / kv_heads;
     const int n_part = n_split * WAVES, part = split * WAVES + wave;
     const int ctx = ctx_len[b] + 1;
-    const int nb = (ctx + 63) >> 6;
 
     const int g = fr < group ? fr : 0;
     // MFMA k-step i pairs K[key][32i + 8fg + j] with Q[g][32i + 8fg + j]: per load instruction the
@@ -1223,22 +1222,30 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f, l_run = 0.f;
-    for (int blk = part; blk < nb; blk += n_part) {
+    // unit = 32 keys (half a V^T block); wave `part` takes units part, part + n_part, ...: at the contexts of a page
+    // (1.4k .. 2.4k keys = 44 .. 76 units) 64 parts leave one unit — one memory round trip — per wave; a wave with
+    // more requests unit u + n_part before it computes unit u
+    const int nu = (ctx + 31) >> 5;
+    bf16x8 kf[2][4], vf[DT], kf2[2][4], vf2[DT];
+    auto load_unit = [&](int u, bf16x8 (&kk)[2][4], bf16x8 (&vv)[DT]) {
+        const int key0 = u * 32;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int key0 = blk * 64 + hf * 32;
-            if (key0 >= ctx) break;
-            bf16x8 kf[2][4];
+        for (int kt = 0; kt < 2; ++kt) {
+            const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 8;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 8;
+            for (int i = 0; i < 4; ++i) kk[kt][i] = ld8_nt(kp + i * 32);
+        }
+        const kr_bf16* vp = vc + (int64_t)(u >> 1) * (HD * 64) + (u & 1) * 32 + fg * 8;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) kf[kt][i] = ld8_nt(kp + i * 32);
-            }
-            bf16x8 vf[DT];
-            const kr_bf16* vp = vc + (int64_t)blk * (HD * 64) + hf * 32 + fg * 8;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vf[dt] = ld8_nt(vp + (dt * 16 + fr) * 64);
+        for (int dt = 0; dt < DT; ++dt) vv[dt] = ld8_nt(vp + (dt * 16 + fr) * 64);
+    };
+    int u = part;
+    if (u < nu) load_unit(u, kf, vf);
+    while (u < nu) {
+        const int un = u + n_part;
+        if (un < nu) load_unit(un, kf2, vf2);
+        {
+            const int key0 = u * 32;
             f32x4 s[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
@@ -1279,6 +1286,15 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[dt], 0, 0, 0);
             }
         }
+        if (un < nu) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kf[kt][i] = kf2[kt][i];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = vf2[dt];
+        }
+        u = un;
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -1766,8 +1782,10 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
     KR_CHECK_ARG(!out || n_split <= 16, "kr_attn_decode_fused: the in-launch merge takes at most 16 splits");
     KR_CHECK_ARG(!out || n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
-    // few splits: 8 waves per workgroup keep the same number of waves streaming the cache
-    if (n_split <= 4)
+    // 8 waves per workgroup: n_split * 8 parts, so that a wave rarely has more than one 32-key unit to fetch
+    // (KARANTA_ATTN_WAVES=4: the 4-wave variant for n_split > 4, kept for A/B measurements)
+    static const bool waves4 = [] { const char* e = getenv("KARANTA_ATTN_WAVES"); return e && e[0] == '4'; }();
+    if (n_split <= 4 || !waves4)
         attn_decode2_kernel<8><<<dim3(n_split, kv_heads, batch), 512, 0, kr_hs(s)>>>(
             q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
     else
