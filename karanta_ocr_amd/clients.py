@@ -221,3 +221,56 @@ client_manager = VLLMClientManager()
 
 def get_vllm_client_for_worker(worker_name: str, **kwargs) -> VLLMClient:
     return client_manager.get_client_from_worker_name(worker_name, **kwargs)
+
+
+# ----------------------------------------------------------------------------- llm_clients surface
+# The reference's data tooling talks to models through ``BaseLLM.completion(prompt, structured_object)``
+# (/root/reference/karanta/llm_clients/base.py:62-72), an async method in the concrete clients returning
+# ``ModelCompletion(generation, model)`` objects (base.py:11-32; litellm_client.py:38-45: ``temperature`` default 1.0,
+# ``max_tokens`` default 512, ``structured_object`` sent as ``response_format``, the content ``json.loads``-ed when a
+# structure was asked for, ``ValueError("Error decoding response: ...")`` otherwise).  Same shape here, served by the
+# MI355X engine; a structured request is enforced on the device (guided decoding), so the decode step cannot fail on
+# a complete answer.
+import asyncio  # noqa: E402
+from dataclasses import asdict, dataclass  # noqa: E402
+
+
+@dataclass
+class ModelCompletion:
+    generation: Any          # dict / list when a structure was requested, else the text
+    model: str
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self), ensure_ascii=False)
+
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+
+class KarantaLLM:
+    """``BaseLLM``-shaped client of one engine server (in-process LocalServer registered for the port, or HTTP)."""
+
+    def __init__(self, model_name: str = "karantaocr", port: int = 8000, host: str = "localhost", **client_kwargs):
+        self.model_name = model_name
+        self._client = VLLMClient(port=port, host=host, **client_kwargs)
+
+    async def completion(self, prompt, structured_object: Optional[Any] = None, **generation_kwargs: Any) -> List[ModelCompletion]:
+        assert isinstance(prompt, list) and prompt, "Prompt must be a non-empty list"
+        assert isinstance(prompt[0], (dict, list)), "Prompt must be a list of dictionaries or a list of lists of dictionaries"
+        temperature = generation_kwargs.get("temperature", 1.0)
+        max_tokens = generation_kwargs.get("max_tokens", 512)
+        conversations = prompt if isinstance(prompt[0], list) else [prompt]
+        loop = asyncio.get_running_loop()
+
+        def one(messages):
+            r = self._client.generate(messages, model=self.model_name, max_tokens=max_tokens, temperature=temperature,
+                                      response_format=structured_object)
+            if not structured_object:
+                return ModelCompletion(generation=r["text"], model=self.model_name)
+            try:
+                return ModelCompletion(generation=json.loads(r["text"]), model=self.model_name)
+            except json.JSONDecodeError:
+                raise ValueError(f"Error decoding response: {r['text']}")
+
+        # the conversations of a batch go out together: the server batches them (continuous or static)
+        return list(await asyncio.gather(*[loop.run_in_executor(None, one, m) for m in conversations]))

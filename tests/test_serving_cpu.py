@@ -448,3 +448,36 @@ def test_guided_and_logprobs_request_surface():
         assert plain.chat_completions({"messages": vision_message(), "max_tokens": 9})[0] == 200
     finally:
         plain.close()
+
+
+def test_llm_clients_completion_surface():
+    """BaseLLM.completion shape (karanta/llm_clients/base.py:62-72, litellm_client.py:38-45): one conversation or a list
+    of them, text or json.loads-ed structure, ModelCompletion(generation, model)."""
+    import asyncio
+    from karanta_ocr_amd.clients import KarantaLLM, ModelCompletion
+
+    class JsonEngine(GuidedFakeEngine):
+        def generate(self, pages, max_new_tokens, **kw):
+            res = super().generate(pages, max_new_tokens, **kw)
+            for i, p in enumerate(pages):
+                if p.guide is not None:
+                    res.tokens[i] = np.asarray(list(b'{"a": true}') + [CFG.eos_token_ids[0]], np.int64)
+            return res
+
+    eng = JsonEngine()
+    srv = S.LocalServer(eng, S.ChatFrontend(CFG, S.ByteTokenizer(CFG)), log=lambda *_: None)
+    S.register_local_server(8771, srv)
+    try:
+        llm = KarantaLLM(port=8771)
+        out = asyncio.run(llm.completion(vision_message()))
+        assert out == [ModelCompletion(generation="OK", model="karantaocr")] and eng.calls[-1][1] == 512
+        fmt = {"type": "json_schema", "json_schema": {"name": "p", "schema": {"type": "object", "properties": {"a": {"type": "boolean"}},
+                                                                             "required": ["a"]}}}
+        out = asyncio.run(llm.completion([vision_message(), vision_message("again")], fmt, max_tokens=40, temperature=0.0))
+        assert [o.generation for o in out] == [{"a": True}, {"a": True}] and json.loads(out[0].to_json())["model"] == "karantaocr"
+        assert out[0].to_dict() == {"generation": {"a": True}, "model": "karantaocr"}
+        with pytest.raises(AssertionError):
+            asyncio.run(llm.completion("not a list"))
+    finally:
+        S.unregister_local_server(8771)
+        srv.close()
