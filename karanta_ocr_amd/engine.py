@@ -558,7 +558,7 @@ class Engine:
         grids, off = [], 0
         with torch.cuda.stream(self.stream):
             for im, h, w, rh, rw in metas:
-                src = torch.from_numpy(im).to(dev)
+                src = torch.from_numpy(im if im.flags.writeable else im.copy()).to(dev)   # PIL-backed arrays are read-only
                 key = (h, w, rh, rw)
                 tabs = self._resample_cache.get(key)
                 if tabs is None:
