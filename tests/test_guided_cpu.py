@@ -181,3 +181,36 @@ def test_gpt2_byte_table_roundtrip():
     dec = G._gpt2_byte_decoder()
     assert len(dec) == 256 and sorted(dec.values()) == list(range(256))
     assert dec["Ġ"] == 0x20 and dec["Ċ"] == 0x0A and dec["a"] == ord("a")
+
+
+def test_vocab_bytes_of_a_byte_level_bpe_tokenizer():
+    """vocab_bytes_from_hf on a real `tokenizers` byte-level BPE (the kind Qwen2-VL ships): every ordinary token's bytes
+    are what decoding that token alone yields, concatenated pieces give back the text, added special tokens are b""."""
+    tokenizers = pytest.importorskip("tokenizers")
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    tk = Tokenizer(models.BPE())
+    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tk.decoder = decoders.ByteLevel()
+    corpus = ["---\nprimary_language: en\nis_table: False\n", "Habari ya dunia — naïve café ✓ 12345", "{\"a\": true, \"b\": [1, 2]}"] * 20
+    tk.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=400, special_tokens=["<|im_start|>", "<|im_end|>"],
+                                                      initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    V = tk.get_vocab_size()
+    voc = G.vocab_bytes_from_hf(tk, V + 3)                      # a model's vocab may be padded past the tokenizer's
+    assert len(voc) == V + 3 and voc[V:] == [b"", b"", b""]
+    assert voc[tk.token_to_id("<|im_start|>")] == b"" and voc[tk.token_to_id("<|im_end|>")] == b""
+    assert sorted(b for b in voc if len(b) == 1) == [bytes([i]) for i in range(256)], "all 256 single bytes are tokens"
+    for text in corpus[:3] + ["naïve ✓\n\n"]:
+        ids = tk.encode(text, add_special_tokens=False).ids
+        assert b"".join(voc[i] for i in ids) == text.encode("utf-8")
+    multi = [i for i in range(V) if len(voc[i]) > 1]
+    assert multi, "training produced merges"
+    for i in multi[:50]:
+        try:
+            piece = voc[i].decode("utf-8")
+        except UnicodeDecodeError:
+            continue                                            # a token may end inside a UTF-8 character
+        assert tk.decode([i]) == piece
+    # and a guide over that vocabulary: the oracle's rule allows exactly the tokens that keep "---\n" viable
+    g = G.compile_regex(r"---\n[a-z_]+: (?:en|null)")
+    ok = O.guide_token_mask(g.trans, g.accept, g.start, voc, [])
+    assert ok.any() and all(b"---\n".startswith(voc[i]) or voc[i].startswith(b"---\n") for i in np.flatnonzero(ok))
