@@ -74,9 +74,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(k x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale / fmas / fixup: ~10
+// instructions per element in every GEMM epilogue); the result is rounded to bf16 right after
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (bid % 8) get a
 // contiguous chunk of the work list, so neighbouring tiles share that XCD's L2.

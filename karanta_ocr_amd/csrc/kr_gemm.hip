@@ -53,6 +53,149 @@ __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_
     }
 }
 
+// Epilogue shared by the GEMM kernels: lane (fr, fg) of a wave holds, per (nt, mt) accumulator, 4 consecutive n
+// (n_base + nt*16 + fg*4 ..) of one m (m_base + mt*16 + fr).
+// wlds != nullptr: the wave's own MT*16 x 128-byte LDS scratch (the staging buffers are free by now).  The bf16
+// results go through it and leave as 16-byte-per-lane, row-contiguous stores (whole 128-byte lines per 8 lanes)
+// instead of 8-byte pieces of 16 different rows per instruction: the direct form wrote C at ~2 TB/s with one
+// workgroup per CU and nothing to overlap it with (vit fc1: 233 of 642 us).  Values are identical either way.
+// LDSEPI / HAS_R are compile-time: runtime selects inside the unrolled (mt, nt) loops turn into a branch per accumulator.
+template <int EPI, int NT, int MT, bool LDSEPI, bool HAS_R>
+__device__ __forceinline__ void gemm_epilogue_impl(f32x4 (&acc)[NT][MT], const kr_bf16* __restrict__ bias,
+                                                   const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc,
+                                                   int64_t M, int N, int64_t m_base, int n_base, int fr, int fg, char* wlds_) {
+    constexpr bool HALF = EPI == KR_EPI_SILU_MUL8;       // output is N / 2 wide: 64-byte scratch rows
+    constexpr int ROWB = HALF ? 64 : 128;
+    char* const wlds = wlds_;
+    // scratch chunk (16 B) c of row r sits at c ^ swz(r): 2-way conflicts on the 8-byte writes, none on the reads
+    auto swz = [](int r) { return HALF ? ((r >> 1) & 3) : (r & 7); };
+    // ---------------- epilogue: lane holds 4 consecutive n for one m
+    // Operand loads are unconditional (clamped addresses) and hoisted: a guarded load inside the (mt, nt) loops costs
+    // one dependent L2 round trip per accumulator — 32 of them in a row were 8-13 us per tile.
+    if (EPI == KR_EPI_SILU_MUL8) {
+        // gate/up interleaved in groups of 8 rows: a 16-row tile holds gate rows in lane groups 0,1
+        // and the matching up rows in lane groups 2,3 (lane ^ 32)
+        bf16x4 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {   // bias rows are interleaved like the weight rows: every lane adds its own
+            const int n = min(n_base + nt * 16, N - 16);
+            bv[nt] = bias ? *reinterpret_cast<const bf16x4*>(bias + n + fg * 4) : bf16x4{};
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + mt * 16 + fr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n_base + nt * 16;
+                float g[4], u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = acc[nt][mt][j] + bf2f(bv[nt][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(g[j], 32, 64);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(g[j]) * u[j]);
+                if (LDSEPI) {
+                    const int r = mt * 16 + fr;
+                    if (fg < 2) *reinterpret_cast<bf16x4*>(wlds + r * ROWB + ((nt ^ swz(r)) << 4) + (fg & 1) * 8) = o;
+                } else if (fg < 2 && n < N && m < M) {
+                    *reinterpret_cast<bf16x4*>(C + m * ldc + (n >> 1) + fg * 4) = o;
+                }
+            }
+        }
+    } else if (EPI == KR_EPI_SILU_MUL) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + mt * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                const int n = n_base + pr * 32 + fg * 4;  // gate row index in W'
+                if (n >= N) continue;
+                const int oc = ((n_base) >> 1) + pr * 16 + fg * 4;
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[2 * pr][mt][j]) * acc[2 * pr + 1][mt][j]);
+                *reinterpret_cast<bf16x4*>(C + m * ldc + oc) = o;
+            }
+        }
+    } else {
+        bf16x4 bv[NT];
+        int ncl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            ncl[nt] = min(n_base + nt * 16 + fg * 4, N - 4);
+            bv[nt] = bias ? *reinterpret_cast<const bf16x4*>(bias + ncl[nt]) : bf16x4{};
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + mt * 16 + fr;
+            const int64_t mc = m < M ? m : M - 1;
+            bf16x4 rv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) rv[nt] = HAS_R ? *reinterpret_cast<const bf16x4*>(R + mc * ldr + ncl[nt]) : bf16x4{};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n_base + nt * 16 + fg * 4;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][j];
+                if (bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[nt][j]);
+                }
+                if (EPI == KR_EPI_QUICK_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = act_quick_gelu(v[j]);
+                } else if (EPI == KR_EPI_GELU_ERF) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = act_gelu_erf(v[j]);
+                }
+                if (HAS_R) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[nt][j]);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+                if (LDSEPI) {
+                    const int r = mt * 16 + fr;
+                    *reinterpret_cast<bf16x4*>(wlds + r * ROWB + (((nt * 2 + (fg >> 1)) ^ swz(r)) << 4) + (fg & 1) * 8) = o;
+                } else if (m < M && n < N) {
+                    *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
+                }
+            }
+        }
+    }
+    if (LDSEPI) {  // same wave, in-order LDS: its reads see its writes
+        constexpr int LPR = ROWB / 16, RPI = 64 / LPR;   // lanes per row, rows per instruction
+        const int lane = fg * 16 + fr;
+        const int n_out = HALF ? (n_base >> 1) : n_base, n_lim = HALF ? (N >> 1) : N;
+#pragma unroll
+        for (int it = 0; it < MT * 16 / RPI; ++it) {
+            const int r = it * RPI + lane / LPR, c = lane % LPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + r * ROWB + ((c ^ swz(r)) << 4));
+            const int64_t m = m_base + r;
+            const int n = n_out + c * 8;
+            if (m < M && n < n_lim) *reinterpret_cast<u32x4*>(C + m * ldc + n) = v;
+        }
+    }
+}
+
+// LDSEPI kernels (the 256x256 tiles) are only launched with ldc % 8 == 0 and a 16-byte aligned C.
+template <int EPI, int NT, int MT, bool LDSEPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NT][MT], const kr_bf16* __restrict__ bias,
+                                              const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc,
+                                              int64_t M, int N, int64_t m_base, int n_base, int fr, int fg, char* wlds) {
+    constexpr bool L = LDSEPI && EPI != KR_EPI_SILU_MUL;
+    if constexpr (EPI == KR_EPI_SILU_MUL || EPI == KR_EPI_SILU_MUL8) {
+        gemm_epilogue_impl<EPI, NT, MT, L, false>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
+    } else {
+        if (R) gemm_epilogue_impl<EPI, NT, MT, L, true>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
+        else gemm_epilogue_impl<EPI, NT, MT, L, false>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
+    }
+}
+
 template <int EPI, bool WPACK, typename G>
 __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
                                                    const kr_bf16* __restrict__ W, const kr_bf16* __restrict__ bias,
@@ -113,77 +256,152 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
         __syncthreads();
     }
 
-    // ---------------- epilogue: lane holds 4 consecutive n for one m
+    gemm_epilogue<EPI, NT, MT, G::BM == 256>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * WTM, n0 + wc * WTN, fr, fg,
+                                             smem + wave * (WTM * 128));
+}
+
+// -------------------------------------------------------------------------------------
+// gemm_pipe_kernel: the 256x256 tile with the staging kept in flight ACROSS barriers.
+// gemm_kernel drains its LDS-DMA (vmcnt(0)) at every K-step's barrier: one 64 KiB stage is requested at the top of
+// a step and must have landed at its end, so the bytes in flight saw-tooth between 64 KiB and nothing and the MFMA
+// pipe waits on memory latency (the "two barriers per K-step" ceiling, ~900 TFLOP/s measured here).  This kernel:
+//   * K-tiles of 32 (one MFMA k-step), FOUR LDS buffers of [A 256x32][W 256x32] = 32 KiB each (128 KiB);
+//   * two phases per K-tile, each {fragment ds_reads + 2 LDS-DMA per wave -> barrier -> 16 MFMA -> barrier}:
+//     phase 0 reads W (4 n-tiles) + A rows 0..63 of the wave and stages the W half-tiles of K-tile k+3,
+//     phase 1 reads A rows 64..127 and stages the A half-tiles of K-tile k+3;
+//   * a COUNTED wait once per K-tile (vmcnt(8): K-tile k+1 landed, k+2 and k+3 still in flight), never 0 in the
+//     steady state; raw s_barrier (a __syncthreads would drain the DMA);
+//   * the two wave rows (wr = 0 / 1) run one barrier apart, so one half of the workgroup issues loads while the
+//     other half is in its MFMA burst (s_setprio(1) around the burst).
+// Hazards (DMA is ordered for a ds_read only by the issuing wave's vmcnt + a barrier the reader has passed):
+//   RAW  K-tile k+1 is waited for in phase (k,1) before its first barrier and first read in phase (k+1,0);
+//   WAR  buffer (k+3)&3 = (k-1)&3: its W rows were last read in phase (k-1,0), its A rows in phase (k-1,1);
+//        they are restaged in phases (k,0) / (k,1), two phases (four barriers) later — one barrier of stagger fits.
+// LDS image: 64-byte rows (32 k); chunk c (8 k) of row r sits at slot c ^ (((r >> 3) & 1) << 1): the four 16-lane
+// groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) then touch 16 distinct 16-byte slots of the 256-byte bank row.
+constexpr int PK = 32, PBUF = 2 * 256 * PK * 2, PSTAGES = 4;
+
+template <bool PACKED>
+__device__ __forceinline__ void stage_rows32(const kr_bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_total, int k0,
+                                             char* lds_op, int lane, int wave) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int64_t m = m0 + wr * WTM + mt * 16 + fr;
-        if (EPI != KR_EPI_SILU_MUL8 && m >= M) continue;  // (SILU_MUL8 shuffles across lanes: no early exit)
-        if (EPI == KR_EPI_SILU_MUL8) {
-            // gate/up interleaved in groups of 8 rows: a 16-row tile holds gate rows in lane groups 0,1
-            // and the matching up rows in lane groups 2,3 (lane ^ 32)
+    for (int h = 0; h < 2; ++h) {  // the two 128-row halves: each wave fills one 16-row block (1 KiB) of each
+        const int r = h * 128 + wave * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ (((lane >> 5) & 1) << 1);  // source chunk for this LDS slot
+        int64_t gr = row0 + r;
+        gr = gr < rows_total ? gr : rows_total - 1;
+        const kr_bf16* src = PACKED ? g + ((((gr >> 4) * (ld >> 5) + (k0 >> 5)) * 4 + c) * 16 + (gr & 15)) * 8
+                                    : g + gr * ld + k0 + c * 8;
+        char* dst = lds_op + (h * 128 + wave * 16) * 64;  // wave-uniform; the hardware adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+template <int EPI, bool WPACK>
+__global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restrict__ A, int64_t lda, const kr_bf16* __restrict__ W,
+                                                        const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R,
+                                                        int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+                                                        int tiles_n, unsigned nwg) {
+    constexpr int NT = 4, MT = 8, A_BYTES = 256 * PK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (a second one makes hipcc drain the DMA)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned wg = xcd_remap(blockIdx.x, nwg);
+    const int64_t m0 = (int64_t)(wg / tiles_n) * 256;
+    const int n0 = (int)(wg % tiles_n) * 256;
+
+    f32x4 acc[NT][MT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = n0 + wc * WTN + nt * 16;
-                float g[4], u[4];
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = acc[nt][mt][j];
-                if (bias && n < N) {  // bias rows are interleaved like the weight rows: every lane adds its own
-                    const bf16x4 bv = *reinterpret_cast<const bf16x4*>(bias + n + fg * 4);
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / PK;
+    // fragment read offsets inside a buffer (row * 64 + swizzled chunk * 16)
+    const int sw = ((fg ^ (((fr >> 3) & 1) << 1)) << 4);
+    const int a_off = (wr * 128 + fr) * 64 + sw;
+    const int w_off = A_BYTES + (wc * 64 + fr) * 64 + sw;
+
+    // ---- prologue: K-tiles 0..2 requested, K-tile 0 landed and visible
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) g[j] += bf2f(bv[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(g[j], 32, 64);
-                if (fg < 2 && n < N && m < M) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(g[j]) * u[j]);
-                    *reinterpret_cast<bf16x4*>(C + m * ldc + (n >> 1) + fg * 4) = o;
-                }
-            }
-        } else if (EPI == KR_EPI_SILU_MUL) {
-#pragma unroll
-            for (int pr = 0; pr < NT / 2; ++pr) {
-                const int n = n0 + wc * WTN + pr * 32 + fg * 4;  // gate row index in W'
-                if (n >= N) continue;
-                const int oc = ((n0 + wc * WTN) >> 1) + pr * 16 + fg * 4;
-                bf16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[2 * pr][mt][j]) * acc[2 * pr + 1][mt][j]);
-                *reinterpret_cast<bf16x4*>(C + m * ldc + oc) = o;
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = n0 + wc * WTN + nt * 16 + fg * 4;
-                if (n >= N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][j];
-                if (bias) {
-                    const bf16x4 bv = *reinterpret_cast<const bf16x4*>(bias + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
-                }
-                if (EPI == KR_EPI_QUICK_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = act_quick_gelu(v[j]);
-                } else if (EPI == KR_EPI_GELU_ERF) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = act_gelu_erf(v[j]);
-                }
-                if (R) {
-                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * ldr + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-                *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
-            }
+    for (int t = 0; t < 3; ++t) {
+        if (t < nk) {
+            char* buf = smem + t * PBUF;
+            stage_rows32<WPACK>(W, K, n0, N, t * PK, buf + A_BYTES, lane, wave);
+            stage_rows32<false>(A, lda, m0, M, t * PK, buf, lane, wave);
         }
     }
+    if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
+
+    bf16x8 wb[NT], xa[4];
+    for (int k = 0; k < nk; ++k) {
+        const char* cur = smem + (k & 3) * PBUF;
+        char* nxt = smem + ((k + 3) & 3) * PBUF;
+        const bool more = k + 3 < nk;
+        // ---------------- phase 0: W fragments + A rows 0..63
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wb[t] = *reinterpret_cast<const bf16x8*>(cur + w_off + t * 16 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + t * 16 * 64);
+        if (more) stage_rows32<WPACK>(W, K, n0, N, (k + 3) * PK, nxt + A_BYTES, lane, wave);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 1: A rows 64..127; the counted wait of this K-tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + (4 + t) * 16 * 64);
+        if (more) stage_rows32<false>(A, lda, m0, M, (k + 3) * PK, nxt, lane, wave);
+        // K-tile k+1 must have landed (this wave's share); k+2 and k+3 may stay in flight
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (k + 3 == nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][4 + mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier
+    gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, fr, fg, smem + wave * (128 * 128));
+}
+
+template <int EPI, bool WPACK>
+int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
+    constexpr int LDS = PSTAGES * PBUF;
+    const int64_t tiles_m = (M + 255) / 256;
+    const int tiles_n = (N + 255) / 256;
+    const int64_t nwg = tiles_m * tiles_n;
+    KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
+    static bool attr_set = false;
+    if (!attr_set) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    gemm_pipe_kernel<EPI, WPACK><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
 }
 
 template <int EPI, bool WPACK, typename G>
@@ -206,22 +424,25 @@ int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
     return KR_OK;
 }
 
-// 0 = automatic, 128 / 256 = forced (KARANTA_GEMM_TILE, tuning sweeps)
+// 0 = automatic; 128 / 256 / 512 (= pipelined 256x256) forced by KARANTA_GEMM_TILE (tests, tuning sweeps)
 inline int gemm_tile_choice(int64_t M, int N, int K) {
     const char* env = getenv("KARANTA_GEMM_TILE");  // read per call: the tests flip it between launches
     const int forced = env ? atoi(env) : 0;
-    if (forced == 128 || forced == 256) return forced;
-    // the 256x256 tile needs enough workgroups to fill 256 CUs a few times over, no N padding, and either several
-    // N tiles or a long K (measured on the ViT / prefill shapes, gemm_microbench.py: +10-20 % there, -3 % on
-    // N = 1280, K = 1280)
+    if (forced == 128 || forced == 256 || forced == 512) return forced;   // 512: the pipelined 256x256 kernel
+    // the 256x256 tile (pipelined kernel) wants about one workgroup per CU or more and no N padding; measured on the
+    // ViT / prefill / merger shapes (gemm_microbench.py) it beats the 128x128 tile by 10-40 % from 234 workgroups up
     const int64_t wgs = ((M + 255) / 256) * ((N + 255) / 256);
-    return (wgs >= 512 && N % 256 == 0 && (N >= 2048 || K >= 4096)) ? 256 : 128;
+    return (wgs >= 192 && N % 256 == 0) ? 512 : 128;
 }
 
 template <int EPI, bool WPACK>
 int launch_gemm2(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
                  kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
-    if (gemm_tile_choice(M, N, K) == 256) return launch_gemm3<EPI, WPACK, G256>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
+    int tile = gemm_tile_choice(M, N, K);
+    // the 256x256 kernels store C through LDS as 16-byte pieces
+    if ((ldc & 7) != 0 || (reinterpret_cast<uintptr_t>(C) & 15) != 0) tile = 128;
+    if (tile == 512) return launch_gemm_pipe<EPI, WPACK>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
+    if (tile == 256) return launch_gemm3<EPI, WPACK, G256>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
     return launch_gemm3<EPI, WPACK, G128>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, s);
 }
 

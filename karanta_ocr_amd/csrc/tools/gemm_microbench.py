@@ -25,7 +25,7 @@ def run(name, M, N, K, epi, packed, reps=5):
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
     out = {}
-    for tile in (128, 256):
+    for tile in (128, 256, 512):
         os.environ["KARANTA_GEMM_TILE"] = str(tile)
         call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
         call(); torch.cuda.synchronize()
@@ -36,10 +36,13 @@ def run(name, M, N, K, epi, packed, reps=5):
         out[tile] = best
     fl = 2.0 * M * N * K
     print(f"{name:16s} M={M:6d} N={N:6d} K={K:5d}: 128-tile {out[128]*1e3:8.1f} us {fl/out[128]/1e9:7.0f} TF/s | "
-          f"256-tile {out[256]*1e3:8.1f} us {fl/out[256]/1e9:7.0f} TF/s", flush=True)
+          f"256-tile {out[256]*1e3:8.1f} us {fl/out[256]/1e9:7.0f} TF/s | pipelined 256 {out[512]*1e3:8.1f} us {fl/out[512]/1e9:7.0f} TF/s", flush=True)
 
 
 if __name__ == "__main__":
     torch.zeros(1, device=dev)
+    if len(sys.argv) > 1 and sys.argv[1] == "square":   # the shapes GEMM kernels are usually quoted on
+        SHAPES = [("4096^3", 4096, 4096, 4096, EPI_NONE, 0), ("8192^3", 8192, 8192, 8192, EPI_NONE, 0),
+                  ("16384x4096x4096", 16384, 4096, 4096, EPI_NONE, 0)]
     for sh in SHAPES:
         run(*sh)

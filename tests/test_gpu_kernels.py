@@ -209,17 +209,18 @@ def test_gemm_exact_on_integers(L, M, N, K):
     np.testing.assert_array_equal(got, ref_linear(A, W))
 
 
-@pytest.fixture
-def tile256():
-    """Force the 256x256 / 8-wave GEMM geometry (chosen automatically only for very large M)."""
+@pytest.fixture(params=["256", "512"])
+def tile256(request):
+    """Force the 256x256 / 8-wave GEMM geometries (chosen automatically only for very large M): 256 = two barriers per
+    K-step, 512 = the pipelined kernel (four K = 32 LDS buffers, counted vmcnt, staggered wave rows)."""
     import os
-    os.environ["KARANTA_GEMM_TILE"] = "256"
+    os.environ["KARANTA_GEMM_TILE"] = request.param
     yield
     os.environ.pop("KARANTA_GEMM_TILE", None)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 16, 64), (255, 256, 64), (256, 256, 128), (257, 272, 192), (700, 528, 64),
-                                   (513, 1280, 1216)])
+                                   (513, 1280, 1216), (300, 256, 256), (1024, 512, 320), (2049, 768, 1280)])
 def test_gemm_256_tile_exact_on_integers(L, tile256, M, N, K):
     rng = np.random.default_rng(M * 1000 + N + K + 1)
     A, W = ints(rng, M, K), ints(rng, N, K)
