@@ -104,6 +104,15 @@ int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
                  const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc,
                  int64_t M, int N, int K, int epilogue, int w_packed, kr_stream s);
 
+/* kr_gemm_bf16 with weight-only fp8 (BASELINE.json config 5: "fp8 weights, bf16 activations"; SURVEY.md §8(b2)
+ * kr_gemm_fp8): W as OCP e4m3fn codes in the decode layout [N/16][K/64][4][16][16] (weights.pack_w16x64_fp8) with one
+ * f32 scale per output row, C = epi(A (scale * W)^T + bias) (+ residual).  The codes are converted to bf16 on the way
+ * from LDS to the MFMA, accumulation is fp32, the scale multiplies the accumulator.  Epilogues KR_EPI_NONE and
+ * KR_EPI_SILU_MUL8 (the decoder's prefill linears).  K % 64 == 0, N % 16 == 0, ldc % 8 == 0, C 16-byte aligned. */
+int kr_gemm_fp8(const kr_bf16* A, int64_t lda, const uint8_t* w_packed_fp8, const float* w_scale, const kr_bf16* bias,
+                const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                kr_stream s);
+
 /* Decode-time Linear for M <= 16 rows (one row per live sequence): the weight matrix is streamed
  * exactly once from HBM (this is the HBM-roofline kernel of the decode loop).
  * Same semantics and epilogues as kr_gemm_bf16.  If out_f32 != NULL the result is written there

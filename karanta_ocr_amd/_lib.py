@@ -63,6 +63,7 @@ SIGNATURES = {
     "kr_linear_decode_narrow_fp8": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                     i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
     "kr_fp8_to_bf16": [c_p, c_p, i64, c_p],
+    "kr_gemm_fp8": [c_p, i64, c_p, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
     "kr_gumbel_argmax": [c_p, i64, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p],
     "kr_gumbel_argmax_guided": [c_p, i64, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p, c_p, i32, i32, c_p],
     "kr_guide_build_masks": [c_p, c_p, i32, c_p, c_p, i32, c_p, i32, c_p, i32, c_p],

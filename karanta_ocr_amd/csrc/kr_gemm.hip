@@ -298,12 +298,40 @@ __device__ __forceinline__ void stage_rows32(const kr_bf16* __restrict__ g, int6
     }
 }
 
-template <int EPI, bool WPACK>
+// fp8 weights in the decode layout [N/16][K/64][4 k-groups][16 rows][16 B] (weights.pack_w16x64_fp8): the 32 k of a
+// K-tile are half a 1 KiB block (k-groups 2j, 2j+1 = 512 contiguous bytes), so a 256-row W tile is 8 KiB and ONE
+// LDS-DMA per wave (lanes 0-31: row block 2*wave, lanes 32-63: row block 2*wave + 1).
+__device__ __forceinline__ void stage_w8_rows32(const uint8_t* __restrict__ g, int K, int n0, int N, int k0, char* lds_op, int lane,
+                                                int wave) {
+    int rb = (n0 >> 4) + 2 * wave + (lane >> 5);
+    rb = min(rb, (N >> 4) - 1);
+    const uint8_t* src = g + ((int64_t)rb * (K >> 6) + (k0 >> 6)) * 1024 + ((k0 & 32) ? 512 : 0) + (lane & 31) * 16;
+    char* dst = lds_op + wave * 1024;  // wave-uniform; the hardware adds lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// 8 e4m3 codes (two 32-bit words) -> 8 bf16, natural order (cvt_scalef32_pk_bf16_fp8 converts one 16-bit half of a
+// word; its 2 x bf16 result is moved as a 32-bit word: element-wise extraction is mis-lowered by this compiler)
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(u32x2 q) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        o[2 * i + 0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)q[i], 1.0f, false));
+        o[2 * i + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)q[i], 1.0f, true));
+    }
+    return __builtin_bit_cast(bf16x8, o);
+}
+
+// W8: W is fp8 codes + one f32 scale per output row (applied to the accumulators before the epilogue); activations,
+// accumulation and outputs as in the bf16 kernel.
+template <int EPI, bool WPACK, bool W8>
 __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restrict__ A, int64_t lda, const kr_bf16* __restrict__ W,
                                                         const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R,
                                                         int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                                                        int tiles_n, unsigned nwg) {
+                                                        int tiles_n, unsigned nwg, const float* __restrict__ w_scale) {
     constexpr int NT = 4, MT = 8, A_BYTES = 256 * PK * 2;
+    const uint8_t* W8p = reinterpret_cast<const uint8_t*>(W);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (a second one makes hipcc drain the DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -323,19 +351,33 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     // fragment read offsets inside a buffer (row * 64 + swizzled chunk * 16)
     const int sw = ((fg ^ (((fr >> 3) & 1) << 1)) << 4);
     const int a_off = (wr * 128 + fr) * 64 + sw;
-    const int w_off = A_BYTES + (wc * 64 + fr) * 64 + sw;
+    const int w_off = W8 ? A_BYTES + wc * 4 * 512 + (fg >> 1) * 256 + fr * 16 + (fg & 1) * 8   // 8 codes of row fr
+                         : A_BYTES + (wc * 64 + fr) * 64 + sw;
+    auto stage_w = [&](int k0, char* buf) {
+        if constexpr (W8) stage_w8_rows32(W8p, K, n0, N, k0, buf + A_BYTES, lane, wave);
+        else stage_rows32<WPACK>(W, K, n0, N, k0, buf + A_BYTES, lane, wave);
+    };
 
     // ---- prologue: K-tiles 0..2 requested, K-tile 0 landed and visible
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         if (t < nk) {
             char* buf = smem + t * PBUF;
-            stage_rows32<WPACK>(W, K, n0, N, t * PK, buf + A_BYTES, lane, wave);
+            stage_w(t * PK, buf);
             stage_rows32<false>(A, lda, m0, M, t * PK, buf, lane, wave);
         }
     }
-    if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // loads per K-tile and wave: 2 (A) + 2 (bf16 W) or 1 (fp8 W); the counted waits leave two / one K-tile in flight
+    auto wait_two = [] {
+        if constexpr (W8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    auto wait_one = [] {
+        if constexpr (W8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    if (nk >= 3) wait_two();
+    else if (nk == 2) wait_one();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
@@ -346,14 +388,24 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
         char* nxt = smem + ((k + 3) & 3) * PBUF;
         const bool more = k + 3 < nk;
         // ---------------- phase 0: W fragments + A rows 0..63
+        u32x2 wq[NT];
+        if constexpr (W8) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wb[t] = *reinterpret_cast<const bf16x8*>(cur + w_off + t * 16 * 64);
+            for (int t = 0; t < NT; ++t) wq[t] = *reinterpret_cast<const u32x2*>(cur + w_off + t * 512);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wb[t] = *reinterpret_cast<const bf16x8*>(cur + w_off + t * 16 * 64);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + t * 16 * 64);
-        if (more) stage_rows32<WPACK>(W, K, n0, N, (k + 3) * PK, nxt + A_BYTES, lane, wave);
+        if (more) stage_w((k + 3) * PK, nxt);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (W8) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wb[t] = fp8x8_to_bf16(wq[t]);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -367,8 +419,8 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
         for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + (4 + t) * 16 * 64);
         if (more) stage_rows32<false>(A, lda, m0, M, (k + 3) * PK, nxt, lane, wave);
         // K-tile k+1 must have landed (this wave's share); k+2 and k+3 may stay in flight
-        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (k + 3 == nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (more) wait_two();
+        else if (k + 3 == nk) wait_one();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -382,12 +434,22 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier
+    if constexpr (W8) {  // row scales of the quantised weights: lane holds 4 consecutive n per accumulator
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(w_scale + min(n0 + wc * 64 + nt * 16 + fg * 4, N - 4));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][mt][j] *= sc[j];
+        }
+    }
     gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, fr, fg, smem + wave * (128 * 128));
 }
 
-template <int EPI, bool WPACK>
+template <int EPI, bool WPACK, bool W8 = false>
 int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
-                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s, const float* w_scale = nullptr) {
     constexpr int LDS = PSTAGES * PBUF;
     const int64_t tiles_m = (M + 255) / 256;
     const int tiles_n = (N + 255) / 256;
@@ -395,11 +457,12 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK>),
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    gemm_pipe_kernel<EPI, WPACK><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg);
+    gemm_pipe_kernel<EPI, WPACK, W8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
+                                                                            (unsigned)nwg, w_scale);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
@@ -486,6 +549,32 @@ extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, con
             return launch_gemm<KR_EPI_SILU_MUL8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         default:
             kr_set_error("kr_gemm_bf16: unknown epilogue %d", epilogue);
+            return KR_ERR_ARG;
+    }
+}
+
+extern "C" int kr_gemm_fp8(const kr_bf16* A, int64_t lda, const uint8_t* w_packed_fp8, const float* w_scale, const kr_bf16* bias,
+                           const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                           kr_stream s) {
+    KR_CHECK_ARG(A && w_packed_fp8 && w_scale && C, "kr_gemm_fp8: null pointer");
+    KR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "kr_gemm_fp8: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+    KR_CHECK_ARG(K % 64 == 0 && N % 16 == 0, "kr_gemm_fp8: K=%d must be a multiple of 64, N=%d of 16", K, N);
+    KR_CHECK_ARG(lda >= K && (lda & 7) == 0, "kr_gemm_fp8: lda=%lld", (long long)lda);
+    KR_CHECK_ARG((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (residual == nullptr || (ldr & 3) == 0),
+                 "kr_gemm_fp8: C must be 16-byte aligned with ldc %% 8 == 0 (ldr %% 4 == 0)");
+    KR_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)w_packed_fp8 & 15) == 0 && ((uintptr_t)w_scale & 15) == 0,
+                 "kr_gemm_fp8: pointer alignment");
+    if (M == 0) return KR_OK;
+    const kr_bf16* Wp = reinterpret_cast<const kr_bf16*>(w_packed_fp8);
+    switch (epilogue) {
+        case KR_EPI_NONE:
+            KR_CHECK_ARG(ldc >= N, "kr_gemm_fp8: ldc < N");
+            return launch_gemm_pipe<KR_EPI_NONE, true, true>(A, lda, Wp, bias, residual, ldr, C, ldc, M, N, K, s, w_scale);
+        case KR_EPI_SILU_MUL8:
+            KR_CHECK_ARG(ldc >= N / 2 && !residual, "kr_gemm_fp8: SILU_MUL8 takes no residual");
+            return launch_gemm_pipe<KR_EPI_SILU_MUL8, true, true>(A, lda, Wp, bias, residual, ldr, C, ldc, M, N, K, s, w_scale);
+        default:
+            kr_set_error("kr_gemm_fp8: epilogue %d (NONE and SILU_MUL8 only: the decoder's prefill linears)", epilogue);
             return KR_ERR_ARG;
     }
 }

@@ -295,6 +295,8 @@ class Engine:
             raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
         self.w = DeviceWeights(cfg, self.device, weight_dtype)
         self.fp8 = weight_dtype == "fp8"
+        # fp8 engine: prefill GEMMs read the fp8 codes (kr_gemm_fp8); KARANTA_FP8_PREFILL=0: their dequantised bf16 copy
+        self.fp8_prefill_gemm = os.environ.get("KARANTA_FP8_PREFILL", "1") == "1"
         self._graphs: Dict[Tuple[int, bool], int] = {}
         self._prof_on = False
         self._prof_events: List[Tuple[C.c_void_p, C.c_void_p]] = []
@@ -418,8 +420,13 @@ class Engine:
         self.w.load(weights)
 
     # ------------------------------------------------------------------ small launch helpers
-    def _gemm(self, A, W, C_, M, bias=None, res=None, epi=EPI_NONE, packed=False):
+    def _gemm(self, A, W, C_, M, bias=None, res=None, epi=EPI_NONE, packed=False, w8=None, w_scale=None):
         N, K = W.shape
+        if w8 is not None and self.fp8_prefill_gemm:
+            # fp8 engine: the prefill streams the SAME e4m3 codes + row scales the decode kernels read (kr_gemm_fp8)
+            self.L.kr_gemm_fp8(ptr(A), A.stride(0), ptr(w8), ptr(w_scale), ptr(bias), ptr(res),
+                               res.stride(0) if res is not None else 0, ptr(C_), C_.stride(0), M, N, K, epi, self.s)
+            return
         self.L.kr_gemm_bf16(ptr(A), A.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
                             ptr(C_), C_.stride(0), M, N, K, epi, 1 if packed else 0, self.s)
 
@@ -866,7 +873,7 @@ class Engine:
             for i in range(t.num_layers):
                 p = f"llm.{i}."
                 L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln1.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
-                self._gemm(self.p_h, w.view(p + "qkv.w"), self.p_qkv, M, bias=w.view(p + "qkv.b"), packed=True)
+                self._gemm(self.p_h, w.view(p + "qkv.w"), self.p_qkv, M, bias=w.view(p + "qkv.b"), packed=True, **self._w8kw(p + "qkv.w"))
                 kc, vc = self.kcache[i], self.vtcache[i]
                 L.kr_qkv_prep(ptr(self.p_qkv), t.qkv_dim, 0, t.q_dim, t.q_dim + t.kv_dim, ptr(self.p_cos), ptr(self.p_sin),
                               ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
@@ -875,10 +882,10 @@ class Engine:
                 L.kr_attn_varlen(ptr(self.p_q), ptr(kc), ptr(vc), ptr(self.p_o), ptr(qblk), ptr(qlen),
                                  plan.qblk.shape[0], self.p_q.shape[1], H, KVH, hd, k_head_stride, vt_head_stride,
                                  hd ** -0.5, 1, s)
-                self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x, packed=True)
+                self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x, packed=True, **self._w8kw(p + "o.w"))
                 L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln2.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
-                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL8, packed=True)
-                self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x, packed=True)
+                self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL8, packed=True, **self._w8kw(p + "gate_up.w"))
+                self._gemm(self.p_act, w.view(p + "down.w"), self.p_x, M, res=self.p_x, packed=True, **self._w8kw(p + "down.w"))
             # last position of every sequence -> final norm (fused) -> lm_head -> greedy token
             if whole_batch:
                 L.kr_embed_scatter(ptr(self.d_last), ptr(self.p_x), 0, ptr(self.d_x), B, d, s)

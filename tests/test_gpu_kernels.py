@@ -1195,6 +1195,54 @@ def test_linear_narrow_fp8_plain_and_slabs(L, M, N, K, waves, ksplit):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (255, 256, 64), (257, 272, 192), (700, 528, 320), (2049, 768, 1280), (300, 1536, 8960)])
+def test_gemm_fp8_exact_on_small_integers(L, M, N, K):
+    """kr_gemm_fp8 (weight-only fp8 prefill GEMM): integer weights exact in e4m3, power-of-two row scales, integer
+    activations -> exact result; catches a wrong half-block / k-group / row-block address, a wrong conversion order, a
+    missing scale, a miscounted vmcnt (stale LDS tile)."""
+    from karanta_ocr_amd import weights as W
+    rng = np.random.default_rng(M + N + K + 9)
+    A = ints(rng, M, K)
+    Wi = rng.integers(-8, 9, size=(N, K)).astype(np.float32)
+    if K > 256:
+        Wi[:, 200:] = 0
+        Wi[::5, K - 40:] = rng.integers(-1, 2, size=(len(Wi[::5]), 40))
+    Wi[:, 0] = 448
+    A[:, 0] = 0                                                        # (keeps the sums small: column 0 only fixes the scales)
+    scale_pow = (2.0 ** rng.integers(-2, 3, size=N)).astype(np.float32)
+    q, sc = W.quantize_fp8_rows(Wi * scale_pow[:, None])
+    np.testing.assert_array_equal(W.fp8_e4m3_to_f32(q) * sc[:, None], Wi * scale_pow[:, None])
+    Ad, qd, sd = dev_bf16(A), torch.from_numpy(W.pack_w16x64_fp8(q)).to(DEV), torch.from_numpy(sc).to(DEV)
+    ldc = (N + 7) // 8 * 8 + 8
+    C_ = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.kr_gemm_fp8(ptr(Ad), K, ptr(qd), ptr(sd), 0, 0, 0, ptr(C_), ldc, M, N, K, EPI_NONE, 0)
+    got = host(C_)
+    np.testing.assert_array_equal(got[:, :N], bf16_round(ref_linear(A, Wi * scale_pow[:, None])))   # exact sums, one rounding
+    assert (got[:, N:] == 7.0).all(), "columns beyond N untouched"
+
+
+@pytest.mark.parametrize("epi", [EPI_NONE, EPI_SILU_MUL8])
+def test_gemm_fp8_matches_dequantised_reference(L, epi):
+    rng = np.random.default_rng(91 + epi)
+    from karanta_ocr_amd import weights as W
+    M, N, K = 1394, 2048 if epi == EPI_NONE else 1024, 1536
+    A, Wf = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    bias = rnd(rng, N, scale=0.1)
+    res = rnd(rng, M, N) if epi == EPI_NONE else None
+    q, sc, ref = fp8_ref(A, Wf, bias, res, epi)
+    Ad, qd, sd, bd = dev_bf16(A), torch.from_numpy(W.pack_w16x64_fp8(q)).to(DEV), torch.from_numpy(sc).to(DEV), dev_bf16(bias)
+    nc = N // 2 if epi == EPI_SILU_MUL8 else N
+    C_ = torch.zeros(M, nc, dtype=torch.bfloat16, device=DEV)
+    rd = dev_bf16(res) if res is not None else None
+    L.kr_gemm_fp8(ptr(Ad), K, ptr(qd), ptr(sd), ptr(bd), ptr(rd) if rd is not None else 0, N if rd is not None else 0, ptr(C_), nc, M, N, K,
+                  epi, 0)
+    assert_close_bf16(host(C_), ref, what=f"gemm fp8 epi {epi}")
+    with pytest.raises(KarantaHipError):
+        L.kr_gemm_fp8(ptr(Ad), K, ptr(qd), ptr(sd), 0, 0, 0, ptr(C_), nc, M, N, K, EPI_QUICK_GELU, 0)
+    with pytest.raises(KarantaHipError):
+        L.kr_gemm_fp8(ptr(Ad), K, ptr(qd), ptr(sd), 0, 0, 0, ptr(C_[:, 4:]), nc, M, N, K, epi, 0)    # C not 16-byte aligned
+
+
 def test_gumbel_argmax_matches_oracle_noise(L):
     """kr_gumbel_argmax partials against the oracle's sample_scores: same counter-based noise (integer hash bit-exact,
     the two logs within float rounding), T = 0 rows untouched, ties to the lowest index, sampled frequencies follow
