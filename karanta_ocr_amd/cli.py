@@ -51,6 +51,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU image front end")
     ap.add_argument("--max-pixels", type=int, default=None)
     ap.add_argument("--greedy", action="store_true", help="ignore request temperatures")
+    ap.add_argument("--quantization", default=None, choices=("fp8",),
+                    help="decoder Linears as fp8 codes + row scales (vLLM's flag; implied by a checkpoint with a quantization_config)")
     ap.add_argument("--max-logprobs", type=int, default=None,
                     help="record log-probabilities in the decode graph: the largest top_logprobs a request may ask for (0..20)")
     return ap
@@ -80,6 +82,18 @@ def parse_args(argv: Optional[List[str]] = None):
     return args
 
 
+def _checkpoint_is_fp8(model_dir: str) -> bool:
+    """config.json carries a quantization_config for fp8 weights (compressed-tensors / fp8 methods)."""
+    import json
+    try:
+        with open(os.path.join(model_dir, "config.json")) as f:
+            q = json.load(f).get("quantization_config") or {}
+    except OSError:
+        return False
+    blob = json.dumps(q).lower()
+    return bool(q) and ("fp8" in blob or "float8" in blob or '"num_bits": 8' in blob and '"type": "float"' in blob)
+
+
 def make_server(args, log=print):
     """Engine + front end + LocalServer from parsed arguments (weights and tokenizer from args.model_dir)."""
     from . import image_processing as IP
@@ -88,10 +102,12 @@ def make_server(args, log=print):
     from .weights import load_checkpoint
 
     cfg, tensors = load_checkpoint(args.model_dir)
+    weight_dtype = "fp8" if (args.quantization == "fp8" or _checkpoint_is_fp8(args.model_dir)) else "bf16"
     max_pixels = args.max_pixels or IP.MAX_PIXELS_CLASS_DEFAULT
     patches_per_page = max_pixels // (cfg.vision.patch_size ** 2) + 64
     eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 63) // 64 * 64,
-                 max_patches=args.max_num_seqs * patches_per_page, max_prompt_tokens=args.max_num_seqs * args.max_model_len // 2)
+                 max_patches=args.max_num_seqs * patches_per_page, max_prompt_tokens=args.max_num_seqs * args.max_model_len // 2,
+                 weight_dtype=weight_dtype)
     eng.load_weights(tensors)
     front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), max_pixels=max_pixels,
                          max_model_len=args.max_model_len, device_images=not args.host_images)

@@ -168,6 +168,7 @@ def load_checkpoint(model_dir: str) -> tuple:
     files = sorted(f for f in os.listdir(model_dir) if f.endswith(".safetensors"))
     if not files:
         raise FileNotFoundError(f"no *.safetensors under {model_dir}")
+    raw: Dict[str, np.ndarray] = {}
     for fn in files:
         with safe_open(os.path.join(model_dir, fn), framework="pt") as sf:
             for k in sf.keys():
@@ -175,8 +176,25 @@ def load_checkpoint(model_dir: str) -> tuple:
                 if t.dtype == torch.bfloat16:
                     arr = t.view(torch.int16).numpy().view(np.uint16)
                 else:
-                    arr = t.float().numpy()
-                tensors[canonical_name(k)] = arr
+                    arr = t.float().numpy()          # float8_e4m3fn codes come back as their (unscaled) values
+                raw[k] = arr
+    # fp8 checkpoints (compressed-tensors, e.g. the reference's allenai/olmOCR-7B-0725-FP8, karanta/constants.py:23):
+    # `<linear>.weight` holds e4m3 values and `<linear>.weight_scale` one scale per output channel ([N, 1]) or per
+    # tensor.  They are dequantised here; Engine(weight_dtype="fp8") re-derives codes + row scales (identical codes when
+    # the checkpoint used the full e4m3 range per row).  Activation scales of static schemes are not used.
+    for k in [k for k in raw if k.endswith(".weight_scale") or k.endswith(".weight_scale_inv")]:
+        base = k[: k.rindex(".")] + ".weight"
+        sc = as_f32(raw.pop(k)).reshape(-1)
+        if base not in raw:
+            continue
+        w = as_f32(raw[base])
+        if sc.size not in (1, w.shape[0]):
+            raise ValueError(f"{k}: {sc.size} scales for a weight of shape {w.shape} (per-tensor or per-output-channel only)")
+        raw[base] = w * (sc.reshape(-1, 1) if sc.size > 1 else sc[0])
+    for k in [k for k in raw if k.endswith(".input_scale")]:
+        raw.pop(k)
+    for k, arr in raw.items():
+        tensors[canonical_name(k)] = arr
     return cfg, tensors
 
 

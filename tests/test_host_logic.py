@@ -257,3 +257,63 @@ def test_fp8_e4m3_codec_and_packing():
     np.testing.assert_array_equal(W.unpack_w16x64_fp8(W.pack_w16x64_fp8(q)), q)
     p = W.pack_w16x64_fp8(q).reshape(2, 2, 4, 16, 16)                    # [tile][chunk][g][r][16]
     np.testing.assert_array_equal(p[1, 1, 2, 5], q[16 + 5, 64 + 32:64 + 48])
+
+
+def test_load_checkpoint_bf16_and_fp8_compressed_tensors(tmp_path):
+    """weights.load_checkpoint on a directory shaped like a hub snapshot: bf16 tensors come back bit-exact; an fp8
+    checkpoint in the compressed-tensors layout (e4m3 `weight` + per-channel or per-tensor `weight_scale`, the shape of
+    the reference's allenai/olmOCR-7B-0725-FP8, karanta/constants.py:23) comes back dequantised, and re-quantising it the
+    engine's way reproduces the checkpoint's codes."""
+    import json
+    torch = pytest.importorskip("torch")
+    st = pytest.importorskip("safetensors.torch")
+    from karanta_ocr_amd import weights as W
+    from karanta_ocr_amd.config import TINY
+    cfg = TINY
+    w = W.random_weights(cfg, 3)
+    hf_cfg = {"model_type": "qwen2_vl", "tie_word_embeddings": False, "eos_token_id": list(cfg.eos_token_ids),
+              "image_token_id": cfg.image_token_id, "video_token_id": cfg.video_token_id,
+              "vision_start_token_id": cfg.vision_start_token_id, "vision_end_token_id": cfg.vision_end_token_id,
+              "text_config": {"hidden_size": cfg.text.hidden_size, "intermediate_size": cfg.text.intermediate_size,
+                              "num_hidden_layers": cfg.text.num_layers, "num_attention_heads": cfg.text.num_heads,
+                              "num_key_value_heads": cfg.text.num_kv_heads, "vocab_size": cfg.text.vocab_size,
+                              "rms_norm_eps": cfg.text.rms_norm_eps,
+                              "rope_parameters": {"rope_theta": cfg.text.rope_theta, "mrope_section": list(cfg.text.mrope_section)}},
+              "vision_config": {"depth": cfg.vision.depth, "embed_dim": cfg.vision.embed_dim, "num_heads": cfg.vision.num_heads,
+                                "hidden_size": cfg.vision.hidden_size, "mlp_ratio": cfg.vision.mlp_ratio}}
+    quantised = {}
+    tensors = {}
+    for name, arr in w.items():
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        is_dec_linear = ".language_model.layers." in name and name.endswith("_proj.weight")
+        if is_dec_linear:
+            codes, sc = W.quantize_fp8_rows(arr)
+            per_tensor = name.endswith("o_proj.weight")                    # one layer kind with a single scale
+            if per_tensor:
+                s1 = np.float32(np.abs(arr).max() / 448.0)
+                codes = W.f32_to_fp8_e4m3(arr / s1)
+                sc = np.full(1, s1, np.float32)
+            tensors[name] = torch.from_numpy(codes.copy()).view(torch.float8_e4m3fn)
+            tensors[name[:-len("weight")] + "weight_scale"] = torch.from_numpy(sc.reshape(-1, 1) if not per_tensor else sc)
+            quantised[name] = (codes, sc, per_tensor)
+        else:
+            tensors[name] = t.to(torch.bfloat16)
+    d = tmp_path / "tiny-fp8"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(hf_cfg))
+    st.save_file(tensors, str(d / "model.safetensors"))
+    cfg2, got = W.load_checkpoint(str(d))
+    assert cfg2.text == cfg.text and cfg2.vision.depth == cfg.vision.depth and cfg2.eos_token_ids == cfg.eos_token_ids
+    assert set(got) == set(w), "scale tensors are folded in, nothing else is added or lost"
+    for name, arr in w.items():
+        if name in quantised:
+            codes, sc, per_tensor = quantised[name]
+            want = W.fp8_e4m3_to_f32(codes) * (sc[0] if per_tensor else sc.reshape(-1, 1))
+            np.testing.assert_array_equal(got[name], want.astype(np.float32))
+            if not per_tensor:                                          # the engine's quantiser finds the same codes again
+                c2, s2 = W.quantize_fp8_rows(got[name])
+                np.testing.assert_array_equal(c2, codes)
+                np.testing.assert_allclose(s2, sc.reshape(-1), rtol=1e-6)
+        else:
+            assert got[name].dtype == np.uint16                          # bf16 bit patterns
+            np.testing.assert_array_equal(W.from_bf16_bits(got[name]), arr)
