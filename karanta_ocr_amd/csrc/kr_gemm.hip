@@ -1,15 +1,18 @@
 // Dense linears on the MI355X matrix cores.
 //
-//  gemm_kernel : C[M,N] = epi(A[M,K] W[N,K]^T + bias) (+R)   M large (ViT, merger, decoder prefill)
-//                128x128x64 block tile, 4 waves (2x2, 64x64 each) or 256x256x64, 8 waves (2x4, 128x64 each),
-//                v_mfma_f32_16x16x32_bf16,
-//                both operands K-contiguous, staged HBM->LDS with 16-byte LDS-DMA
-//                (global_load_lds_dwordx4) into an XOR-swizzled image (swizzle applied on the
-//                per-lane SOURCE address, linear LDS destination), double buffered.
-//                MFMA-bound; roofline = 2.5 PFLOP/s dense bf16.
-//  gemv_kernel : same contract for M <= 16 (decode).  Weights go HBM -> VGPR exactly once with
-//                non-temporal 16-byte loads, 8+ loads in flight per wave; x (<= 16 rows) is staged
-//                (optionally RMS-normalised) in LDS.  HBM-bound; roofline = 8 TB/s.
+//  gemm_kernel      : C[M,N] = epi(A[M,K] W[N,K]^T + bias) (+R)   M large (ViT, merger, decoder prefill)
+//                     128x128x64 block tile, 4 waves (2x2, 64x64 each) — small / ragged M, 2-3 workgroups per CU —
+//                     or 256x256x64, 8 waves (kept for A/B runs); v_mfma_f32_16x16x32_bf16, both operands
+//                     K-contiguous, staged HBM->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) into an
+//                     XOR-swizzled image (swizzle on the per-lane SOURCE address, linear LDS destination), double
+//                     buffered, one drained barrier pair per K-step.
+//  gemm_pipe_kernel : the 256x256 tile for every GEMM with >= 192 tiles: four K = 32 LDS buffers, counted vmcnt
+//                     (staging in flight across barriers), staggered wave rows; bf16 W (row-major or decode layout)
+//                     or fp8 W codes + row scales (kr_gemm_fp8).  Epilogue through LDS: full-line stores.
+//                     MFMA-bound; roofline = 2.5 PFLOP/s dense bf16 (the chip clocks near 1.5 GHz at this duty).
+//  gemv_kernel      : same contract for M <= 16 (decode).  Weights go HBM -> VGPR exactly once with
+//                     non-temporal 16-byte loads, 8+ loads in flight per wave; x (<= 16 rows) is staged
+//                     (optionally RMS-normalised) in LDS.  HBM-bound; roofline = 8 TB/s.
 #include "kr_common.h"
 
 // =====================================================================================
