@@ -774,16 +774,10 @@ class Engine:
                 self.L.kr_graph_destroy(g)
             self._graphs.clear()
 
-    def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int,
-                slots: Optional[Sequence[int]] = None, defer_activation: bool = False):
-        """embed+scatter, M-RoPE, 28 x decoder layer over the flattened prompts (causal varlen
-        attention writing the KV cache), last-token logits -> first greedy token.
-        Leaves the decode state (d_x, d_ctx, d_delta, history row 0) ready.  Returns prompt lengths.
-        ``slots`` (slot scheduler): the cache / state slots the pages go to; only those slots' state is
-        touched, the other sequences keep decoding from where they are.  ``defer_activation`` (overlapped
-        admission): only the layers run here (they fill the slots' KV rows); the slot state writes and the first
-        sampling step are returned as a record for `_activate` to apply on the decode stream."""
-        cfg, t, L, s, w, dev = self.cfg, self.cfg.text, self.L, self.s, self.w, self.device
+    def _prefill_prepare(self, pages: Sequence[PageRequest], n_image_tokens_total: int, slots: Optional[Sequence[int]] = None):
+        """Host side of `prefill` (numpy only: token sources, M-RoPE tables of the prompt and of every decode position,
+        the varlen attention plan).  `generate` runs it while the ViT launches are still executing."""
+        cfg, t = self.cfg, self.cfg.text
         B = len(pages)
         whole_batch = slots is None
         slots = list(range(B)) if whole_batch else [int(j) for j in slots]
@@ -821,18 +815,35 @@ class Engine:
                                   f"features: {n_image_tokens_total}")
         plan = POS.prefill_attn_plan(lens, slots, t.num_kv_heads, self.s_max)
         last_rows = (np.cumsum(lens) - 1).astype(np.int32)
+        # rotary table of every decode position of every sequence: pos = P + k + delta (all three
+        # M-RoPE axes equal for generated text, TF:1124-1136), cos/sin rounded to bf16 (TF:169)
+        kk = np.arange(self.max_new, dtype=np.int64)
+        cs = np.zeros((B, self.max_new, t.head_dim), np.float32)
+        for b in range(B):
+            p1 = lens[b] + kk + int(deltas[b])
+            c_, s_ = POS.mrope_tables(np.stack([p1, p1, p1]), t.head_dim, t.rope_theta, t.mrope_section)
+            cs[b, :, : t.head_dim // 2], cs[b, :, t.head_dim // 2:] = c_[:, : t.head_dim // 2], s_[:, : t.head_dim // 2]
+        return {"B": B, "whole_batch": whole_batch, "slots": slots, "lens": lens, "M": M, "src": src, "cos": cos, "sin": sin,
+                "deltas": deltas, "plan": plan, "last_rows": last_rows, "cs": cs, "n_img": n_image_tokens_total}
+
+    def prefill(self, pages: Sequence[PageRequest], n_image_tokens_total: int,
+                slots: Optional[Sequence[int]] = None, defer_activation: bool = False, prep=None):
+        """embed+scatter, M-RoPE, 28 x decoder layer over the flattened prompts (causal varlen
+        attention writing the KV cache), last-token logits -> first greedy token.
+        Leaves the decode state (d_x, d_ctx, d_delta, history row 0) ready.  Returns prompt lengths.
+        ``slots`` (slot scheduler): the cache / state slots the pages go to; only those slots' state is
+        touched, the other sequences keep decoding from where they are.  ``defer_activation`` (overlapped
+        admission): only the layers run here (they fill the slots' KV rows); the slot state writes and the first
+        sampling step are returned as a record for `_activate` to apply on the decode stream."""
+        cfg, t, L, s, w, dev = self.cfg, self.cfg.text, self.L, self.s, self.w, self.device
+        if prep is None or prep["n_img"] != n_image_tokens_total:
+            prep = self._prefill_prepare(pages, n_image_tokens_total, slots)
+        B, whole_batch, slots, lens, M = prep["B"], prep["whole_batch"], prep["slots"], prep["lens"], prep["M"]
+        src, cos, sin, deltas, plan, last_rows, cs = (prep[k] for k in ("src", "cos", "sin", "deltas", "plan", "last_rows", "cs"))
         with torch.cuda.stream(self.stream):
             self._h2d(self.p_src, src)
             self._h2d(self.p_cos, cos)
             self._h2d(self.p_sin, sin)
-            # rotary table of every decode position of every sequence: pos = P + k + delta (all three
-            # M-RoPE axes equal for generated text, TF:1124-1136), cos/sin rounded to bf16 (TF:169)
-            kk = np.arange(self.max_new, dtype=np.int64)
-            cs = np.zeros((B, self.max_new, t.head_dim), np.float32)
-            for b in range(B):
-                p1 = lens[b] + kk + int(deltas[b])
-                c_, s_ = POS.mrope_tables(np.stack([p1, p1, p1]), t.head_dim, t.rope_theta, t.mrope_section)
-                cs[b, :, : t.head_dim // 2], cs[b, :, t.head_dim // 2:] = c_[:, : t.head_dim // 2], s_[:, : t.head_dim // 2]
             temps = np.asarray([float(getattr(p, "temperature", 0.0) or 0.0) for p in pages], np.float32)
             seeds = np.asarray([int(getattr(p, "seed", 0) or 0) & 0xFFFFFFFF for p in pages], np.uint32).view(np.int32)
             if temps.max(initial=0.0) > 0 and not self._sampling:
@@ -1168,9 +1179,10 @@ class Engine:
         pix = self._pixels_for(pages, pixel_values_device)
         if pix is not None:
             n_img_tok = self.vit_forward(pix, grids).shape[0]
+        prep = self._prefill_prepare(pages, n_img_tok)   # host work of the prefill, under the ViT launches still running
         self.stream.synchronize()
         t1 = time.perf_counter()
-        lens = self.prefill(pages, n_img_tok)
+        lens = self.prefill(pages, n_img_tok, prep=prep)
         logits_steps = []
         if return_logits:
             self.stream.synchronize()
@@ -1268,7 +1280,8 @@ class Engine:
         grids = [g for p in pages for g in p.grids]
         pix = self._pixels_for(pages, None)
         n_img_tok = self.vit_forward(pix, grids).shape[0] if pix is not None else 0
-        return self.prefill(pages, n_img_tok, slots=slots)
+        prep = self._prefill_prepare(pages, n_img_tok, slots)   # host tables while the ViT launches execute
+        return self.prefill(pages, n_img_tok, slots=slots, prep=prep)
 
     # Overlapped admission (optional, SlotScheduler(overlap=True); measured: no gain on the ragged serving benchmark —
     # 6.56 vs 6.57 pages/s, with or without a high-priority decode stream: the ViT / prefill launches fill all 256 CUs
