@@ -156,6 +156,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal of the N > 1 control flow) ranks share devices
+    local_rank %= max(1, torch.cuda.device_count())
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")

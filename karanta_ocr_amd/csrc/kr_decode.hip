@@ -964,6 +964,21 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
         bias1 = *reinterpret_cast<const bf16x4*>(a.bias + tile[NT - 1] * 16 + fg * 4);
     }
 
+    // bias / residual of the PLAIN epilogue: requested here, behind the weight ring, instead of after the cross-wave
+    // reduction (where the residual was one more dependent memory round trip at the end of every o_proj launch).
+    // Unconditional loads (a valid dummy address when the operand is absent): no branch, no early wait.
+    bf16x4 res_pre[MT][NT], bias_pre[NT];
+    if (EPI == DEPI_PLAIN) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = min(tile[t], ntiles - 1) * 16 + fg * 4;
+            bias_pre[t] = *reinterpret_cast<const bf16x4*>(a.bias ? a.bias + n : a.x);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                res_pre[mt][t] = *reinterpret_cast<const bf16x4*>(a.residual ? a.residual + (int64_t)rb[mt] * a.ldr + n : a.x);
+        }
+    }
+
     // ---- 5. K loop of this wave
     const char* xl[MT];
 #pragma unroll
@@ -1063,12 +1078,13 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = sum[t][j];
             if (a.bias) {
-                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n);
+                const bf16x4 bv = EPI == DEPI_PLAIN ? bias_pre[t] : *reinterpret_cast<const bf16x4*>(a.bias + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += bf2f(bv[j]);
             }
             if (a.residual) {
-                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
+                const bf16x4 rv = EPI == DEPI_PLAIN ? res_pre[mt][t]
+                                                    : *reinterpret_cast<const bf16x4*>(a.residual + (int64_t)b * a.ldr + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
             }
