@@ -214,3 +214,32 @@ def test_vocab_bytes_of_a_byte_level_bpe_tokenizer():
     g = G.compile_regex(r"---\n[a-z_]+: (?:en|null)")
     ok = O.guide_token_mask(g.trans, g.accept, g.start, voc, [])
     assert ok.any() and all(b"---\n".startswith(voc[i]) or voc[i].startswith(b"---\n") for i in np.flatnonzero(ok))
+
+
+def test_random_patterns_against_python_re():
+    """Seeded fuzz: 600 random patterns from a small grammar (classes, escapes, groups, alternation, every quantifier
+    form, a non-ASCII literal) — the DFA and `re.fullmatch` (ASCII classes) agree on random strings."""
+    rng = random.Random(20251031)
+    atoms = ["a", "b", "c", "0", r"\d", r"\w", r"\s", ".", "[ab]", "[^a]", "[a-c0]", r"\.", "é", r"[\s\S]", r"\n", "-", "[-a]", r"[a\]]"]
+
+    def gen(depth=0):
+        r = rng.random()
+        if depth > 3 or r < 0.35:
+            return rng.choice(atoms)
+        if r < 0.55:
+            return gen(depth + 1) + gen(depth + 1)
+        if r < 0.7:
+            return "(?:" + gen(depth + 1) + "|" + gen(depth + 1) + ")"
+        if r < 0.9:
+            return "(?:" + gen(depth + 1) + ")" + rng.choice(["*", "+", "?", "{2}", "{1,3}", "{0,2}", "{2,}", "*?", "+?"])
+        return "(" + gen(depth + 1) + ")"
+
+    checked = 0
+    while checked < 600:
+        pat = gen()
+        rx = re.compile(pat, re.ASCII)
+        g = G.compile_regex(pat)
+        checked += 1
+        for _ in range(40):
+            s = "".join(rng.choice("abc0 .-\né]x") for _ in range(rng.randint(0, 6)))
+            assert g.fullmatch(s.encode()) == (rx.fullmatch(s) is not None), (pat, s)
