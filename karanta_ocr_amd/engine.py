@@ -475,18 +475,20 @@ class Engine:
             return self.w.view_u8(name + "8"), self.w.view_f32(name[:-1] + "s")
         return None, None
 
-    def _wide_geometry(self, N: int):
+    def _wide_geometry(self, N: int, M: int = 0):
         """(workgroups, waves) of a wide launch.  No idle waves: W = tiles per CU (at most 8), then just enough
         workgroups for one tile per wave (gate/up of the 2B decoder: 1120 tiles = 224 workgroups x 5 waves);
-        beyond that the waves loop over their tiles."""
+        beyond that the waves loop over their tiles.  More than 16 rows: 8 waves, so that the branch-free prologue
+        (4 rows per wave) stages all 32 rows — with 5 waves 12 rows went the slow way, behind the weight ring
+        (gate/up at B = 32: 16.7 -> 14.7 us)."""
         tiles = N // 16
-        waves = self.wide_waves or min(8, -(-tiles // self.wide_blocks))
+        waves = self.wide_waves or (8 if M > 16 else min(8, -(-tiles // self.wide_blocks)))
         return min(self.wide_blocks, -(-tiles // waves)), waves
 
     def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None):
         """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
         N, K = W.shape
-        blocks, waves = self._wide_geometry(N)
+        blocks, waves = self._wide_geometry(N, M)
         o = out if out is not None else out_f32
         tail = (0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0, ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0,
                 M, N, K, blocks, waves, ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
