@@ -879,6 +879,35 @@ def test_linear_wide_two_column_tiles(L, M, N, K, blocks, waves):
         assert i_[b, int(np.lexsort((i_[b], -a_[b]))[0])] == int(ref[b].argmax()) and a_[b].max() == ref[b].max()
 
 
+def test_linear_wide_at_the_bench_shapes(L):
+    """The two wide launches of the headline workload at their real sizes (Qwen2-VL-2B, batch 8): gate/up
+    (N = 17920, 224 workgroups x 5 waves, one tile per wave) and the lm_head (N = 151936, 256 x 8, 4-5 tiles per wave):
+    exact on integers over every output / the argmax of every row."""
+    rng = np.random.default_rng(2025)
+    M, K = 8, 1536
+    x = ints(rng, M, K)
+    W = ints(rng, 17920, K)
+    W[:, K // 2 + 40:] = 0
+    W[::3, 100:300] = 1
+    np.testing.assert_array_equal(run_wide(L, DEC_PLAIN, x, W, 224, 5), ref_linear(x, W))
+    V = 151936
+    Wv = ints(rng, V, K)
+    Wv[:, 300:] = 0
+    ref = ref_linear(x, Wv)
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(Wv))
+    blocks, waves = 256, 8
+    n_part = blocks * waves
+    av = torch.zeros(M, n_part, device=DEV); ai = torch.zeros(M, n_part, dtype=torch.int32, device=DEV)
+    lg = torch.zeros(M, V, dtype=torch.float32, device=DEV)
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), K, ptr(Wd), 0, 0, 1e-6, 0, 0, 0, ptr(lg), V, M, V, K, blocks, waves, ptr(av), ptr(ai), 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(lg.cpu().numpy(), ref)
+    a_, i_ = av.cpu().numpy(), ai.cpu().numpy()
+    for b in range(M):
+        best = int(np.lexsort((i_[b], -a_[b]))[0])                   # highest value, ties to the lowest token id
+        assert i_[b, best] == int(np.flatnonzero(ref[b] == ref[b].max())[0]) and a_[b, best] == ref[b].max()
+
+
 def test_linear_wide_rejects_33_rows_and_k3584_above_16(L):
     x = torch.zeros(33, 3584, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(KarantaHipError):
