@@ -16,6 +16,10 @@ for (k, grid), cs in sorted(g.items()):
     n = len(next(iter(cs.values())))
     print(f"{k} grid={grid} launches={n}")
     wc = np.mean(cs["SQ_WAVE_CYCLES"]) if "SQ_WAVE_CYCLES" in cs else None
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "SQ_BUSY_CYCLES" in cs:
+        # SQ_BUSY_CYCLES sums the 32 shader engines' busy cycles: / 32 = the launch's cycles; x 1024 SIMDs = SIMD-cycles
+        print(f"    MFMA pipe busy, fraction of SIMD-cycles  {np.mean(cs['SQ_VALU_MFMA_BUSY_CYCLES']) / (np.mean(cs['SQ_BUSY_CYCLES']) * 32):8.3f}"
+              f"   (launch = {np.mean(cs['SQ_BUSY_CYCLES']) / 32 / 1e6:.3f} M cycles)")
     for c, v in sorted(cs.items()):
         extra = f"  ({100 * np.mean(v) / wc:5.1f}% of SQ_WAVE_CYCLES)" if wc and c != "SQ_WAVE_CYCLES" else ""
         print(f"    {c:32s} {np.mean(v):16.0f}{extra}")
