@@ -286,6 +286,8 @@ class LocalServer:
         toks, reason = slot["tokens"], slot["reason"]
         text = self.frontend.tok.decode(toks)
         self.latencies.append(time.time() - t0)
+        if len(self.latencies) > 20000:          # bounded: /metrics reads the last 10000
+            del self.latencies[:10000]
         n_in, n_out = int(len(parsed.input_ids)), int(len(toks))
         choice: Dict[str, Any] = {"index": 0, "message": {"role": "assistant", "content": text}, "finish_reason": reason}
         if parsed.logprobs is not None:
