@@ -22,7 +22,9 @@ SOURCES = ["kr_api.hip", "kr_elementwise.hip", "kr_gemm.hip", "kr_attention.hip"
            "kr_selftest.hip"]
 HEADERS = [os.path.join(CSRC, "kr_common.h"), os.path.join(os.path.dirname(HERE), "include", "karanta_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-ffp-contract=fast"]
+         "-fno-gpu-rdc", "-ffp-contract=fast",
+         # leading scalar kernel arguments arrive in SGPRs at wave start (kr_decode.hip: WideHot)
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:

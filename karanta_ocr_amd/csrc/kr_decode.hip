@@ -488,15 +488,23 @@ template <> struct WideCfg<32, 2> { static constexpr int U = 8, RL = 4; };
 // wave-uniform branch at the top of the kernel (each contains the workgroup's single barrier): a branch around
 // the weight loads inside a common body would make the compiler's s_waitcnt bookkeeping assume the shorter
 // path, and the wait for x would become a wait for the weights.
+// The fields every wave needs before its first load, as plain kernel arguments ahead of the struct: with
+// -mllvm -amdgpu-kernarg-preload-count=16 the command processor delivers them in SGPRs at wave start, so the x / weight
+// requests do not wait for a scalar load of the (cold) kernarg segment.
+struct WideHot {
+    const kr_bf16* x; const kr_bf16* wp; const kr_bf16* norm_w; int64_t ldx;
+    int M, N, wide_blocks, wide_waves; float norm_eps;
+};
+
 template <int EPI, int NCH, bool ACTIVE, bool W8, int MT>
-__device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
+__device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs& a, char* smem) {
     using WC = WChunk<W8>;
     constexpr int U = WideCfg<NCH, MT>::U, RL = WideCfg<NCH, MT>::RL;
     constexpr int NR = 2 * MT;  // x rows a wave stages in the branch-free prologue (8 waves x NR rows = 16 MT)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = a.wide_waves, nblk = a.wide_blocks;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = h.wide_waves, nblk = h.wide_blocks;
     const int fr = lane & 15, fg = lane >> 4;
-    const int M = a.M, K = a.K, nchunks = NCH ? NCH : (K >> 6), ntiles = a.N >> 4;
+    const int M = h.M, K = NCH ? NCH * 64 : a.K, nchunks = NCH ? NCH : (K >> 6), ntiles = h.N >> 4;
     const int stride = nblk * W;
     const int xrow = K * 2 + 16, kc = K >> 3;
     int t = blockIdx.x + nblk * wave;
@@ -505,11 +513,11 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     // constant: s_waitcnt bookkeeping does not survive divergent control flow) ...
     constexpr bool FULL = NCH != 0;  // RL * 64 == K / 8 exactly
     bf16x8 xv[NR][RL], nwv[RL];
-    const bool has_norm = a.norm_w != nullptr;
+    const bool has_norm = h.norm_w != nullptr;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int b = wave + r * W;
-        const kr_bf16* xp = a.x + (int64_t)(b < M ? b : 0) * a.ldx;
+        const kr_bf16* xp = h.x + (int64_t)(b < M ? b : 0) * h.ldx;
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
             const int c = lane + i * 64;
@@ -517,7 +525,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
         }
     }
     {
-        const kr_bf16* np = has_norm ? a.norm_w : a.x;  // always a valid address; unused without a norm
+        const kr_bf16* np = has_norm ? h.norm_w : h.x;  // always a valid address; unused without a norm
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
             const int c = lane + i * 64;
@@ -526,7 +534,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
     }
     // ---- ... then the weight ring
     WC wbuf[U];
-    const char* wbase = reinterpret_cast<const char*>(a.wp) + lane * 16;
+    const char* wbase = reinterpret_cast<const char*>(h.wp) + lane * 16;
     const char* wp = wbase + ((int64_t)(ACTIVE ? t : 0) * nchunks) * WC::BYTES;
     if (ACTIVE) {
 #pragma unroll
@@ -546,7 +554,7 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
             }
         }
         ss = wave_sum(ss);
-        const float rs = rsqrtf(ss / (float)K + a.norm_eps);
+        const float rs = rsqrtf(ss / (float)K + h.norm_eps);
         if (b < M) {
 #pragma unroll
             for (int i = 0; i < RL; ++i) {
@@ -569,20 +577,20 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
         for (int i = 0; i < RL; ++i) {
             const int c = lane + i * 64;
             if (c < kc) {
-                v[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+                v[i] = ld8(h.x + (int64_t)b * h.ldx + c * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ss += bf2f(v[i][j]) * bf2f(v[i][j]);
             }
         }
         ss = wave_sum(ss);
-        const float rs = a.norm_w ? rsqrtf(ss / (float)K + a.norm_eps) : 1.f;
+        const float rs = h.norm_w ? rsqrtf(ss / (float)K + h.norm_eps) : 1.f;
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
             const int c = lane + i * 64;
             if (c < kc) {
                 bf16x8 o = v[i];
-                if (a.norm_w) {
-                    const bf16x8 nw = ld8(a.norm_w + c * 8);
+                if (h.norm_w) {
+                    const bf16x8 nw = ld8(h.norm_w + c * 8);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[j]) * bfround(bf2f(v[i][j]) * rs));
                 }
@@ -712,11 +720,13 @@ __device__ __forceinline__ void dec_wide_body(const DecLinArgs& a, char* smem) {
 }
 
 template <int EPI, int NCH, bool W8, int MT>
-__global__ void __launch_bounds__(512) dec_wide_kernel(const DecLinArgs a) {
+__global__ void __launch_bounds__(512) dec_wide_kernel(const kr_bf16* x, const kr_bf16* wp, const kr_bf16* norm_w, int64_t ldx, int M,
+                                                       int N, int wide_blocks, int wide_waves, float norm_eps, const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WideHot h{x, wp, norm_w, ldx, M, N, wide_blocks, wide_waves, norm_eps};
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x + a.wide_blocks * wave < (a.N >> 4)) dec_wide_body<EPI, NCH, true, W8, MT>(a, smem);
-    else dec_wide_body<EPI, NCH, false, W8, MT>(a, smem);
+    if ((int)blockIdx.x + wide_blocks * wave < (N >> 4)) dec_wide_body<EPI, NCH, true, W8, MT>(h, a, smem);
+    else dec_wide_body<EPI, NCH, false, W8, MT>(h, a, smem);
 }
 
 template <int EPI, int NCH, bool W8, int MT>
@@ -729,7 +739,7 @@ int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a);
+    fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.ldx, a.M, a.N, a.wide_blocks, a.wide_waves, a.norm_eps, a);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
