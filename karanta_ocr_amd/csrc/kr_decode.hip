@@ -791,7 +791,10 @@ constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 // U = ring depth in 64-wide K chunks: the host picks the smallest instantiated U that covers a wave's share of K
 // (then every chunk is requested up front and at most one request per wave is redundant), else the deepest ring.
 template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8, int MT>
-__global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs a) {
+__global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* hx, const kr_bf16* hwp, const kr_bf16* hnorm_w, const float* hpart_in,
+                                                                int64_t hldx, int hM, int hN, int hK, int hksplit, float hnorm_eps,
+                                                                const DecLinArgs a) {
+    // hot fields as leading scalars: preloaded into SGPRs at wave start (see WideHot)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WC = WChunk<W8>;
     constexpr int RL = NarrowCfg<NCH>::RL;
@@ -800,9 +803,9 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int g = blockIdx.x, ks = blockIdx.y;
-    const int M = a.M, K = a.K;
-    const int nchunks = NCH ? NCH : (K >> 6), ntiles = a.N >> 4, kc = K >> 3;
-    const int cpb = (nchunks + a.ksplit - 1) / a.ksplit;
+    const int M = hM, K = hK;
+    const int nchunks = NCH ? NCH : (K >> 6), ntiles = hN >> 4, kc = K >> 3;
+    const int cpb = (nchunks + hksplit - 1) / hksplit;
     const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
     const int nblk = cb1 - cb0;
     const int c0 = cb0 + (wave * nblk) / WAVES, c1 = cb0 + ((wave + 1) * nblk) / WAVES;  // even shares, contiguous
@@ -821,41 +824,32 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
     const char* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-        wp[t] = reinterpret_cast<const char*>(a.wp) + ((int64_t)min(tile[t], ntiles - 1) * nchunks) * WC::BYTES + lane * 16;
+        wp[t] = reinterpret_cast<const char*>(hwp) + ((int64_t)min(tile[t], ntiles - 1) * nchunks) * WC::BYTES + lane * 16;
     int rb[MT];  // batch rows of this lane's accumulator columns (one per column tile)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rb[mt] = min(fr + 16 * mt, M - 1);
 
-    // ---- 1. the oldest loads of every wave: what the prologue and the epilogue wait for
-    int pos[MT], plen[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        pos[mt] = plen[mt] = 0;
-        if (EPI == DEPI_ROPE_KV) {
-            pos[mt] = a.ctx_len[rb[mt]];
-            plen[mt] = a.prompt_len[rb[mt]];
-        }
-    }
+    // ---- 1. the oldest loads of every wave: what the prologue waits for (addresses from preloaded arguments only)
     bf16x8 xv[NORM ? RL : 1], nwv[NORM ? RL : 1];
     f32x4 pv[PKS ? PKS : 1][NORM ? RL : 1][2];
     bf16x8 xf[NORM ? 1 : U][MT][2];
     const char* xg[MT];   // x fragments: + c*128 + WC::x_byte(h, fg)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xg[mt] = reinterpret_cast<const char*>(a.x + (int64_t)rb[mt] * a.ldx);
+    for (int mt = 0; mt < MT; ++mt) xg[mt] = reinterpret_cast<const char*>(hx + (int64_t)rb[mt] * hldx);
     if (NORM) {
         const int b = wave < M ? wave : 0;
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
             const int c = lane + i * 64;
             if (FULL || c < kc) {
-                xv[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+                xv[i] = ld8(hx + (int64_t)b * hldx + c * 8);
 #pragma unroll
                 for (int k = 0; k < PKS; ++k) {
-                    const float* pp = a.part_in + ((int64_t)k * M + b) * K + c * 8;
+                    const float* pp = hpart_in + ((int64_t)k * M + b) * K + c * 8;
                     pv[k][i][0] = *reinterpret_cast<const f32x4*>(pp);
                     pv[k][i][1] = *reinterpret_cast<const f32x4*>(pp + 4);
                 }
-                nwv[i] = ld8(a.norm_w + c * 8);
+                nwv[i] = ld8(hnorm_w + c * 8);
             }
         }
     } else {
@@ -867,6 +861,17 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
                 xf[u][mt][0] = *reinterpret_cast<const bf16x8*>(xg[mt] + c * 128 + WC::x_byte(0, fg));
                 xf[u][mt][1] = *reinterpret_cast<const bf16x8*>(xg[mt] + c * 128 + WC::x_byte(1, fg));
             }
+        }
+    }
+    // decode position / prompt length of the rotary epilogue: their pointers come from the argument STRUCT (a scalar
+    // load), so they are requested after the x rows, which need preloaded arguments only
+    int pos[MT], plen[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pos[mt] = plen[mt] = 0;
+        if (EPI == DEPI_ROPE_KV) {
+            pos[mt] = a.ctx_len[rb[mt]];
+            plen[mt] = a.prompt_len[rb[mt]];
         }
     }
     // ---- 2. the weight ring (clamped, not branched: short waves re-request their last chunk)
@@ -891,7 +896,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
                 }
             }
             ss = wave_sum(ss);
-            const float rs = rsqrtf(ss / (float)K + a.norm_eps);
+            const float rs = rsqrtf(ss / (float)K + hnorm_eps);
 #pragma unroll
             for (int i = 0; i < RL; ++i) {
                 const int c = lane + i * 64;
@@ -926,14 +931,14 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
             for (int i = 0; i < RL; ++i) {
                 const int c = lane + i * 64;
                 if (FULL || c < kc) {
-                    v[i] = ld8(a.x + (int64_t)b * a.ldx + c * 8);
+                    v[i] = ld8(hx + (int64_t)b * hldx + c * 8);
                     if (PKS) {
                         float f[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) f[j] = bf2f(v[i][j]);
 #pragma unroll
                         for (int k = 0; k < PKS; ++k) {
-                            const float* pp = a.part_in + ((int64_t)k * M + b) * K + c * 8;
+                            const float* pp = hpart_in + ((int64_t)k * M + b) * K + c * 8;
                             const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -982,10 +987,10 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const DecLinArgs
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = min(tile[t], ntiles - 1) * 16 + fg * 4;
-            bias_pre[t] = *reinterpret_cast<const bf16x4*>(a.bias ? a.bias + n : a.x);
+            bias_pre[t] = *reinterpret_cast<const bf16x4*>(a.bias ? a.bias + n : hx);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                res_pre[mt][t] = *reinterpret_cast<const bf16x4*>(a.residual ? a.residual + (int64_t)rb[mt] * a.ldr + n : a.x);
+                res_pre[mt][t] = *reinterpret_cast<const bf16x4*>(a.residual ? a.residual + (int64_t)rb[mt] * a.ldr + n : hx);
         }
     }
 
@@ -1143,7 +1148,7 @@ int launch_narrow_m(DecLinArgs& a, int groups, kr_stream s) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
+    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.part_in, a.ldx, a.M, a.N, a.K, a.ksplit, a.norm_eps, a);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
