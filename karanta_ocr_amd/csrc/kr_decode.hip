@@ -792,7 +792,7 @@ constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 // (then every chunk is requested up front and at most one request per wave is redundant), else the deepest ring.
 template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8, int MT>
 __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* hx, const kr_bf16* hwp, const kr_bf16* hnorm_w, const float* hpart_in,
-                                                                int64_t hldx, int hM, int hN, int hK, int hksplit, float hnorm_eps,
+                                                                int64_t hldx, int hM, int hN, int hK, int hcpb, float hnorm_eps,
                                                                 const DecLinArgs a) {
     // hot fields as leading scalars: preloaded into SGPRs at wave start (see WideHot)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
     const int g = blockIdx.x, ks = blockIdx.y;
     const int M = hM, K = hK;
     const int nchunks = NCH ? NCH : (K >> 6), ntiles = hN >> 4, kc = K >> 3;
-    const int cpb = (nchunks + hksplit - 1) / hksplit;
+    const int cpb = hcpb;   // chunks per K split, computed on the host (a runtime integer division is ~30 instructions here)
     const int cb0 = min(ks * cpb, nchunks), cb1 = min(cb0 + cpb, nchunks);
     const int nblk = cb1 - cb0;
     const int c0 = cb0 + (wave * nblk) / WAVES, c1 = cb0 + ((wave + 1) * nblk) / WAVES;  // even shares, contiguous
@@ -1148,7 +1148,7 @@ int launch_narrow_m(DecLinArgs& a, int groups, kr_stream s) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.part_in, a.ldx, a.M, a.N, a.K, a.ksplit, a.norm_eps, a);
+    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.part_in, a.ldx, a.M, a.N, a.K, cpb, a.norm_eps, a);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
