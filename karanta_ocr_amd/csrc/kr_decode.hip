@@ -1224,9 +1224,11 @@ int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
                                                                   const kr_bf16* __restrict__ vtcache,
-                                                                  const int32_t* __restrict__ ctx_len, kr_bf16* __restrict__ out,
-                                                                  float* __restrict__ ws, int* __restrict__ counters, int heads,
-                                                                  int kv_heads, int s_max, float scale_log2e) {
+                                                                  const int32_t* __restrict__ ctx_len, int heads, int kv_heads,
+                                                                  int s_max, float scale_log2e, kr_bf16* __restrict__ out,
+                                                                  float* __restrict__ ws, int* __restrict__ counters) {
+    // argument order: everything the first loads need sits in the 16 preloaded dwords (kernarg preload), so the
+    // scalar load of ctx_len[b] leaves at once instead of behind a load of the argument tail
     constexpr int HD = 128, DT = HD / 16, REC = HD + 4, NTHR = WAVES * 64;
     __shared__ __attribute__((aligned(16))) float o_s[WAVES][16][HD];
     __shared__ float m_s[WAVES][16], l_s[WAVES][16];
@@ -1818,10 +1820,10 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     static const bool waves4 = [] { const char* e = getenv("KARANTA_ATTN_WAVES"); return e && e[0] == '4'; }();
     if (n_split <= 4 || !waves4)
         attn_decode2_kernel<8><<<dim3(n_split, kv_heads, batch), 512, 0, kr_hs(s)>>>(
-            q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
+            q, kcache, vtcache, ctx_len, heads, kv_heads, s_max, scale * 1.4426950408889634f, out, workspace, counters);
     else
         attn_decode2_kernel<4><<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
-            q, kcache, vtcache, ctx_len, out, workspace, counters, heads, kv_heads, s_max, scale * 1.4426950408889634f);
+            q, kcache, vtcache, ctx_len, heads, kv_heads, s_max, scale * 1.4426950408889634f, out, workspace, counters);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
