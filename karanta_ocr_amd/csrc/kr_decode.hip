@@ -1225,8 +1225,9 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
                                                                   const kr_bf16* __restrict__ vtcache,
                                                                   const int32_t* __restrict__ ctx_len, int heads, int kv_heads,
-                                                                  int s_max, float scale_log2e, kr_bf16* __restrict__ out,
-                                                                  float* __restrict__ ws, int* __restrict__ counters) {
+                                                                  int group, int n_split, int s_max, float scale_log2e,
+                                                                  kr_bf16* __restrict__ out, float* __restrict__ ws,
+                                                                  int* __restrict__ counters) {
     // argument order: everything the first loads need sits in the 16 preloaded dwords (kernarg preload), so the
     // scalar load of ctx_len[b] leaves at once instead of behind a load of the argument tail
     constexpr int HD = 128, DT = HD / 16, REC = HD + 4, NTHR = WAVES * 64;
@@ -1235,8 +1236,9 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
     __shared__ int last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int split = blockIdx.x, n_split = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
-    const int group = heads / kv_heads;
+    // group (= heads / kv_heads) and n_split (= gridDim.x) are arguments: a runtime division and a read of the dispatch
+    // packet would both sit in front of the first loads
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int n_part = n_split * WAVES, part = split * WAVES + wave;
     const int ctx = ctx_len[b] + 1;
 
@@ -1820,10 +1822,12 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     static const bool waves4 = [] { const char* e = getenv("KARANTA_ATTN_WAVES"); return e && e[0] == '4'; }();
     if (n_split <= 4 || !waves4)
         attn_decode2_kernel<8><<<dim3(n_split, kv_heads, batch), 512, 0, kr_hs(s)>>>(
-            q, kcache, vtcache, ctx_len, heads, kv_heads, s_max, scale * 1.4426950408889634f, out, workspace, counters);
+            q, kcache, vtcache, ctx_len, heads, kv_heads, heads / kv_heads, n_split, s_max, scale * 1.4426950408889634f, out, workspace,
+            counters);
     else
         attn_decode2_kernel<4><<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
-            q, kcache, vtcache, ctx_len, heads, kv_heads, s_max, scale * 1.4426950408889634f, out, workspace, counters);
+            q, kcache, vtcache, ctx_len, heads, kv_heads, heads / kv_heads, n_split, s_max, scale * 1.4426950408889634f, out, workspace,
+            counters);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
