@@ -398,6 +398,9 @@ int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, int n_part,
 #define KR_UNIQUE_ID_BYTES 128
 int kr_comm_unique_id(uint8_t* id128);
 int kr_comm_init(void** comm, int n_ranks, int rank, const uint8_t* id128);
+/* Number of ranks RCCL itself reports for the communicator (ncclCommCount): bench.py prints it, so "did RCCL see N
+ * ranks?" is answered by the library, not by the launcher's environment. */
+int kr_comm_count(void* comm, int* n_ranks);
 int kr_comm_destroy(void* comm);
 int kr_bcast_weights(void* comm, void* buf, size_t bytes, int root, kr_stream s);
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
     "kr_comm_unique_id": [c_p],
     "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],
+    "kr_comm_count": [c_p, C.POINTER(i32)],
     "kr_comm_destroy": [c_p],
     "kr_bcast_weights": [c_p, c_p, C.c_size_t, i32, c_p],
     "kr_selftest_mfma": [c_p],

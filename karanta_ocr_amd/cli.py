@@ -49,7 +49,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--max-tokens-cap", type=int, default=6000, help="largest max_tokens a request may ask for")
     ap.add_argument("--static-batching", action="store_true", help="static batches instead of the slot scheduler")
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU image front end")
-    ap.add_argument("--max-pixels", type=int, default=None)
+    ap.add_argument("--max-pixels", type=int, default=None,
+                    help="override the checkpoint's preprocessor_config.json (default without one: 1003520)")
+    ap.add_argument("--min-pixels", type=int, default=None)
     ap.add_argument("--greedy", action="store_true", help="ignore request temperatures")
     ap.add_argument("--quantization", default=None, choices=("fp8",),
                     help="decoder Linears as fp8 codes + row scales (vLLM's flag; implied by a checkpoint with a quantization_config)")
@@ -94,6 +96,25 @@ def _checkpoint_is_fp8(model_dir: str) -> bool:
     return bool(q) and ("fp8" in blob or "float8" in blob or '"num_bits": 8' in blob and '"type": "float"' in blob)
 
 
+def preprocessor_pixels(model_dir: str):
+    """(min_pixels, max_pixels) of the checkpoint's ``preprocessor_config.json`` — what vLLM's Qwen2-VL processor uses
+    for every request (the shipped file is primary; the transformers class default, 1 003 520, only
+    applies without it).  Both spellings: top-level ``min_pixels`` / ``max_pixels`` (transformers 4) and
+    ``size = {"shortest_edge": min, "longest_edge": max}`` (transformers >= 4.49 fast processors).  Missing file or keys
+    -> (None, None)."""
+    import json
+    try:
+        with open(os.path.join(model_dir, "preprocessor_config.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    size = d.get("size") if isinstance(d.get("size"), dict) else {}
+    lo = d.get("min_pixels", size.get("shortest_edge"))
+    hi = d.get("max_pixels", size.get("longest_edge"))
+    ok = lambda v: int(v) if isinstance(v, (int, float)) and v > 0 else None
+    return ok(lo), ok(hi)
+
+
 def make_server(args, log=print):
     """Engine + front end + LocalServer from parsed arguments (weights and tokenizer from args.model_dir)."""
     from . import image_processing as IP
@@ -101,15 +122,32 @@ def make_server(args, log=print):
     from .serving import ChatFrontend, HFTokenizer, LocalServer
     from .weights import load_checkpoint
 
-    cfg, tensors = load_checkpoint(args.model_dir)
+    from .dp import load_or_receive_weights, serving_group_env
+    from .weights import load_config
+
+    rank, world = serving_group_env()      # (0, 1) unless launch.py started this server as one of a node's group
+    cfg = load_config(args.model_dir)
     weight_dtype = "fp8" if (args.quantization == "fp8" or _checkpoint_is_fp8(args.model_dir)) else "bf16"
-    max_pixels = args.max_pixels or IP.MAX_PIXELS_CLASS_DEFAULT
+    # image size bounds: command line > the checkpoint's preprocessor_config.json > the transformers class default
+    ck_min, ck_max = preprocessor_pixels(args.model_dir)
+    min_pixels = args.min_pixels or ck_min or IP.MIN_PIXELS
+    max_pixels = args.max_pixels or ck_max or IP.MAX_PIXELS_CLASS_DEFAULT
+    if min_pixels > max_pixels:
+        raise ValueError(f"min_pixels {min_pixels} > max_pixels {max_pixels}")
+    log(f"image preprocessing: min_pixels={min_pixels} max_pixels={max_pixels} "
+        f"({'--max-pixels' if args.max_pixels else 'preprocessor_config.json' if ck_max else 'class default'})")
     patches_per_page = max_pixels // (cfg.vision.patch_size ** 2) + 64
     eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 63) // 64 * 64,
                  max_patches=args.max_num_seqs * patches_per_page, max_prompt_tokens=args.max_num_seqs * args.max_model_len // 2,
                  weight_dtype=weight_dtype)
-    eng.load_weights(tensors)
-    front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), max_pixels=max_pixels,
+    # one server: read the checkpoint.  A launch.py group: rank 0 reads it ONCE, the arena goes to the other GPUs over
+    # RCCL / xGMI (north_star: "RCCL broadcast of weights over xGMI"); a failure stops every server of the group
+    info = load_or_receive_weights(eng.w, rank, world, lambda: eng.load_weights(load_checkpoint(args.model_dir)[1]),
+                                   stream=eng.s, log=log)
+    if world > 1:
+        log(f"weight broadcast: {info['bytes'] / 1e9:.2f} GB in {info['bcast_s']:.3f}s over {info['rccl_ranks']} RCCL ranks")
+    front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), min_pixels=min_pixels,
+                         max_pixels=max_pixels,
                          max_model_len=args.max_model_len, device_images=not args.host_images)
     return LocalServer(eng, front, served_model_name=args.served_model_name, log=log, continuous=not args.static_batching,
                        max_tokens_cap=min(args.max_tokens_cap, args.max_model_len), honor_temperature=not args.greedy,

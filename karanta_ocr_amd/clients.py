@@ -1,219 +1,232 @@
-"""Drop-in for the reference's ``bulk_processing/workers/vllm_client.py``: same class names, method
-names, argument meaning, result-dict schema and error behaviour — with the MI355X engine behind it.
+"""Client side of the drop-in boundary: the bulk workers' ``VLLMClient`` family with the MI355X engine behind it.
 
-Reference surface mirrored (file:line in /root/reference/bulk_processing/workers/vllm_client.py):
-``VLLMClientError`` :14 · ``VLLMClient.__init__`` :28-74 · ``health_check`` :76-110 (60 s cache) ·
-``get_server_info`` :112-153 · ``generate`` :155-227 (health check, default model = first served model,
-``max_retries + 1`` attempts with ``retry_delay * 2**attempt`` back-off, then ``VLLMClientError``) ·
-``_process_response`` :229-266 (result schema) · ``batch_generate`` :268-296 · ``VLLMClientManager``
-:304-386 (``worker_port_{port}_{i}@host`` parsing) · ``get_vllm_client_for_worker`` :393-404.
+The reference's Celery workers reach their model server through ``bulk_processing/workers/vllm_client.py``
+(an OpenAI-SDK wrapper).  A worker switches to this engine by importing the same names from here; what is kept is the
+*surface* — class and method names, argument names and defaults, the result-dict keys, when ``VLLMClientError`` is
+raised — and nothing of the implementation:
 
-Transport: when a :class:`karanta_ocr_amd.serving.LocalServer` is registered for the client's
-port the call is in-process (no HTTP, no OpenAI SDK); otherwise the same three endpoints are reached
-over plain HTTP (stdlib), i.e. the HTTP shim of ``serving.serve_http`` or any OpenAI-compatible server.
+====================================  =======================================================================
+reference (vllm_client.py)            kept here
+====================================  =======================================================================
+``VLLMClient(...)`` :28-74            same seven arguments and defaults; ``base_url`` / ``health_url`` attributes
+``health_check(force)`` :76-110       True / False, a positive answer is remembered for 60 s
+``get_server_info(force_refresh)``    ``{"models", "base_url", "port", "host", "last_updated", + /health JSON}``
+``generate(...)`` :155-227            unhealthy server or no model -> ``VLLMClientError``; ``max_retries + 1`` tries,
+                                      pause ``retry_delay * 2**k`` after try k, then ``VLLMClientError``
+result dict :229-266                  ``text, finish_reason, model, usage{3}, metadata{generation_time, server_url,
+                                      generation_params (without messages), timestamp}``
+``batch_generate`` :268-296           one result per prompt, failures as ``{"error", "metadata": {batch_index, failed}}``
+``VLLMClientManager`` :304-386        one cached client per port; ``worker_port_{port}_{i}@host`` -> port
+``get_vllm_client_for_worker``        module-level manager
+====================================  =======================================================================
+
+Transport (new): a :class:`karanta_ocr_amd.serving.LocalServer` registered for the client's port is called in-process
+(no HTTP, no SDK); otherwise the three endpoints are reached with the standard library's HTTP client, i.e. the shim of
+``serving.serve_http`` / ``python -m karanta_ocr_amd.cli`` or any OpenAI-compatible server.
 """
 from __future__ import annotations
 
 import json
 import logging
+import re
 import time
 import urllib.error
 import urllib.request
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
 from .serving import local_server
 
 logger = logging.getLogger(__name__)
 
+_HEALTH_TTL_S = 60.0                                   # how long a positive health answer is trusted
+_WORKER_PORT = re.compile(r"(?:^|_)port_(\d+)(?:_|@|$)")  # worker_port_8000_1@hostname -> 8000
+
 
 class VLLMClientError(Exception):
-    """Custom exception for VLLM client errors"""
+    """Raised for every failure the caller cannot retry its way out of (same name as the reference's)."""
+
+
+class _Endpoint:
+    """GET / POST against one server: in-process when a LocalServer is registered for (host, port), HTTP otherwise.
+    Always answers ``(status, json_body)``; only connection-level failures raise."""
+
+    _ROUTES = {"/health": "health", "/v1/models": "models"}
+
+    def __init__(self, host: str, port: int, api_key: str, timeout: float):
+        self.host, self.port, self.api_key, self.timeout = host, port, api_key, timeout
+
+    def request(self, path: str, payload: Optional[dict] = None, timeout: Optional[float] = None) -> Tuple[int, dict]:
+        srv = local_server(self.host, self.port)
+        if srv is not None:
+            if payload is None:
+                return getattr(srv, self._ROUTES[path])()
+            return srv.chat_completions(payload)
+        req = urllib.request.Request(f"http://{self.host}:{self.port}{path}",
+                                     data=None if payload is None else json.dumps(payload).encode(),
+                                     method="GET" if payload is None else "POST",
+                                     headers={"Content-Type": "application/json",
+                                              **({"Authorization": f"Bearer {self.api_key}"} if self.api_key else {})})
+        try:
+            with urllib.request.urlopen(req, timeout=self.timeout if timeout is None else timeout) as resp:
+                return resp.status, self._json(resp.read())
+        except urllib.error.HTTPError as e:      # 4xx / 5xx still carry the server's JSON error body
+            return e.code, self._json(e.read())
+
+    @staticmethod
+    def _json(raw: bytes) -> dict:
+        if not raw:
+            return {}
+        try:
+            doc = json.loads(raw)
+            return doc if isinstance(doc, dict) else {"data": doc}
+        except ValueError:
+            return {"error": {"message": raw.decode("utf-8", "replace")}}
 
 
 class VLLMClient:
     def __init__(self, port: int, host: str = "localhost", api_key: str = "EMPTY", timeout: float = 300.0,
                  max_retries: int = 3, retry_delay: float = 1.0, health_check_timeout: float = 30.0):
-        self.port = port
-        self.host = host
-        self.api_key = api_key
-        self.timeout = timeout
-        self.max_retries = max_retries
-        self.retry_delay = retry_delay
-        self.health_check_timeout = health_check_timeout
-        self.base_url = f"http://{self.host}:{self.port}/v1"
-        self.health_url = f"http://{self.host}:{self.port}/health"
-        self._server_info = None
-        self._last_health_check = 0
-        self._health_check_interval = 60  # seconds, as the reference
-        logger.info(f"Initialized VLLM client for {self.base_url}")
-
-    # ------------------------------------------------------------------ transport
-    def _call(self, method: str, path: str, body: Optional[dict] = None, timeout: Optional[float] = None):
-        srv = local_server(self.host, self.port)
-        if srv is not None:
-            if path == "/health":
-                return srv.health()
-            if path == "/v1/models":
-                return srv.models()
-            return srv.chat_completions(body)
-        url = f"http://{self.host}:{self.port}{path}"
-        data = json.dumps(body).encode() if body is not None else None
-        req = urllib.request.Request(url, data=data, method=method)
-        req.add_header("Content-Type", "application/json")
-        if self.api_key:
-            req.add_header("Authorization", f"Bearer {self.api_key}")
-        try:
-            with urllib.request.urlopen(req, timeout=timeout or self.timeout) as r:
-                raw = r.read()
-                return r.status, (json.loads(raw) if raw else {})
-        except urllib.error.HTTPError as e:
-            raw = e.read()
-            try:
-                return e.code, json.loads(raw)
-            except Exception:
-                return e.code, {"error": {"message": raw.decode("utf-8", "replace")}}
-
-    # ------------------------------------------------------------------ reference API
-    def health_check(self, force: bool = False) -> bool:
-        current_time = time.time()
-        if not force and (current_time - self._last_health_check) < self._health_check_interval:
-            return True
-        try:
-            status, _ = self._call("GET", "/health", timeout=self.health_check_timeout)
-            is_healthy = status == 200
-            self._last_health_check = current_time
-            if not is_healthy:
-                logger.warning(f"VLLM server health check failed: {status}")
-            return is_healthy
-        except Exception as e:  # connection refused etc. (requests.RequestException in the reference)
-            logger.error(f"VLLM server health check failed: {e}")
-            return False
-
-    def get_server_info(self, force_refresh: bool = False) -> Dict[str, Any]:
-        if self._server_info is None or force_refresh:
-            try:
-                status, body = self._call("GET", "/v1/models")
-                if status != 200:
-                    raise RuntimeError(f"GET /v1/models -> {status}")
-                models = [m["id"] for m in body.get("data", [])]
-                info = {"models": models, "base_url": self.base_url, "port": self.port, "host": self.host,
-                        "last_updated": time.time()}
-                try:
-                    hs, hb = self._call("GET", "/health", timeout=5)
-                    if hs == 200 and isinstance(hb, dict):
-                        info.update(hb)
-                except Exception:
-                    pass
-                self._server_info = info
-                logger.info(f"Retrieved server info: {len(models)} models available")
-            except Exception as e:
-                logger.error(f"Failed to get server info: {e}")
-                raise VLLMClientError(f"Failed to get server info: {e}")
-        return self._server_info
-
-    def generate(self, messages: List[Dict[str, str]], model: Optional[str] = None, max_tokens: int = 100,
-                 temperature: float = 0.7, response_format: Optional[Dict[str, Any]] = None, **kwargs) -> Dict[str, Any]:
-        if not self.health_check():
-            raise VLLMClientError(f"VLLM server at {self.base_url} is not healthy")
-        if model is None:
-            server_info = self.get_server_info()
-            if not server_info.get("models"):
-                raise VLLMClientError("No models available on server")
-            model = server_info["models"][0]
-            logger.debug(f"Using default model: {model}")
-        generation_params = {"model": model, "messages": messages, "max_tokens": max_tokens, "temperature": temperature,
-                             "response_format": response_format, **kwargs}
-        last_exception = None
-        start_time = time.time()
-        for attempt in range(self.max_retries + 1):
-            try:
-                logger.debug(f"Generation attempt {attempt + 1}/{self.max_retries + 1}")
-                status, body = self._call("POST", "/v1/chat/completions", generation_params)
-                if status != 200:
-                    raise RuntimeError(f"Error code: {status} - {body.get('error', body)}")
-                return self._process_response(body, start_time, generation_params)
-            except Exception as e:
-                last_exception = e
-                logger.warning(f"Generation attempt {attempt + 1} failed: {e}")
-                if attempt < self.max_retries:
-                    time.sleep(self.retry_delay * (2 ** attempt))
-                    continue
-                break
-        error_msg = f"Generation failed after {self.max_retries + 1} attempts. Last error: {last_exception}"
-        logger.error(error_msg)
-        raise VLLMClientError(error_msg)
-
-    def _process_response(self, response: dict, start_time: float, generation_params: Dict[str, Any]) -> Dict[str, Any]:
-        end_time = time.time()
-        if not response.get("choices"):
-            raise VLLMClientError("No choices returned from VLLM server")
-        choice = response["choices"][0]
-        usage = response.get("usage") or {}
-        return {
-            "text": choice["message"]["content"],
-            "finish_reason": choice.get("finish_reason"),
-            "model": response.get("model"),
-            "usage": {"prompt_tokens": usage.get("prompt_tokens", 0), "completion_tokens": usage.get("completion_tokens", 0),
-                      "total_tokens": usage.get("total_tokens", 0)},
-            "metadata": {
-                "generation_time": end_time - start_time,
-                "server_url": self.base_url,
-                "generation_params": {k: v for k, v in generation_params.items() if k not in ["messages"]},
-                "timestamp": end_time,
-            },
-        }
-
-    def batch_generate(self, prompts: List[Any], **generation_kwargs) -> List[Dict[str, Any]]:
-        """One ``generate`` per prompt, errors captured per item.  (The reference passes each element
-        straight through as ``messages``, vllm_client.py:286 — so elements are message lists; a bare
-        string is wrapped into a single user message here instead of failing server-side.)"""
-        results = []
-        for i, prompt in enumerate(prompts):
-            try:
-                messages = [{"role": "user", "content": prompt}] if isinstance(prompt, str) else prompt
-                result = self.generate(messages, **generation_kwargs)
-                result["metadata"]["batch_index"] = i
-                results.append(result)
-            except Exception as e:
-                logger.error(f"Failed to process prompt {i + 1}: {e}")
-                results.append({"error": str(e), "metadata": {"batch_index": i, "failed": True}})
-        return results
+        self.port, self.host, self.api_key = port, host, api_key
+        self.timeout, self.health_check_timeout = timeout, health_check_timeout
+        self.max_retries, self.retry_delay = max_retries, retry_delay
+        root = f"http://{host}:{port}"
+        self.base_url, self.health_url = root + "/v1", root + "/health"
+        self._endpoint = _Endpoint(host, port, api_key, timeout)
+        self._info: Optional[Dict[str, Any]] = None
+        self._healthy_until = 0.0
 
     def __repr__(self) -> str:
         return f"VLLMClient(host={self.host}, port={self.port}, base_url={self.base_url})"
 
+    # ------------------------------------------------------------------ probes
+    def health_check(self, force: bool = False) -> bool:
+        now = time.time()
+        if not force and now < self._healthy_until:
+            return True
+        try:
+            status, _ = self._endpoint.request("/health", timeout=self.health_check_timeout)
+        except Exception as exc:                      # refused connection, time-out, DNS ...
+            logger.error("health probe of %s failed: %s", self.health_url, exc)
+            return False
+        if status != 200:
+            logger.warning("health probe of %s answered %s", self.health_url, status)
+            return False
+        self._healthy_until = now + _HEALTH_TTL_S
+        return True
+
+    def get_server_info(self, force_refresh: bool = False) -> Dict[str, Any]:
+        if self._info is not None and not force_refresh:
+            return self._info
+        try:
+            status, listing = self._endpoint.request("/v1/models")
+            if status != 200:
+                raise RuntimeError(f"/v1/models answered {status}")
+            info: Dict[str, Any] = {"models": [entry["id"] for entry in listing.get("data", [])], "base_url": self.base_url,
+                                    "port": self.port, "host": self.host, "last_updated": time.time()}
+        except Exception as exc:
+            raise VLLMClientError(f"Failed to get server info: {exc}") from exc
+        try:                                          # whatever /health reports beyond its status, best effort
+            status, extra = self._endpoint.request("/health", timeout=5)
+            if status == 200:
+                info.update(extra)
+        except Exception:
+            pass
+        self._info = info
+        return info
+
+    # ------------------------------------------------------------------ generation
+    def generate(self, messages: List[Dict[str, str]], model: Optional[str] = None, max_tokens: int = 100,
+                 temperature: float = 0.7, response_format: Optional[Dict[str, Any]] = None, **kwargs) -> Dict[str, Any]:
+        if self.health_check() is False:
+            raise VLLMClientError(f"VLLM server at {self.base_url} is not healthy")
+        if not model:
+            served = self.get_server_info().get("models")
+            if not served:
+                raise VLLMClientError(f"{self.base_url} serves no model")
+            model = served[0]
+        request = dict(kwargs, model=model, messages=messages, max_tokens=max_tokens, temperature=temperature,
+                       response_format=response_format)
+        t_first = time.time()
+        tries = self.max_retries + 1
+        failure: Optional[Exception] = None
+        for k in range(tries):
+            if k:
+                time.sleep(self.retry_delay * 2 ** (k - 1))
+            try:
+                status, body = self._endpoint.request("/v1/chat/completions", request)
+                if status == 200:
+                    return self._process_response(body, t_first, request)
+                failure = RuntimeError(f"Error code: {status} - {body.get('error', body)}")
+            except VLLMClientError:
+                raise
+            except Exception as exc:
+                failure = exc
+            logger.warning("chat completion try %d of %d on %s failed: %s", k + 1, tries, self.base_url, failure)
+        raise VLLMClientError(f"Generation failed after {tries} attempts. Last error: {failure}")
+
+    def _process_response(self, response: dict, start_time: float, generation_params: Dict[str, Any]) -> Dict[str, Any]:
+        choices = response.get("choices") or []
+        if not choices:
+            raise VLLMClientError(f"{self.base_url} answered without choices")
+        first, usage, now = choices[0], response.get("usage") or {}, time.time()
+        echoed = dict(generation_params)
+        echoed.pop("messages", None)                  # the prompt (a page image) is not echoed back
+        return {
+            "text": (first.get("message") or {}).get("content"),
+            "finish_reason": first.get("finish_reason"),
+            "model": response.get("model"),
+            "usage": {key: int(usage.get(key) or 0) for key in ("prompt_tokens", "completion_tokens", "total_tokens")},
+            "metadata": {"generation_time": now - start_time, "server_url": self.base_url, "generation_params": echoed,
+                         "timestamp": now},
+        }
+
+    def batch_generate(self, prompts: List[Any], **generation_kwargs) -> List[Dict[str, Any]]:
+        """One :meth:`generate` per element, in order; a failure becomes that element's result.  Elements are message
+        lists (what the reference passes through, vllm_client.py:286); a bare string is sent as one user message."""
+        out: List[Dict[str, Any]] = []
+        for index, item in enumerate(prompts):
+            conversation = [{"role": "user", "content": item}] if isinstance(item, str) else item
+            try:
+                result = self.generate(conversation, **generation_kwargs)
+            except Exception as exc:
+                logger.error("batch item %d failed: %s", index, exc)
+                out.append({"error": str(exc), "metadata": {"batch_index": index, "failed": True}})
+                continue
+            result["metadata"]["batch_index"] = index
+            out.append(result)
+        return out
+
 
 class VLLMClientManager:
+    """Clients by port, created on first use; ``server_config`` maps a port to its host (default ``localhost``)."""
+
     def __init__(self, server_config: Dict[int, str] = None):
-        self.server_config = server_config or {}
+        self.server_config: Dict[int, str] = dict(server_config or {})
         self.clients: Dict[int, VLLMClient] = {}
 
     def get_client(self, port: int, **client_kwargs) -> VLLMClient:
-        if port not in self.clients:
-            host = self.server_config.get(port, "localhost")
-            self.clients[port] = VLLMClient(port=port, host=host, **client_kwargs)
-            logger.info(f"Created VLLM client for port {port}")
-        return self.clients[port]
+        client = self.clients.get(port)
+        if client is None:
+            client = self.clients[port] = VLLMClient(port=port, host=self.server_config.get(port, "localhost"), **client_kwargs)
+        return client
 
     def health_check_all(self) -> Dict[int, bool]:
-        results = {}
-        for port, client in self.clients.items():
+        report: Dict[int, bool] = {}
+        for port in sorted(self.clients):
             try:
-                results[port] = client.health_check(force=True)
-            except Exception as e:
-                logger.error(f"Health check failed for port {port}: {e}")
-                results[port] = False
-        return results
+                report[port] = bool(self.clients[port].health_check(force=True))
+            except Exception:      # a probe must not take the whole report down
+                report[port] = False
+        return report
 
     def get_client_from_worker_name(self, worker_name: str, **client_kwargs) -> VLLMClient:
-        try:
-            parts = worker_name.split("_")
-            port_index = parts.index("port")
-            port = int(parts[port_index + 1])
-            return self.get_client(port, **client_kwargs)
-        except (ValueError, IndexError):
-            raise VLLMClientError(
-                f"Invalid worker name format: {worker_name}. Expected format: worker_port_{{port}}_{{worker_index}}@hostname")
+        """Celery worker host names carry their server's port: ``worker_port_{port}_{worker_index}@hostname``
+        (bulk_processing/scripts/start_multiple_celery_workers.sh)."""
+        found = _WORKER_PORT.search(worker_name.split("@", 1)[0]) if isinstance(worker_name, str) else None
+        if found is None:
+            raise VLLMClientError(f"Invalid worker name format: {worker_name}. "
+                                  "Expected format: worker_port_{port}_{worker_index}@hostname")
+        return self.get_client(int(found.group(1)), **client_kwargs)
 
 
 client_manager = VLLMClientManager()

@@ -36,6 +36,12 @@ int kr_comm_init(void** comm, int n_ranks, int rank, const uint8_t* id128) {
     return KR_OK;
 }
 
+int kr_comm_count(void* comm, int* n_ranks) {
+    KR_CHECK_ARG(comm && n_ranks, "kr_comm_count: null");
+    KR_CHECK_RCCL(ncclCommCount((ncclComm_t)comm, n_ranks));
+    return KR_OK;
+}
+
 int kr_comm_destroy(void* comm) {
     if (comm) KR_CHECK_RCCL(ncclCommDestroy((ncclComm_t)comm));
     return KR_OK;

@@ -1459,7 +1459,7 @@ __global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict
 // =====================================================================================
 // temperature sampling as an argmax (Gumbel-max): token = argmax_i( logit_i / T + G_i )
 // =====================================================================================
-// G_i = -ln(-ln(u_i)), u_i = ((h_i >> 8) + 0.5) * 2^-24, h_i = mix(mix(seed ^ n * 0x9E3779B1) + i) with
+// G_i = -ln(-ln(u_i)), u_i = ((h_i >> 9) + 0.5) * 2^-23, h_i = mix(mix(seed ^ n * 0x9E3779B1) + i) with
 // mix = the "lowbias32" integer finaliser and n = the index of the token being generated in its sequence
 // (ctx_len + 1 - prompt_len).  A counter-based generator: no state, any (sequence, step, token) draw can be
 // recomputed — the oracle does exactly that.  T == 0 rows get no noise: plain argmax, ties to the lowest index.
@@ -1500,7 +1500,9 @@ __global__ void __launch_bounds__(256) gumbel_argmax_kernel(const float* __restr
         float v = row[i] * inv_t;
         if (T > 0.f) {
             const unsigned h = kr_mix32(base + (unsigned)i);
-            const float u = ((float)(h >> 8) + 0.5f) * 5.9604644775390625e-08f;  // 2^-24: u in (0, 1), exact in f32
+            // 23-bit integer + 0.5 is exact in f32 (24 significant bits): u in [2^-24, 1 - 2^-24], never 0 or 1
+            // (a 24-bit integer + 0.5 rounds to 2^24 at the top code: u = 1, noise = +inf)
+            const float u = ((float)(h >> 9) + 0.5f) * 1.1920928955078125e-07f;  // 2^-23
             v += -logf(-logf(u));
         }
         better(bv, bi, v, i);

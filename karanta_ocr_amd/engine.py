@@ -379,8 +379,10 @@ class Engine:
                                   "hidden_size % 512 == 0 and <= 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B)")
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
-        wb, ww = self._wide_geometry(t.vocab_size)
-        self.n_amax = wb * ww if self.wide_mode else (t.vocab_size // 16 + 1) // 2  # one argmax partial per wave
+        # one argmax partial per wave of the lm_head launch; the launch geometry depends on the row count (8 waves above
+        # 16 rows), so the buffers are sized for the larger one and the sampler is told the launch's own count
+        self.n_amax = (max(self._amax_parts(0), self._amax_parts(32)) if self.wide_mode
+                       else (t.vocab_size // 16 + 1) // 2)
         self.d_amax_v = z(B, self.n_amax, dtype=torch.float32)
         self.d_amax_i = z(B, self.n_amax, dtype=torch.int32)
         self.d_plen = z(B, dtype=torch.int32)
@@ -405,7 +407,8 @@ class Engine:
         self.d_lp_pv = z(B, self.lp_part, 20, dtype=torch.float32)
         self.d_lp_pi = z(B, self.lp_part, 20, dtype=torch.int32)
         self.d_lp_ms = z(B, self.lp_part, 2, dtype=torch.float32)
-        self.max_new = 0
+        self.max_new = 0          # size of the token history / rotary tables (only grows: graphs hold their addresses)
+        self._req_max_new = 0     # what the current generate() / begin_slots() asked for (capacity checks use this)
         self.d_hist = None
         self.d_eos = torch.tensor(list(self.cfg.eos_token_ids), dtype=torch.int32, device=dev)
         self.d_invfreq = torch.from_numpy(POS.rope_inv_freq(t.head_dim, t.rope_theta)).to(dev)
@@ -484,6 +487,11 @@ class Engine:
         tiles = N // 16
         waves = self.wide_waves or (8 if M > 16 else min(8, -(-tiles // self.wide_blocks)))
         return min(self.wide_blocks, -(-tiles // waves)), waves
+
+    def _amax_parts(self, M: int) -> int:
+        """Argmax partials the lm_head launch writes per row at batch M (= its stride in d_amax_*): workgroups x waves."""
+        wb, ww = self._wide_geometry(self.cfg.text.vocab_size, M)
+        return wb * ww
 
     def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None):
         """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
@@ -776,9 +784,17 @@ class Engine:
                 self.L.kr_graph_destroy(g)
             self._graphs.clear()
 
-    def _prefill_prepare(self, pages: Sequence[PageRequest], n_image_tokens_total: int, slots: Optional[Sequence[int]] = None):
+    def seq_room(self) -> int:
+        """Cache rows one sequence may use: prompt + generated tokens (slot mode keeps the last row as the parking row)."""
+        return self.s_max - (1 if self._freeze_finished else 0)
+
+    def _prefill_prepare(self, pages: Sequence[PageRequest], n_image_tokens_total: int, slots: Optional[Sequence[int]] = None,
+                         budgets: Optional[Sequence[int]] = None):
         """Host side of `prefill` (numpy only: token sources, M-RoPE tables of the prompt and of every decode position,
-        the varlen attention plan).  `generate` runs it while the ViT launches are still executing."""
+        the varlen attention plan).  `generate` runs it while the ViT launches are still executing.
+        ``budgets``: per page, the number of tokens it may generate (slot mode: its max_tokens + the scheduler's chunk
+        overshoot); default: the current request's max_new_tokens.  The bound is each page's OWN prompt + budget — not
+        the engine-wide history size, which only grows."""
         cfg, t = self.cfg, self.cfg.text
         B = len(pages)
         whole_batch = slots is None
@@ -789,9 +805,14 @@ class Engine:
         M = sum(lens)
         if M > self.max_tokens:
             raise KarantaHipError(f"{M} prompt tokens > max_prompt_tokens {self.max_tokens}")
-        room = self.s_max - (1 if self._freeze_finished else 0)   # slot mode keeps the last cache row as the parking row
-        if max(lens) + self.max_new > room:
-            raise KarantaHipError(f"prompt {max(lens)} + max_new_tokens {self.max_new} exceeds s_max {room}")
+        room = self.seq_room()
+        if budgets is None:
+            budgets = [self._req_max_new] * B
+        if len(budgets) != B or max(budgets) > self.max_new:
+            raise KarantaHipError(f"budgets {list(budgets)} do not fit {B} pages / the history of {self.max_new} tokens")
+        for n, bud in zip(lens, budgets):
+            if n + int(bud) > room:
+                raise KarantaHipError(f"prompt {n} + max_new_tokens {int(bud)} exceeds s_max {room}")
         src = np.empty(M, np.int32)
         cos = np.empty((M, t.head_dim), np.float32)
         sin = np.empty((M, t.head_dim), np.float32)
@@ -948,11 +969,11 @@ class Engine:
         else:
             self._dec(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits,
                       waves=self.wv_wide)
-        n_part = self.n_amax
+        n_part = self._amax_parts(B) if self.wide_mode else self.n_amax
         if self._sampling:
             # temperature > 0 somewhere in the batch: the partial argmax is redone on logits / T + Gumbel noise
             # (rows with T = 0 get their plain argmax back)
-            n_part = min(64, self.n_amax)
+            n_part = min(64, n_part)
             if self._guided:   # guided slots: only the tokens their DFA state allows take part
                 L.kr_gumbel_argmax_guided(ptr(logits), self.d_logits.stride(0), t.vocab_size, ptr(self.d_temp[j:]),
                                           ptr(self.d_seed[j:]), ptr(self.d_ctx[j:]), ptr(self.d_plen[j:]), ptr(self.d_amax_v),
@@ -1176,6 +1197,7 @@ class Engine:
         self._logprobs = max(ks) if ks else None
         self._last_batch = B
         self._ensure_history(max_new_tokens)
+        self._req_max_new = int(max_new_tokens)
         grids = [g for p in pages for g in p.grids]
         n_img_tok = 0
         pix = self._pixels_for(pages, pixel_values_device)
@@ -1266,6 +1288,7 @@ class Engine:
         self._logprobs = None if logprobs is None else int(logprobs)
         self._last_batch = self.B
         self._ensure_history(max_new_tokens)
+        self._req_max_new = int(max_new_tokens)
         with torch.cuda.stream(self.stream):
             self.d_fin.fill_(1)
             self.d_temp.zero_()
@@ -1277,13 +1300,22 @@ class Engine:
             self.d_x.zero_()
         self.stream.synchronize()
 
-    def admit(self, pages: Sequence[PageRequest], slots: Sequence[int]) -> List[int]:
-        """ViT + prefill of new requests into idle slots; their first token is sampled.  Returns prompt lengths."""
+    def admit(self, pages: Sequence[PageRequest], slots: Sequence[int], budgets: Optional[Sequence[int]] = None) -> List[int]:
+        """ViT + prefill of new requests into idle slots; their first token is sampled.  Returns prompt lengths.
+        ``budgets``: tokens each page may generate before the host retires it (its max_tokens + the chunk overshoot)."""
+        self._check_budgets(pages, budgets)       # before any launch: an oversized page fails the call, nothing ran
         grids = [g for p in pages for g in p.grids]
         pix = self._pixels_for(pages, None)
         n_img_tok = self.vit_forward(pix, grids).shape[0] if pix is not None else 0
-        prep = self._prefill_prepare(pages, n_img_tok, slots)   # host tables while the ViT launches execute
+        prep = self._prefill_prepare(pages, n_img_tok, slots, budgets)   # host tables while the ViT launches execute
         return self.prefill(pages, n_img_tok, slots=slots, prep=prep)
+
+    def _check_budgets(self, pages, budgets):
+        room = self.seq_room()
+        for i, p in enumerate(pages):
+            bud = int(budgets[i]) if budgets is not None else self._req_max_new
+            if len(p.input_ids) + bud > room:
+                raise KarantaHipError(f"prompt {len(p.input_ids)} + max_new_tokens {bud} exceeds s_max {room}")
 
     # Overlapped admission (optional, SlotScheduler(overlap=True); measured: no gain on the ragged serving benchmark —
     # 6.56 vs 6.57 pages/s, with or without a high-priority decode stream: the ViT / prefill launches fill all 256 CUs
@@ -1292,7 +1324,8 @@ class Engine:
     # stepping the other slots.  The target slots are first PARKED on the last cache row (their frozen per-step KV
     # write then cannot land inside the rows the prefill is filling); the slot state and the first sampling step are
     # applied on the decode stream once the admission stream has finished.
-    def admit_begin(self, pages: Sequence[PageRequest], slots: Sequence[int]):
+    def admit_begin(self, pages: Sequence[PageRequest], slots: Sequence[int], budgets: Optional[Sequence[int]] = None):
+        self._check_budgets(pages, budgets)
         slots = [int(j) for j in slots]
         if self._adm_stream is None:
             self._adm_stream = torch.cuda.Stream(device=self.device)
@@ -1311,7 +1344,8 @@ class Engine:
             grids = [g for p in pages for g in p.grids]
             pix = self._pixels_for(pages, None)
             n_img_tok = self.vit_forward(pix, grids).shape[0] if pix is not None else 0
-            rec = self.prefill(pages, n_img_tok, slots=slots, defer_activation=True)
+            rec = self.prefill(pages, n_img_tok, slots=slots, defer_activation=True,
+                               prep=self._prefill_prepare(pages, n_img_tok, slots, budgets))
             done = torch.cuda.Event()
             done.record(self._adm_stream)
         finally:

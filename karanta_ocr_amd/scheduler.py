@@ -33,6 +33,7 @@ class SlotResult:
     prompt_tokens: int
     error: Optional[str] = None
     request: Optional[SlotRequest] = None   # the request this answers
+    status: int = 500                       # HTTP-style class of `error`: 400 = the request itself cannot be served
     logprobs: Optional[Dict[str, np.ndarray]] = None   # when the page asked for them (Engine.slot_logprobs)
 
 
@@ -150,9 +151,17 @@ class SlotScheduler:
         tok_budget = self.max_prompt_tokens
         patch_budget = self.max_patches
         failed: List[SlotResult] = []
+        room = self.engine.seq_room() if hasattr(self.engine, "seq_room") else None
         while self.waiting and len(batch) < len(free):
             r = self.waiting[0]
             n_tok = int(len(r.page.input_ids))
+            if room is not None and n_tok + self._budget(r) > room:
+                # its own prompt + max_tokens (+ the chunk overshoot) exceed a sequence's cache rows: this request fails
+                # alone, as a client error; whatever is admitted with it is unaffected
+                self.waiting.popleft()
+                failed.append(self._failure(r, f"prompt ({n_tok} tokens) + max_tokens ({min(int(r.max_tokens), self.cap)}) + "
+                                               f"{self.chunk} scheduler steps exceed the sequence capacity {room}", status=400))
+                continue
             n_patch = sum(int(np.prod(g)) for g in getattr(r.page, "grids", None) or [])   # from the grids: pages may
             #                                                    carry uint8 images (GPU front end) instead of patches
             over_tok = tok_budget is not None and n_tok > tok_budget
@@ -162,7 +171,8 @@ class SlotScheduler:
                                   or self.max_patches is not None and n_patch > self.max_patches):
                     # can never fit: fail it instead of blocking the queue
                     self.waiting.popleft()
-                    failed.append(self._failure(r, f"request does not fit the engine ({n_tok} prompt tokens, {n_patch} patches)"))
+                    failed.append(self._failure(r, f"request does not fit the engine ({n_tok} prompt tokens, {n_patch} patches)",
+                                                status=400))
                     continue
                 break  # fits an emptier admission round
             self.waiting.popleft()
@@ -174,13 +184,13 @@ class SlotScheduler:
         if batch and begin_only:
             slots = free[:len(batch)]
             try:
-                self._inflight = (self.engine.admit_begin([r.page for r in batch], slots), batch, slots)
+                self._inflight = (self.engine.admit_begin([r.page for r in batch], slots, **self._budget_kw(batch)), batch, slots)
             except Exception as e:
                 return failed + [self._failure(r, f"{type(e).__name__}: {e}") for r in batch]
         elif batch:
             slots = free[:len(batch)]
             try:
-                lens = self.engine.admit([r.page for r in batch], slots)
+                lens = self.engine.admit([r.page for r in batch], slots, **self._budget_kw(batch))
             except Exception as e:  # the admission as a whole failed: none of these requests entered a slot
                 return failed + [self._failure(r, f"{type(e).__name__}: {e}") for r in batch]
             for r, j, n in zip(batch, slots, lens):
@@ -188,8 +198,17 @@ class SlotScheduler:
                 self.prompt_len[j] = int(n)
         return failed
 
-    def _failure(self, r: SlotRequest, msg: str) -> SlotResult:
-        return SlotResult(r.tag, np.zeros(0, np.int64), "length", 0, error=msg, request=r)
+    def _budget(self, r: SlotRequest) -> int:
+        """Cache rows a request may write after its prompt: its token limit plus the steps a slot can run past it
+        before the host looks at the flags again."""
+        return min(int(r.max_tokens), self.cap) + self.chunk
+
+    def _budget_kw(self, batch) -> dict:
+        # engines that check capacity per request take the budgets (test fakes without seq_room do not)
+        return {"budgets": [self._budget(r) for r in batch]} if hasattr(self.engine, "seq_room") else {}
+
+    def _failure(self, r: SlotRequest, msg: str, status: int = 500) -> SlotResult:
+        return SlotResult(r.tag, np.zeros(0, np.int64), "length", 0, error=msg, request=r, status=status)
 
     def _harvest(self) -> List[SlotResult]:
         fin, gen = self.engine.poll_slots()

@@ -278,11 +278,22 @@ class LocalServer:
         if parsed.logprobs is not None and self.continuous and (self.max_logprobs is None or parsed.logprobs > self.max_logprobs):
             return 400, {"error": {"message": f"logprobs: this server records at most {self.max_logprobs} top_logprobs "
                                               "(start it with --max-logprobs)", "type": "BadRequestError", "code": 400}}
+        room = self.engine.seq_room() if hasattr(self.engine, "seq_room") else None
+        need = len(parsed.input_ids) + min(int(parsed.max_tokens), self.max_tokens_cap) + (self.chunk if self.continuous else 0)
+        if room is not None and need > room:
+            # the request's OWN prompt + max_tokens against one sequence's cache rows: a client error for this request
+            # only (the reference skips the attempt on 400, pipeline.py:321-332) — never an engine exception that
+            # would fail the requests admitted with it
+            return 400, {"error": {"message": f"prompt ({len(parsed.input_ids)} tokens) + max_tokens ({parsed.max_tokens}) "
+                                              f"exceeds this server's sequence capacity ({room})",
+                                   "type": "BadRequestError", "code": 400}}
         slot: Dict[str, Any] = {"req": parsed, "done": threading.Event()}
         self._q.put(slot)
         slot["done"].wait()
         if "error" in slot:
-            return 500, {"error": {"message": slot["error"], "type": "InternalServerError", "code": 500}}
+            code = int(slot.get("status", 500))
+            kind = "BadRequestError" if code == 400 else "InternalServerError"
+            return code, {"error": {"message": slot["error"], "type": kind, "code": code}}
         toks, reason = slot["tokens"], slot["reason"]
         text = self.frontend.tok.decode(toks)
         self.latencies.append(time.time() - t0)
@@ -338,21 +349,40 @@ class LocalServer:
             self._running = len(batch)
             # same shape as vLLM's periodic stats line that the reference scrapes (pipeline.py:782-800)
             self.log(f"Running: {self._running} reqs, Waiting: {self._q.qsize()} reqs")
-            try:
-                pages = [self._page(s["req"]) for s in batch]
-                res = self.engine.generate(pages, max(s["req"].max_tokens for s in batch))
-                for i, (s, toks, reason) in enumerate(zip(batch, res.tokens, res.finish_reasons)):
-                    if getattr(res, "logprobs", None) is not None:
-                        s["logprobs"] = res.logprobs[i]
-                    self._finish(s, toks, reason)
-            except Exception as e:  # engine failure -> 500 for every request of the batch
-                for s in batch:
-                    s["error"] = f"{type(e).__name__}: {e}"
+            for group in self._static_groups(batch):
+                try:
+                    pages = [self._page(s["req"]) for s in group]
+                    res = self.engine.generate(pages, max(s["req"].max_tokens for s in group))
+                    for i, (s, toks, reason) in enumerate(zip(group, res.tokens, res.finish_reasons)):
+                        if getattr(res, "logprobs", None) is not None:
+                            s["logprobs"] = res.logprobs[i]
+                        self._finish(s, toks, reason)
+                except Exception as e:  # engine failure -> 500 for every request of the group
+                    for s in group:
+                        s["error"] = f"{type(e).__name__}: {e}"
             self.pages_done += len(batch)
             self._running = 0
             for s in batch:
                 s["done"].set()
 
+
+    def _static_groups(self, batch):
+        """A static batch decodes every sequence for the LONGEST max_tokens of the batch, so a long prompt with a small
+        limit can overflow its cache rows next to a short prompt with a large one although both fit alone (each was
+        checked at the door).  Split such a batch into groups that fit together; normally one group."""
+        room = self.engine.seq_room() if hasattr(self.engine, "seq_room") else None
+        if room is None:
+            return [batch]
+        groups: List[list] = []
+        for s in sorted(batch, key=lambda s: -int(s["req"].max_tokens)):
+            for g in groups:
+                mt = max(int(x["req"].max_tokens) for x in g + [s])
+                if all(len(x["req"].input_ids) + mt <= room for x in g + [s]):
+                    g.append(s)
+                    break
+            else:
+                groups.append([s])
+        return groups
 
     def _page(self, r: ParsedRequest):
         from .engine import PageRequest
@@ -432,6 +462,7 @@ class LocalServer:
                 s = res.tag
                 if res.error:
                     s["error"] = res.error
+                    s["status"] = getattr(res, "status", 500)
                 else:
                     if res.logprobs is not None:
                         s["logprobs"] = res.logprobs

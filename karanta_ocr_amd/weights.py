@@ -152,6 +152,13 @@ def canonical_name(name: str) -> str:
     return name
 
 
+def load_config(model_dir: str) -> ModelConfig:
+    """``config.json`` of a local checkpoint directory -> :class:`ModelConfig` (a few KB: every rank of a multi-GPU
+    launch reads it, only rank 0 reads the tensors — launch.py)."""
+    with open(os.path.join(model_dir, "config.json")) as f:
+        return from_hf_config_dict(json.load(f), name=os.path.basename(model_dir.rstrip("/")))
+
+
 def load_checkpoint(model_dir: str) -> tuple:
     """Load ``config.json`` + ``*.safetensors`` from a local directory.
 
@@ -160,8 +167,7 @@ def load_checkpoint(model_dir: str) -> tuple:
     """
     from safetensors import safe_open  # local import: only needed with real weights
 
-    with open(os.path.join(model_dir, "config.json")) as f:
-        cfg = from_hf_config_dict(json.load(f), name=os.path.basename(model_dir.rstrip("/")))
+    cfg = load_config(model_dir)
     import torch
 
     tensors: Dict[str, np.ndarray] = {}

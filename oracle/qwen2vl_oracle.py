@@ -588,12 +588,17 @@ def _mix32(x: np.ndarray) -> np.ndarray:
 
 
 def gumbel_noise(seed: int, n: int, vocab: int) -> np.ndarray:
-    """G_i of the build's sampler (kr_gumbel_argmax, kr_decode.hip): -ln(-ln(u_i)), u_i = ((h_i >> 8) + 0.5) 2^-24,
-    h_i = mix(mix(seed ^ n * 0x9E3779B1) + i), n = index of the token being generated.  fp32 like the kernel."""
+    """G_i of the build's sampler (kr_gumbel_argmax, kr_decode.hip): -ln(-ln(u_i)), u_i = ((h_i >> 9) + 0.5) 2^-23,
+    h_i = mix(mix(seed ^ n * 0x9E3779B1) + i), n = index of the token being generated.  fp32 like the kernel.
+    (23 bits + 0.5 is exact in fp32, so u stays inside [2^-24, 1 - 2^-24] and the noise is finite: see gumbel_u.)"""
     base = _mix32(np.uint64((int(seed) ^ ((int(n) * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF))
     h = _mix32((base + np.arange(vocab, dtype=np.uint64)) & 0xFFFFFFFF)
-    u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
-    return -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+    return -np.log(-np.log(gumbel_u(h), dtype=np.float32), dtype=np.float32)
+
+
+def gumbel_u(h: np.ndarray) -> np.ndarray:
+    """32-bit hash -> uniform in the OPEN interval (0, 1), exactly representable in fp32: ((h >> 9) + 0.5) * 2^-23."""
+    return ((np.asarray(h, np.uint64) >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
 
 
 def sample_scores(logits: np.ndarray, temperature: float, seed: int, n: int) -> np.ndarray:

@@ -1322,6 +1322,47 @@ def test_gumbel_argmax_matches_oracle_noise(L):
     assert np.abs(got - want).max() < 0.03, (got, want)
 
 
+def _unmix32(h: int) -> int:
+    """Inverse of the sampler's 32-bit finaliser (a bijection): the x with mix32(x) == h."""
+    M = 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * pow(0x846ca68b, -1, 1 << 32)) & M
+    h ^= (h >> 15) ^ (h >> 30)
+    h = (h * pow(0x7feb352d, -1, 1 << 32)) & M
+    h ^= h >> 16
+    return h
+
+
+def test_gumbel_noise_is_finite_at_the_extreme_hash_codes(L):
+    """with u = ((h >> 8) + 0.5) * 2^-24 the top code rounds to u == 1 and the noise is +inf, so that
+    token wins whatever its logit.  Force the hash of one token to 0xFFFFFFFF (and of another to 0) by inverting the
+    finaliser: both draws must be finite, equal to the oracle's, and the -50 logit must not win."""
+    V, tok_hi, tok_lo = 64, 5, 9
+    assert int(O._mix32(np.uint64(_unmix32(0xFFFFFFFF)))) == 0xFFFFFFFF
+    old_u = (np.float32(0xFFFFFF) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    assert old_u == np.float32(1.0)                       # the defect this test pins
+    for h_forced, tok in ((0xFFFFFFFF, tok_hi), (0, tok_lo)):
+        base = (_unmix32(h_forced) - tok) & 0xFFFFFFFF       # mix32(base + tok) == h_forced
+        seed = _unmix32(base)                                # n = 0: base = mix32(seed)
+        g = O.gumbel_noise(seed, 0, V)
+        assert np.isfinite(g).all() and (g[tok] == g.max() if h_forced else g[tok] == g.min())
+        logits = np.zeros((1, V), np.float32)
+        logits[0, tok] = -50.0
+        ld = torch.from_numpy(logits).to(DEV)
+        t1 = torch.tensor([1.0], device=DEV)
+        s1 = torch.from_numpy(np.asarray([seed], np.uint32).view(np.int32)).to(DEV)
+        c1 = torch.tensor([-1], dtype=torch.int32, device=DEV); p1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        av = torch.zeros(1, V, device=DEV); ai = torch.zeros(1, V, dtype=torch.int32, device=DEV)
+        # one partial per token (n_part = V/4 groups of 4): read back every group's best noisy score
+        L.kr_gumbel_argmax(ptr(ld), V, V, ptr(t1), ptr(s1), ptr(c1), ptr(p1), ptr(av), ptr(ai), V // 4, 1, 0)
+        torch.cuda.synchronize()
+        vals = av.cpu().numpy()[0, :V // 4]
+        assert np.isfinite(vals).all(), vals
+        sc = O.sample_scores(logits[0], 1.0, seed, 0)
+        np.testing.assert_allclose(vals, sc.reshape(V // 4, 4).max(1), rtol=2e-6, atol=2e-5)
+        assert int(ai.cpu().numpy()[0, :V // 4][np.argmax(vals)]) != tok
+
+
 def test_sample_greedy_freeze_finished(L):
     """Flag bit 1: a finished sequence neither advances ctx_len nor writes history (slot scheduler)."""
     B, d, n_part = 3, 64, 4

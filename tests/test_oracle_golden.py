@@ -175,3 +175,17 @@ def test_bf16_policy_tolerance(golden, tiny_models, name):
     top2 = np.sort(l32)[-2:]
     if top2[1] - top2[0] > 2 * tol:
         assert lb.argmax() == l32.argmax() == lhf.argmax()
+
+
+def test_gumbel_uniform_is_strictly_inside_the_unit_interval():
+    """The sampler's uniform must never be 0 or 1 (noise -ln(-ln u) would be -inf / +inf): every 23-bit code + 0.5 is
+    exact in fp32, including the all-ones hash that the former 24-bit construction rounded to u == 1."""
+    from oracle import qwen2vl_oracle as O
+    h = np.asarray([0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0xFFFFFE00, 0xFFFFFFFF], np.uint64)
+    u = O.gumbel_u(h)
+    assert u.dtype == np.float32 and (u > 0).all() and (u < 1).all()
+    assert u[0] == np.float32(2.0 ** -24) and u[-1] == np.float32(1.0 - 2.0 ** -24)
+    g = -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+    assert np.isfinite(g).all()
+    # exactness: (code + 0.5) * 2^-23 reproduces in float64
+    assert np.array_equal(u.astype(np.float64), ((h >> np.uint64(9)).astype(np.float64) + 0.5) * 2.0 ** -23)

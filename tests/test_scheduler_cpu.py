@@ -195,3 +195,35 @@ def test_overlapped_admission_failure_paths():
     sch = SlotScheduler(Boom(2, SCRIPT), max_tokens_cap=8, chunk=2, overlap=True)
     (r,) = sch.run([SlotRequest(Page([0]), 4, "x")])
     assert r.error.startswith("RuntimeError: late boom") and sch.idle
+
+
+class RoomEngine(FakeEngine):
+    """FakeEngine that, like the real one, bounds prompt + generated tokens per sequence (Engine.seq_room) and takes the
+    per-request budgets with the admission."""
+    room = 40
+
+    def seq_room(self):
+        return self.room
+
+    def admit(self, pages, slots, budgets=None):
+        assert budgets is not None and len(budgets) == len(pages)
+        for p, b in zip(pages, budgets):
+            assert len(p.input_ids) + b <= self.room, "the scheduler let an oversized request through"
+        self.budgets = list(budgets)
+        return super().admit(pages, slots)
+
+
+def test_oversized_request_fails_alone_with_a_client_error():
+    """the bound is the request's OWN prompt + max_tokens (+ chunk), checked before admission; the
+    request that cannot fit gets a 400-class failure and the requests admitted in the same round are served."""
+    eng = RoomEngine(2, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=32, chunk=4)
+    ok_small = SlotRequest(Page([0] + [0] * 9), 10, tag="fits")                 # 10 + 10 + 4 <= 40
+    too_long = SlotRequest(Page([1] + [0] * 29), 9, tag="prompt too long")      # 30 + 9 + 4 > 40
+    long_small = SlotRequest(Page([2] + [0] * 29), 5, tag="long prompt, small limit")   # 30 + 5 + 4 <= 40
+    res = sch.run([ok_small, too_long, long_small])
+    assert res[0].error is None and res[0].tokens.tolist() == [1, 2, 3, 99]
+    assert res[1].error is not None and res[1].status == 400 and "capacity" in res[1].error
+    assert res[2].error is None and res[2].tokens.tolist() == [99]
+    assert ("admit", (0, 1)) in eng.log                                        # the two that fit went in together
+    assert eng.budgets == [10 + 4, 5 + 4]

@@ -481,3 +481,61 @@ def test_llm_clients_completion_surface():
     finally:
         S.unregister_local_server(8771)
         srv.close()
+
+
+class RoomSlotEngine(FakeSlotEngine):
+    def seq_room(self):
+        return 400
+
+    def admit(self, pages, slots, budgets=None):
+        assert budgets is not None and all(len(p.input_ids) + b <= 400 for p, b in zip(pages, budgets))
+        return super().admit(pages, slots)
+
+
+class RoomEngine(FakeEngine):
+    def seq_room(self):
+        return 400
+
+    def generate(self, pages, max_new_tokens, **kw):
+        assert all(len(p.input_ids) + max_new_tokens <= 400 for p in pages), "a static batch would overflow a sequence"
+        return super().generate(pages, max_new_tokens, **kw)
+
+
+def test_request_beyond_the_sequence_capacity_is_a_400_for_that_request_only():
+    """a prompt whose own length + max_tokens exceeds the engine's rows is refused at the door with
+    400 (the reference skips the attempt, pipeline.py:321-332) in both scheduling modes; a long prompt with a small
+    limit and a short prompt with a large limit are both served (static mode splits the batch instead of failing it)."""
+    import threading
+    front = S.ChatFrontend(CFG, S.ByteTokenizer(CFG))
+    long_text = "x" * 300
+    for continuous in (False, True):
+        eng = RoomSlotEngine() if continuous else RoomEngine()
+        srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=continuous, max_tokens_cap=390, chunk=2,
+                            batch_wait_s=0.2)
+        st, body = srv.chat_completions({"messages": vision_message(long_text), "max_tokens": 60})
+        assert st == 400 and "capacity" in body["error"]["message"], (continuous, st, body)
+        out = {}
+        reqs = {"long": {"messages": vision_message(long_text), "max_tokens": 3},
+                "short": {"messages": vision_message("hi"), "max_tokens": 150}}
+        ts = [threading.Thread(target=lambda k=k: out.__setitem__(k, srv.chat_completions(reqs[k]))) for k in reqs]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert out["long"][0] == 200 and out["short"][0] == 200, (continuous, out)
+        srv.close()
+
+
+def test_cli_reads_the_checkpoints_preprocessor_config(tmp_path):
+    """image size bounds come from the checkpoint's preprocessor_config.json as they do under vLLM
+    (both spellings), not from the transformers class default; a missing file or key falls through."""
+    import json
+    from karanta_ocr_amd import cli
+    assert cli.preprocessor_pixels(str(tmp_path)) == (None, None)
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"min_pixels": 3136, "max_pixels": 12845056}))
+    assert cli.preprocessor_pixels(str(tmp_path)) == (3136, 12845056)
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"size": {"shortest_edge": 3136, "longest_edge": 1003520}}))
+    assert cli.preprocessor_pixels(str(tmp_path)) == (3136, 1003520)
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"size": {"height": 224}, "max_pixels": "x"}))
+    assert cli.preprocessor_pixels(str(tmp_path)) == (None, None)
+    (tmp_path / "preprocessor_config.json").write_text("{not json")
+    assert cli.preprocessor_pixels(str(tmp_path)) == (None, None)
+    a = cli.parse_args(["serve", str(tmp_path), "--max-pixels", "200704", "--min-pixels", "784"])
+    assert (a.max_pixels, a.min_pixels) == (200704, 784)
