@@ -8,12 +8,14 @@
 Workload (BASELINE.json configs[1]): Qwen2-VL-2B bf16, batch = 8 synthetic 1024x1024 scans per GPU,
 greedy, fixed T_out decode (ignore-EOS throughput mode), seeded random-init weights
 of the real architecture (no checkpoints exist offline).  A "step" is one pass of the hot path over
-one batch: ViT -> scatter -> prefill -> T_out greedy decode steps.  The timed region starts with the
-pages' pixel_values already resident in HBM.
+one batch: GPU image front end (bicubic resize, normalise, patchify) -> ViT -> scatter -> prefill -> T_out greedy
+decode steps.  The timed region starts with the pages resident in HBM as uint8 RGB images (what a decoded PNG is).
 
 Multi-GPU: pure data parallel (one process per GPU, disjoint pages, no steady-state collective);
 the only collective is the one-time RCCL broadcast of the packed weight arena from rank 0
-(kr_bcast_weights), timed separately.  `scaling` is therefore "weak".
+(kr_bcast_weights), timed separately.  `scaling` is therefore "weak".  `python bench.py --gpus N` starts its own
+N ranks (fresh child processes, before anything touches the GPU) when it was not started by torch.distributed.run;
+a rank that fails — the RCCL broadcast included, there is no fallback — makes the whole run exit non-zero.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     — the decode gate/up GEMV (half of the decoder's HBM bytes) timed live with HIP events
@@ -53,28 +55,32 @@ def build_prompt(cfg, n_image_tokens: int, rng) -> np.ndarray:
     return np.minimum(ids, cfg.text.vocab_size - 1)
 
 
-def cpu_baseline(cfg, pv_page: np.ndarray, grid, ids: np.ndarray, t_out: int) -> dict:
-    """Oracle (numpy) on the host cores, bounded sample: the 2B architecture truncated to 2 ViT blocks
-    and 2 decoder layers (full widths, full vocabulary), one 1024x1024 page, 8 decode tokens (median); per-block
-    and per-layer times are measured by differencing against a 1-block / 1-layer run and extrapolated
-    linearly to the full depth (32 blocks, 28 layers) and to T_out tokens."""
+def cpu_baseline(cfg, pv_page: np.ndarray, grid, ids: np.ndarray, t_out: int, weights=None) -> dict:
+    """Oracle (numpy) on the host cores, one 1024x1024 page of the bench workload.
+
+    With the full model's weights at hand (rank 0 has just generated them for the GPU) and enough host cores, the
+    sample is the WHOLE model: every ViT block, every decoder layer of the prefill and N_DEC decode tokens are
+    measured, nothing about the depth is extrapolated — only the decode length (per-token median x T_out).
+    Otherwise (small hosts): the architecture truncated to 2 ViT blocks + 2 decoder layers (full widths, full
+    vocabulary), per-block / per-layer times by differencing against a 1-block / 1-layer run, extrapolated linearly
+    to the full depth; `sample` says which of the two ran."""
     from karanta_ocr_amd.weights import random_weights
     from oracle import qwen2vl_oracle as O  # checker / baseline only
 
     t_start = time.perf_counter()
-    small = dataclasses.replace(cfg, vision=dataclasses.replace(cfg.vision, depth=2),
-                                text=dataclasses.replace(cfg.text, num_layers=2))
-    w = random_weights(small, 7)
+    N_DEC = 8
+    try:  # BLAS threads = this job's CPU share (16 cores per GPU on the bench boxes), not every core of the host
+        import threadpoolctl
+        cores = min(16, os.cpu_count() or 1)
+        limiter = threadpoolctl.threadpool_limits(limits=cores)
+    except Exception:
+        limiter, cores = None, os.cpu_count() or 1
+    full = weights is not None and cores >= 12 and os.environ.get("KARANTA_CPU_BASELINE", "full") == "full"
 
-    def vit(depth):
-        t0 = time.perf_counter()
-        out = O.vit_forward(pv_page, [grid], w, dataclasses.replace(small.vision, depth=depth))
-        return time.perf_counter() - t0, out
-
-    def llm(layers, img):
-        tc = dataclasses.replace(small.text, num_layers=layers)
-        emb = O.embed_and_scatter(ids[None], img, w, small)
-        pos, delta = O.get_rope_index(ids[None], [grid], small.image_token_id, 2)
+    def llm(w, mcfg, layers, img):
+        tc = dataclasses.replace(mcfg.text, num_layers=layers)
+        emb = O.embed_and_scatter(ids[None], img, w, mcfg)
+        pos, delta = O.get_rope_index(ids[None], [grid], mcfg.image_token_id, 2)
         cache = O.KVCache.empty(layers)
         t0 = time.perf_counter()
         logits = O.decoder_forward(emb, pos, w, tc, cache)
@@ -83,50 +89,167 @@ def cpu_baseline(cfg, pv_page: np.ndarray, grid, ids: np.ndarray, t_out: int) ->
         for s in range(N_DEC):
             t0 = time.perf_counter()
             nxt = logits.argmax(-1)
-            e = O.embed_and_scatter(nxt[:, None], None, w, small)
+            e = O.embed_and_scatter(nxt[:, None], None, w, mcfg)
             ppos = np.tile((len(ids) + s + delta)[None, :, None], (3, 1, 1))
             logits = O.decoder_forward(e, ppos, w, tc, cache)
             per_tok.append(time.perf_counter() - t0)
         return t_pre, float(np.median(per_tok))   # median: the host is shared, single tokens get preempted
 
-    N_DEC = 8
-    try:  # BLAS threads = this job's CPU share (16 cores per GPU on the bench boxes), not every core of the host
-        import threadpoolctl
-        cores = min(16, os.cpu_count() or 1)
-        limiter = threadpoolctl.threadpool_limits(limits=cores)
-    except Exception:
-        limiter, cores = None, os.cpu_count() or 1
-    v2, img = vit(2)
-    v1, _ = vit(1)
-    p2, d2 = llm(2, img)
-    p1, d1 = llm(1, img)
+    if full:
+        t0 = time.perf_counter()
+        img = O.vit_forward(pv_page, [grid], weights, cfg.vision)
+        t_vit = time.perf_counter() - t0
+        t_pre, t_dec = llm(weights, cfg, cfg.text.num_layers, img)
+        how = (f"FULL depth measured ({cfg.vision.depth} ViT blocks, {cfg.text.num_layers} decoder layers): vit {t_vit:.1f}s + prefill "
+               f"{t_pre:.1f}s + decode {t_dec*1e3:.0f} ms/token (median of {N_DEC} tokens at ctx ~{len(ids)}); only T_out={t_out} is "
+               f"extrapolated (per-token x T_out)")
+    else:
+        small = dataclasses.replace(cfg, vision=dataclasses.replace(cfg.vision, depth=2),
+                                    text=dataclasses.replace(cfg.text, num_layers=2))
+        w = random_weights(small, 7)
+
+        def vit(depth):
+            t0 = time.perf_counter()
+            out = O.vit_forward(pv_page, [grid], w, dataclasses.replace(small.vision, depth=depth))
+            return time.perf_counter() - t0, out
+
+        v2, img = vit(2)
+        v1, _ = vit(1)
+        p2, d2 = llm(w, small, 2, img)
+        p1, d1 = llm(w, small, 1, img)
+        vit_blk, pre_l, dec_l = max(v2 - v1, 0.0), max(p2 - p1, 0.0), max(d2 - d1, 0.0)
+        t_vit = (v1 - vit_blk) + cfg.vision.depth * vit_blk
+        t_pre = (p1 - pre_l) + cfg.text.num_layers * pre_l
+        t_dec = (d1 - dec_l) + cfg.text.num_layers * dec_l
+        how = (f"{cfg.name} widths TRUNCATED to 2 ViT blocks + 2 decoder layers, {N_DEC} decode tokens (median); extrapolated "
+               f"linearly to {cfg.vision.depth} blocks / {cfg.text.num_layers} layers / T_out={t_out}: vit {t_vit:.1f}s + prefill "
+               f"{t_pre:.1f}s + decode {t_dec*1e3:.0f} ms/token")
     if limiter is not None:
         limiter.restore_original_limits()
-    vit_blk, pre_l, dec_l = max(v2 - v1, 0.0), max(p2 - p1, 0.0), max(d2 - d1, 0.0)
-    t_vit = (v1 - vit_blk) + cfg.vision.depth * vit_blk
-    t_pre = (p1 - pre_l) + cfg.text.num_layers * pre_l
-    t_dec = (d1 - dec_l) + cfg.text.num_layers * dec_l
     t_page = t_vit + t_pre + t_out * t_dec
     return {
         "value": 1.0 / t_page, "unit": "pages/s", "cores": int(cores), "kind": "port",
         "sample": (f"oracle/qwen2vl_oracle.py (numpy fp32, BLAS threads={cores}), 1 page 1024x1024 ({grid[1]}x{grid[2]} patches, "
-                   f"P={len(ids)}), Qwen2-VL-2B widths truncated to 2 ViT blocks + 2 decoder layers, {N_DEC} decode tokens (median); "
-                   f"extrapolated linearly to 32 blocks / 28 layers / T_out={t_out}: vit {t_vit:.1f}s + prefill {t_pre:.1f}s + "
-                   f"decode {t_dec*1e3:.0f} ms/token; sample wall {time.perf_counter()-t_start:.0f}s"),
+                   f"P={len(ids)}); {how}; sample wall {time.perf_counter()-t_start:.0f}s"),
     }
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed PMC pass (None if absent)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            ks = json.load(f)["kernels"]
-        for name, v in ks.items():
-            if "dec_wide_kernel<4" in name:   # <EPI=SILU8, K/64>: the gate/up launch
-                return v["hbm_read_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    """(HBM bytes per launch of the roofline kernel, file) from the newest committed PMC pass; (None, None) if absent."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                ks = json.load(f)["kernels"]
+            for kname, v in ks.items():
+                if "dec_wide_kernel<4" in kname:   # <EPI=SILU8, K/64>: the gate/up launch
+                    return v["hbm_read_bytes_per_launch"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+class stdout_to_stderr:
+    """File-descriptor level: native libraries (gloo's "[Gloo] Rank 0 is connected ..." banner) print to fd 1, and
+    rank 0's stdout must carry exactly ONE line, the JSON."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
+def spawn_ranks(n: int, argv, script: str = None, env=None, grace_s: float = 15.0) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, HIP_VISIBLE_DEVICES untouched), relay rank 0's stdout (the JSON line),
+    let the other ranks' stdout go to stderr, and return non-zero if ANY rank does.  When one rank dies the others are
+    terminated by PID after `grace_s` (they would otherwise wait in a collective forever).  Nothing here imports torch
+    or touches the GPU: the children are ordinary processes, not an exec of an initialised one."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+    out0: list = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    first_bad = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad = time.time()
+        if first_bad is not None and time.time() - first_bad > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    if out0 and out0[0]:
+        for line in out0[0].decode("utf-8", "replace").splitlines():
+            # only the JSON line is the result; anything else a library wrote to rank 0's stdout is log output
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+        sys.stdout.flush()
+    codes = [p.returncode for p in procs]
+    if any(c != 0 for c in codes):
+        print(f"[bench] rank exit codes {codes}: the run is INVALID", file=sys.stderr, flush=True)
+        return next(c for c in codes if c != 0) or 1
+    return 0
+
+
+def dry_run(args, rank: int, world: int) -> None:
+    """The N-rank control plane without an engine (CPU only; gloo): what every rank does around the timed region."""
+    import torch
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.all_reduce(torch.zeros(1))
+
+    if os.environ.get("KARANTA_BENCH_DRY_FAIL_RANK") == str(rank):      # tests: a rank that dies before the barrier
+        raise SystemExit(7)
+    from karanta_ocr_amd.dp import shard_pages
+    mine = list(shard_pages(world * args.batch, world, rank))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))          # rank-dependent "work": the MAX over ranks must win
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        counts = [None] * world
+        dist.all_gather_object(counts, len(mine))
+    else:
+        counts = [len(mine)]
+    if rank == 0:
+        print(json.dumps({"metric": "pages_per_sec", "dry_run": True, "value": None, "unit": "pages/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 2),
+                          "pages_per_rank": counts, "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.all_reduce(torch.zeros(1))
+        dist.destroy_process_group()
 
 
 def main():
@@ -149,25 +272,40 @@ def main():
     ap.add_argument("--decode-splits", type=int, default=8)
     ap.add_argument("--weights", default="bf16", choices=("bf16", "fp8"),
                     help="fp8: decoder Linears as e4m3fn codes + per-row scales (BASELINE.json config 5); activations stay bf16")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the N-rank control plane (self-launch, rendezvous, barriers, max-over-ranks timing, "
+                         "rank 0's JSON line, exit codes) with no engine: the line carries \"dry_run\": true and no measurement")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torch.distributed.run: start the N ranks ourselves, BEFORE torch is imported or the GPU is touched
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal of the N > 1 control flow) ranks share devices
-    local_rank %= max(1, torch.cuda.device_count())
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         # control plane (barriers, the RCCL unique id, max-over-ranks timing) over gloo on CPU tensors; the
         # data plane — the one-time weight broadcast — is RCCL through the C-ABI (kr_bcast_weights)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.all_reduce(torch.zeros(1))      # the first collective connects the pairs (and prints gloo's banner)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    n_dev = torch.cuda.device_count()
+    if world > 1 and n_dev < world and os.environ.get("KARANTA_BENCH_SHARE_GPUS") != "1":
+        # RCCL cannot put two ranks on one device (ncclCommInitRank fails): refuse instead of producing a number that
+        # is not an N-GPU number.  KARANTA_BENCH_SHARE_GPUS=1 is a control-flow rehearsal and is labelled as such.
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {n_dev}")
+    local_rank %= max(1, n_dev)
+    if world > 1:
+        torch.cuda.set_device(local_rank)
 
     from karanta_ocr_amd import image_processing as IP
     from karanta_ocr_amd._lib import lib, ptr
@@ -182,21 +320,29 @@ def main():
 
     # ---------------- inputs: synthetic scans -> patches (host) -> HBM
     t0 = time.perf_counter()
-    pvs, grids = [], []
+    pvs, grids, page_imgs = [], [], []
     for i in range(B):
-        pv, g = IP.image_to_patches(IP.synthetic_page(rank * B + i, args.page, args.page_width or args.page), max_pixels=args.max_pixels)
-        pvs.append(pv)
+        im = IP.synthetic_page(rank * B + i, args.page, args.page_width or args.page)
+        page_imgs.append(im)
+        if i == 0 and rank == 0:      # host-side patches of page 0: the CPU baseline's input (same pixels as the GPU's)
+            pv, g = IP.image_to_patches(im, max_pixels=args.max_pixels)
+            pvs.append(pv)
+        else:
+            rh, rw = IP.smart_resize(im.shape[0], im.shape[1], 28, IP.MIN_PIXELS, args.max_pixels)
+            g = (1, rh // 14, rw // 14)
         grids.append(g)
     n_img_tok = [g[1] * g[2] // 4 for g in grids]
     rng = np.random.default_rng(1234 + rank)
-    pages = [PageRequest(build_prompt(cfg, n_img_tok[i], rng), None, [grids[i]]) for i in range(B)]
+    # the pages enter the timed region as uint8 RGB images resident in HBM (3 MB per 1024x1024 page): resize,
+    # normalisation and patch order run on the GPU inside every step (PageRequest.images, kr_image_*)
+    imgs_dev = [torch.from_numpy(np.ascontiguousarray(im)).to(f"cuda:{local_rank}") for im in page_imgs]
+    pages = [PageRequest(build_prompt(cfg, n_img_tok[i], rng), None, [grids[i]], images=[imgs_dev[i]]) for i in range(B)]
     P = [len(p.input_ids) for p in pages]
     log(f"preprocessed {B} pages in {time.perf_counter()-t0:.1f}s: grid {grids[0]}, image tokens {n_img_tok[0]}, prompt P={P[0]}")
 
     s_max = (max(P) + T_out + 63) // 64 * 64
-    eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(len(p) for p in pvs),
+    eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(g[1] * g[2] for g in grids),
                  max_prompt_tokens=sum(P), decode_splits=args.decode_splits, weight_dtype=args.weights)
-    pix_dev = torch.from_numpy(np.concatenate(pvs, 0)).to(dev)
     if args.guided:
         # no tokenizer ships with random-init weights: the byte tokens 0..255 carry their byte, the rest are specials;
         # the pattern allows any text, so the mask / advance kernels do their full per-step work
@@ -209,14 +355,14 @@ def main():
 
     # ---------------- weights: rank 0 materialises them, the others receive the arena over RCCL
     t0 = time.perf_counter()
-    bcast_s = None
+    bcast_s, rccl_ranks, host_weights = None, None, None
     if rank == 0:
-        eng.load_weights(random_weights(cfg, 0, as_bits=True))
+        host_weights = random_weights(cfg, 0, as_bits=True)
+        eng.load_weights(host_weights)
         log(f"random-init {cfg.name} weights generated + uploaded in {time.perf_counter()-t0:.1f}s "
             f"({eng.w.nbytes/1e9:.2f} GB arena)")
     else:
         eng.w.allocate()
-    bcast_path = None
     if world > 1:
         from karanta_ocr_amd.dp import broadcast_weights
 
@@ -224,26 +370,20 @@ def main():
             a = eng.w.arena
             return int(a[:: max(1, a.numel() // (1 << 22))].to(torch.int64).sum().item())
 
-        try:
-            bcast_s = broadcast_weights(eng.w.arena, rank, world, stream=eng.s)   # kr_comm_* / kr_bcast_weights (RCCL)
-            bcast_path = "kr_bcast_weights"
-        except Exception as e:  # library-level RCCL failure: the weights are seeded, regenerate them locally
-            print(f"[bench] rank {rank}: kr_bcast_weights failed ({e}); regenerating the seeded weights locally",
-                  file=sys.stderr, flush=True)
-            t0 = time.perf_counter()
-            if rank != 0:
-                eng.load_weights(random_weights(cfg, 0, as_bits=True))
-            bcast_s, bcast_path = time.perf_counter() - t0, "FAILED: regenerated locally"
+        # NO fallback: a failed broadcast raises on every rank (dp.BroadcastError) and the run exits non-zero — "did
+        # RCCL move the weights between N ranks?" is answered by the exit code and by rccl_ranks (ncclCommCount)
+        info = {}
+        bcast_s = broadcast_weights(eng.w.arena, rank, world, stream=eng.s, info=info)
+        rccl_ranks = info.get("rccl_ranks")
         digs = [None] * world
         dist.all_gather_object(digs, digest())
-        if digs[rank] != digs[0]:  # never observed; keeps the run valid (weights are seeded, so identical by construction)
-            eng.load_weights(random_weights(cfg, 0, as_bits=True))
-            bcast_path = "regenerated locally (broadcast digest mismatch)"
-        log(f"weight broadcast via {bcast_path}: {eng.w.nbytes/1e9:.2f} GB in {bcast_s*1e3:.0f} ms; digests equal: {len(set(digs)) == 1}")
+        if len(set(digs)) != 1:
+            raise SystemExit(f"rank {rank}: weight arena digests differ after the broadcast: {digs}")
+        log(f"weight broadcast (kr_bcast_weights, {rccl_ranks} RCCL ranks): {eng.w.nbytes/1e9:.2f} GB in {bcast_s*1e3:.0f} ms; "
+            f"digests equal")
 
     def one_step(profile_every=0):
-        return eng.generate(pages, T_out, ignore_eos=True, use_graph=not args.no_graph,
-                            pixel_values_device=pix_dev, profile_every=profile_every)
+        return eng.generate(pages, T_out, ignore_eos=True, use_graph=not args.no_graph, profile_every=profile_every)
 
     for _ in range(args.warmup):
         one_step()
@@ -286,13 +426,16 @@ def main():
         bytes_step = cfg.decoder_weight_bytes(args.weights) + sum(p + T_out / 2 for p in P) * kvb
         t_step_roof = bytes_step / (HBM_PEAK_GBS * 1e9)
         decode_step_s = phase["decode_s"] / max(T_out - 1, 1)
-        traffic = pmc_traffic()   # the committed PMC pass is of the default workload: not quoted for other shapes
+        traffic, traffic_src = pmc_traffic()   # the committed PMC pass is of the default workload: not quoted for other shapes
         if traffic is not None and abs(traffic / chain["bytes_per_launch"] - 1.0) > 0.25:
             traffic = None
         out = {
             "metric": "pages_per_sec", "value": round(value, 4), "unit": "pages/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the arithmetic type of the path: bf16 MFMA with fp32 accumulation either way; with --weights fp8 the decoder
+            # Linears are STORED as e4m3 codes (+ f32 row scales) and converted to bf16 in registers
+            "dtype": "bf16" if args.weights == "bf16" else "fp8-weights/bf16", "data": "synthetic",
             "config": {
                 "workload": f"{cfg.name} {'bf16' if args.weights == 'bf16' else 'fp8-weight / bf16-activation'} greedy, batch={B} synthetic {args.page_width or args.page}x{args.page} pages per GPU, "
                             f"max_pixels={args.max_pixels} (grid {grids[0][1]}x{grids[0][2]}, {n_img_tok[0]} image tokens), "
@@ -313,23 +456,28 @@ def main():
                 "achieved": round(chain["bytes_per_launch"] / (chain["avg_us"] * 1e-6) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(chain["bytes_per_launch"] / (chain["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)",
+                "traffic": traffic, "traffic_source": f"{traffic_src} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)",
                 "bytes_per_launch": chain["bytes_per_launch"], "avg_us": round(chain["avg_us"], 3),
                 "launches_timed": chain["launches"],
                 "avg_us_definition": "HIP events on the launch stream around a chain of back-to-back launches of this kernel, one per "
                                      "decoder layer's weights (no cache reuse), total / launches; compare the rocprofv3 kernel-trace "
-                                     "average of the same kernel in profiles/r01_kernel_trace_summary.txt",
+                                     "average of the same kernel in profiles/r02_kernel_trace_summary.txt",
                 # the same launch bracketed by events inside the timed decode steps (eager steps every --profile-every):
                 "in_step": {"event_bracket_us": round(prof["bracket_us"], 3), "empty_bracket_us": round(prof["null_bracket_us"], 3),
                             "dispatch_gap_us": round(floor_us, 3), "launches_timed": prof["launches"]},
             },
         }
+        out["timed_region"] = ("uint8 RGB pages resident in HBM -> GPU image front end -> ViT -> prefill -> "
+                               f"{T_out} decode steps (host-side PNG decode and the 3 MB/page H2D copy are outside)")
         if bcast_s is not None:
             out["rccl_weight_bcast_s"] = round(bcast_s, 4)
-            out["rccl_weight_bcast_path"] = bcast_path
+            out["rccl_weight_bcast_path"] = "kr_bcast_weights (ncclBroadcast)"
+            out["rccl_ranks"] = rccl_ranks
+            if os.environ.get("KARANTA_BENCH_SHARE_GPUS") == "1" and n_dev < world:
+                out["config"]["WARNING"] = f"control-flow rehearsal: {world} ranks on {n_dev} GPU(s) — not an N-GPU measurement"
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle, bounded sample) ...")
-            out["cpu_baseline"] = cpu_baseline(cfg, pvs[0], grids[0], pages[0].input_ids, T_out)
+            out["cpu_baseline"] = cpu_baseline(cfg, pvs[0], grids[0], pages[0].input_ids, T_out, weights=host_weights)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -237,7 +237,8 @@ class PageRequest:
     grids: List[Tuple[int, int, int]] = field(default_factory=list)
     temperature: float = 0.0                   # 0: greedy; > 0: Gumbel-max sampling (kr_gumbel_argmax)
     seed: int = 0                              # the sampler is counter-based: (seed, token index) fixes every draw
-    images: Optional[List[np.ndarray]] = None  # instead of pixel_values: HWC uint8 RGB pages for the GPU front end
+    images: Optional[List[Any]] = None         # instead of pixel_values: HWC uint8 RGB pages for the GPU front end
+    #                                            (numpy arrays, or torch uint8 tensors already resident in HBM)
     guide: Any = None                          # guided.Guide / DeviceGuide: the output must match this pattern
     logprobs: Optional[int] = None             # None: off; k >= 0: log-prob of every token + the k most probable (<= 20)
 
@@ -554,11 +555,16 @@ class Engine:
         if grids is not None and len(grids) != len(images):
             raise KarantaHipError(f"{len(images)} images but {len(grids)} grids")
         for k, im in enumerate(images):
-            im = np.asarray(im)
-            if im.ndim == 2:
-                im = np.stack([im] * 3, axis=-1)
-            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
-                raise KarantaHipError("images must be HWC uint8 RGB arrays")
+            if isinstance(im, torch.Tensor):       # a page already resident in HBM (uint8 HWC): no copy at all
+                if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or not im.is_contiguous():
+                    raise KarantaHipError("device images must be contiguous HWC uint8 RGB tensors")
+            else:
+                im = np.asarray(im)
+                if im.ndim == 2:
+                    im = np.stack([im] * 3, axis=-1)
+                if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                    raise KarantaHipError("images must be HWC uint8 RGB arrays")
+                im = np.ascontiguousarray(im)
             h, w = int(im.shape[0]), int(im.shape[1])
             if grids is not None:
                 g = [int(x) for x in grids[k]]
@@ -567,7 +573,7 @@ class Engine:
                 rh, rw = g[1] * v.patch_size, g[2] * v.patch_size
             else:
                 rh, rw = IP.smart_resize(h, w, unit, min_pixels, max_pixels)
-            metas.append((np.ascontiguousarray(im), h, w, rh, rw))
+            metas.append((im, h, w, rh, rw))
             total += (rh // v.patch_size) * (rw // v.patch_size)
         out = torch.empty(total, v.patch_dim, dtype=torch.float32, device=dev)
         mean = (C.c_float * 3)(*[float(x) for x in IP.CLIP_MEAN])
@@ -575,7 +581,10 @@ class Engine:
         grids, off = [], 0
         with torch.cuda.stream(self.stream):
             for im, h, w, rh, rw in metas:
-                src = torch.from_numpy(im if im.flags.writeable else im.copy()).to(dev)   # PIL-backed arrays are read-only
+                if isinstance(im, torch.Tensor):
+                    src = im if im.device == dev else im.to(dev)
+                else:
+                    src = torch.from_numpy(im if im.flags.writeable else im.copy()).to(dev)   # PIL-backed arrays are read-only
                 key = (h, w, rh, rw)
                 tabs = self._resample_cache.get(key)
                 if tabs is None:

@@ -652,7 +652,8 @@ def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[
                     image_grid_thw: Optional[Sequence[Sequence[int]]], max_new_tokens: int,
                     policy: str = "fp32", ignore_eos: bool = False,
                     return_logits: bool = False, temperature: float = 0.0, seed: int = 0,
-                    guide=None, token_bytes: Optional[Sequence[bytes]] = None, return_raw_logits: bool = False):
+                    guide=None, token_bytes: Optional[Sequence[bytes]] = None, return_raw_logits: bool = False,
+                    image_embeds: Optional[np.ndarray] = None):
     """The call sequence of /root/reference/karanta/training/test_trained_model.py:76-99
     (``model.generate(**inputs, max_new_tokens=N)`` with ``do_sample=False``), i.e. what a
     ``temperature=0`` request to the reference's vLLM server computes
@@ -662,11 +663,13 @@ def generate_greedy(cfg, weights, input_ids: np.ndarray, pixel_values: Optional[
     build's counter-based noise (`sample_scores`); the returned "logits" are then the noisy scores.
     guide = (trans, accept, start) with token_bytes: scores of tokens the automaton forbids become -inf before the
     argmax (after temperature / noise), the state follows the chosen token's bytes.  return_raw_logits: also the
-    model's own logits per step (what log-probabilities are taken from)."""
+    model's own logits per step (what log-probabilities are taken from).  image_embeds: the merged ViT output when the
+    caller has already run :func:`vit_forward` on these pixels (tests that also check the ViT, or that run two decoders
+    on one image) — pixel_values is then not needed."""
     input_ids = np.asarray(input_ids)
     B, P = input_ids.shape
-    img = None
-    if pixel_values is not None:
+    img = image_embeds
+    if img is None and pixel_values is not None:
         img = vit_forward(pixel_values, image_grid_thw, weights, cfg.vision, policy)
     emb = embed_and_scatter(input_ids, img, weights, cfg)
     if image_grid_thw is not None:

@@ -522,6 +522,18 @@ def test_vit_attention_hd80(L, lens):
     run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens))
 
 
+@pytest.mark.parametrize("lens", [[4900], [4920, 1408]])
+def test_vit_attention_hd80_page_sized_segments(L, lens):
+    """The segment lengths of real pages: 70x70 = 4900 patches (1024x1024 scans, 77 KV tiles per query block — the
+    lazy-rescale path runs dozens of times), 82x60 = 4920 (tests/sample.jpg) next to a small second image."""
+    run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens))
+
+
+def test_prefill_attention_hd128_page_sized_prompt(L):
+    """Causal GQA prefill over a page-sized prompt (1394 tokens = the bench's P) next to a short one, 12 q / 2 kv heads."""
+    run_prep_attn(L, [1394, 77], H=12, KVH=2, hd=128, causal=True, seed=1394, as_cache=True, s_max=1408)
+
+
 @pytest.mark.parametrize("lens", [[36], [130, 5, 200], [257]])
 @pytest.mark.parametrize("H,KVH", [(2, 1), (6, 2), (3, 3)])
 def test_prefill_attention_hd128_causal_gqa(L, lens, H, KVH):
@@ -554,10 +566,11 @@ def test_attention_online_softmax_rescale_branch(L):
 
 # ----------------------------------------------------------------------------- decode path
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4), (3, 1)])
-@pytest.mark.parametrize("ctxs", [[0, 5, 63], [64, 100, 700], [1, 1279, 2047]])
+@pytest.mark.parametrize("ctxs", [[0, 5, 63], [64, 100, 700], [1, 1279, 2047], [2431, 1393, 2559]])
 def test_decode_prep_and_attention(L, H, KVH, ctxs):
     rng = np.random.default_rng(H * 100 + sum(ctxs))
-    hd, s_max, B, n_split = 128, 2048, len(ctxs), 4
+    # contexts up to the bench's last step (P = 1394, T_out = 1024 -> 2417 cached tokens) and past it
+    hd, s_max, B, n_split = 128, max(2048, (max(ctxs) + 64) // 64 * 64), len(ctxs), 4
     kc = np.zeros((B, KVH, s_max, hd), np.float32)
     vc = np.zeros((B, KVH, s_max, hd), np.float32)
     for b, c in enumerate(ctxs):
@@ -1439,10 +1452,12 @@ def test_attn_partials_merged_by_o_proj_prologue(L, H, KVH, n_split):
 
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4)])
 @pytest.mark.parametrize("n_split", [1, 4, 8])
-def test_attn_decode_fused(L, H, KVH, n_split):
+@pytest.mark.parametrize("long_ctx", [False, True])
+def test_attn_decode_fused(L, H, KVH, n_split, long_ctx):
     rng = np.random.default_rng(H * 10 + n_split)
-    hd, s_max = 128, 2048
-    ctxs = [0, 64, 100, 1279, 2047]
+    hd, s_max = 128, 2560 if long_ctx else 2048
+    # long_ctx: the contexts of the bench's decode loop (1394 .. 2417) and the last cache row
+    ctxs = [1393, 1394, 2000, 2431, 2559] if long_ctx else [0, 64, 100, 1279, 2047]
     B = len(ctxs)
     kc = np.zeros((B, KVH, s_max, hd), np.float32); vc = np.zeros((B, KVH, s_max, hd), np.float32)
     for b, c in enumerate(ctxs):

@@ -1,0 +1,305 @@
+"""Engine-vs-oracle parity at PRODUCTION WIDTHS, and the BASELINE.json configurations the tiny-model tests never reach.
+
+VERDICT r1 "Missing #1 / Next #1": the engine picks other kernel instantiations at real widths than on the toy configs
+(dec_wide_kernel<.,24> / dec_narrow_kernel<..,24,2,..> at K = 1536, the K = 3584 ones, the deferred split-K chain, the
+256x256 GEMM tiles at M >= 4900, attn_varlen_kernel<80> over a 4900-token segment with its lazy-rescale branch, the
+8-split decode attention at contexts of ~1400).  Here the bench models run at their full widths and full vocabulary with
+the depth truncated to what the oracle finishes in seconds (tests/prodwidth.py), call sequence of
+/root/reference/karanta/training/test_trained_model.py:76-99 (processor -> generate -> ids):
+
+  (a) Qwen2-VL-2B widths, one 1024x1024 scan (70x70 patches, 1225 image tokens): ViT merged output, last-position
+      prefill logits, 12 greedy tokens with a MINIMUM number of decisive comparisons, eager = graph, batch of 3 = solo;
+  (b) Qwen2-VL-7B widths, batch of 4 (BASELINE config 3's per-GPU share), bf16 and fp8 weights (config 5's dtype);
+  (c) config 5 geometry: a 1700x2200 scan at max_pixels = 12 845 056 (158x122 = 19 276 patches) through the ViT;
+  (d) config 1 geometry: a 1056x1422 JPEG through VLLMClient.generate -> LocalServer -> engine (grid 82x60, 1230 image
+      tokens), ids equal to a direct Engine.generate;
+  (e) config 4 shape: 64 requests from 8 VLLMClient worker threads through the continuous server
+      (/root/reference/bulk_processing/workers/inference_worker.py:324-339), every result equal to its solo run.
+
+Tolerance (floating point, stated): engine (bf16 storage, fp32 accumulate) vs the oracle at the same dtype policy —
+ViT merged output and logits within 2 % of the reference's range; tokens equal at every step whose oracle top-2 margin
+exceeds twice that (prodwidth.compare_generation).  Measured errors are written to gpurun_out/prodwidth_report.json.
+"""
+import base64
+import io
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from karanta_ocr_amd import image_processing as IP  # noqa: E402
+from karanta_ocr_amd.engine import Engine, PageRequest  # noqa: E402
+from karanta_ocr_amd.weights import fp8_dequantized_weights, random_weights  # noqa: E402
+from oracle import qwen2vl_oracle as O  # noqa: E402  (checker only)
+
+from tests import prodwidth as PW  # noqa: E402
+
+REPORT = {}
+MAXPIX_A = 1003520
+MAXPIX_B = 12845056
+
+
+def _record(key, **vals):
+    REPORT[key] = {k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in vals.items()}
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "prodwidth_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def m2b():
+    """Qwen2-VL-2B at full widths, 4 ViT blocks + 4 decoder layers, full vocabulary, untied head; engine with 8 slots."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = PW.truncated_config("Qwen2-VL-2B", 4, 4)
+    w = random_weights(cfg, 7, as_bits=True)
+    eng = Engine(cfg, max_batch=8, s_max=2048, max_patches=3 * 4960, max_prompt_tokens=3 * 1400, decode_splits=8)
+    eng.load_weights(w)
+    assert eng.wide_mode and eng.narrow_mode and eng.defer_down, "the production decode kernels must be the ones running"
+    yield cfg, w, eng
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def m7b():
+    """Qwen2-VL-7B at full widths (d 3584, ff 18944, 28/4 heads, vocabulary 152064), 2 ViT blocks + 2 decoder layers."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = PW.truncated_config("Qwen2-VL-7B", 2, 2)
+    w = random_weights(cfg, 11, as_bits=True)
+    return cfg, w, {}      # + a cache: the bf16 and fp8 runs share the page's ViT output (the tower is bf16 in both)
+
+
+# ------------------------------------------------------------------------------------------------------------ (a)
+def test_2b_width_vit_prefill_and_greedy_tokens_match_oracle(m2b):
+    cfg, w, eng = m2b
+    ids, pv, grid = PW.page_inputs(cfg, 300, 1024, 1024, MAXPIX_A, 20, 30, 31)
+    assert grid == (1, 70, 70) and len(ids) == 20 + 1225 + 2 + 30
+    steps = 12
+    # ---- ViT: one 4900-token attention segment, 256x256 GEMM tiles (M = 4900)
+    got_img = eng.vit_forward(pv, [grid])
+    eng.stream.synchronize()
+    got_img = got_img.float().cpu().numpy()
+    ref_img = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+    scale = float(np.abs(ref_img).max())
+    vit_err = float(np.abs(got_img - ref_img).max())
+    assert vit_err < 0.02 * scale, f"ViT merged output off by {vit_err} (range {scale})"
+    # ---- prefill + decode, eager with logits
+    page = PageRequest(ids, pv, [grid])
+    res = eng.generate([page], steps, ignore_eos=True, return_logits=True)
+    o_tok, o_log = O.generate_greedy(cfg, w, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True, return_logits=True,
+                                     image_embeds=ref_img)
+    tol = 0.02 * float(np.abs(o_log[0, 0]).max())
+    errs = [float(np.abs(res.logits[0, i] - o_log[0, i]).max()) for i in range(steps)]
+    assert errs[0] < tol, f"prefill logits off by {errs[0]} (tol {tol})"
+    decisive, walked = PW.compare_generation(res.tokens[0], res.logits[0], o_tok[0], o_log[0], tol, "2B widths")
+    _record("2b_w_v4_l4", vit_err=vit_err, vit_range=scale, tol=tol, logit_err_per_step=errs[:walked + 1],
+            margins=PW.margins(o_log[0]).tolist(), decisive=decisive, walked=walked, tokens=[int(t) for t in res.tokens[0]],
+            oracle_tokens=[int(t) for t in o_tok[0]])
+    assert walked >= 9 and decisive >= 5, f"only {decisive} decisive / {walked} walked steps of {steps} could be compared"
+    # ---- the replayed graph gives the eager tokens; a ragged batch of 3 gives page 0 its solo tokens
+    graph = eng.generate([page], steps, ignore_eos=True)
+    np.testing.assert_array_equal(graph.tokens[0], res.tokens[0])
+    others = [PageRequest(*_pg(cfg, 301, 448, 616, 7)), PageRequest(*_pg(cfg, 302, 1024, 700, 3))]
+    batch = eng.generate([others[0], page, others[1]], steps, ignore_eos=True)
+    np.testing.assert_array_equal(batch.tokens[1], res.tokens[0])
+
+
+def _pg(cfg, index, h, w, n_pre, max_pixels=MAXPIX_A):
+    ids, pv, grid = PW.page_inputs(cfg, index, h, w, max_pixels, n_pre, 5, 1000 + index)
+    return ids, pv, [grid]
+
+
+# ------------------------------------------------------------------------------------------------------------ (b)
+@pytest.mark.parametrize("weight_dtype", ["bf16", "fp8"])
+def test_7b_width_batch_of_4_matches_oracle(m7b, weight_dtype):
+    """BASELINE.json config 3's per-GPU share (4 pages) at the 7B widths; fp8 = config 5's weight format, checked against
+    the oracle on the dequantised state dict (the same model, so the same tolerance and token rule)."""
+    cfg, w, cache = m7b
+    ids, pv, grid = PW.page_inputs(cfg, 310, 1024, 1024, MAXPIX_A, 12, 25, 77)
+    small = [PageRequest(*_pg(cfg, 311 + k, h, wd, 3 + k)) for k, (h, wd) in enumerate([(336, 448), (560, 420), (224, 224)])]
+    pages = [small[0], small[1], PageRequest(ids, pv, [grid]), small[2]]
+    steps = 10
+    eng = Engine(cfg, max_batch=4, s_max=2048, max_patches=sum(len(p.pixel_values) for p in pages),
+                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=8, weight_dtype=weight_dtype)
+    eng.load_weights(w)
+    try:
+        assert eng.wide_mode and eng.narrow_mode and eng.defer_down
+        res = eng.generate(pages, steps, ignore_eos=True, return_logits=True)
+        wref = fp8_dequantized_weights(w, cfg) if weight_dtype == "fp8" else w
+        if "img" not in cache:
+            cache["img"] = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+        o_tok, o_log = O.generate_greedy(cfg, wref, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True, return_logits=True,
+                                         image_embeds=cache["img"])
+        tol = 0.02 * float(np.abs(o_log[0, 0]).max())
+        errs = [float(np.abs(res.logits[2, i] - o_log[0, i]).max()) for i in range(steps)]
+        assert errs[0] < tol, f"prefill logits off by {errs[0]} (tol {tol})"
+        decisive, walked = PW.compare_generation(res.tokens[2], res.logits[2], o_tok[0], o_log[0], tol, f"7B widths {weight_dtype}")
+        _record(f"7b_w_v2_l2_{weight_dtype}", tol=tol, logit_err_per_step=errs[:walked + 1], margins=PW.margins(o_log[0]).tolist(),
+                decisive=decisive, walked=walked)
+        assert walked >= 6 and decisive >= 3, f"only {decisive} decisive / {walked} walked steps of {steps} could be compared"
+        graph = eng.generate(pages, steps, ignore_eos=True)
+        for a, b in zip(graph.tokens, res.tokens):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------ (c)
+def test_config5_geometry_1700x2200_vit_matches_oracle(m7b):
+    """One 1700x2200 newspaper scan at the hub preprocessor's max_pixels (12 845 056): 2212x1708 -> 158x122 = 19 276
+    patches, 4819 image tokens, ONE attention segment of 19 276 tokens (302 KV tiles) — through the 7B model's tower."""
+    cfg, w, _ = m7b
+    pv, grid = IP.image_to_patches(IP.synthetic_page(320, 2200, 1700), max_pixels=MAXPIX_B)
+    assert grid == (1, 158, 122) and len(pv) == 19276
+    eng = Engine(cfg, max_batch=1, s_max=64, max_patches=19276, max_prompt_tokens=64, decode_splits=1)
+    eng.load_weights(w)
+    try:
+        got = eng.vit_forward(pv, [grid])
+        eng.stream.synchronize()
+        got = got.float().cpu().numpy()
+    finally:
+        eng.close()
+    ref = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+    assert got.shape == ref.shape == (4819, 3584)
+    scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
+    _record("config5_vit_19276", err=err, range=scale, rel=err / scale)
+    assert err < 0.02 * scale, f"ViT merged output off by {err} (range {scale})"
+
+
+# ------------------------------------------------------------------------------------------------------------ (d), (e)
+class IdTokenizer:
+    """ByteTokenizer whose decode spells every id out (`<123>`): a completion's text IS its token ids, so the
+    VLLMClient-shaped API can be compared with a direct Engine.generate token for token."""
+
+    def __init__(self, cfg):
+        from karanta_ocr_amd.serving import ByteTokenizer
+        self._b = ByteTokenizer(cfg)
+        self.im_start, self.im_end, self.newline = self._b.im_start, self._b.im_end, self._b.newline
+
+    def encode(self, text):
+        return self._b.encode(text)
+
+    def decode(self, ids):
+        return "".join(f"<{int(i)}>" for i in ids)
+
+
+def _jpeg_data_url(img_u8, quality=90):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img_u8).save(buf, format="JPEG", quality=quality)
+    return "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode()
+
+
+def _vision_request(url, text, max_tokens, **kw):
+    # the message shape of create_vision_message (/root/reference/karanta/data/utils.py:283-297): text first, image second
+    return dict({"model": "karantaocr", "max_tokens": max_tokens, "temperature": 0.0,
+                 "messages": [{"role": "user", "content": [{"type": "text", "text": text},
+                                                           {"type": "image_url", "image_url": {"url": url}}]}]}, **kw)
+
+
+def test_config1_sample_jpg_geometry_through_the_vllm_client(m2b):
+    """BASELINE.json config 1's page — tests/sample.jpg is a 1056x1422 JPEG: smart_resize -> 1148x840, grid 82x60, 1230
+    image tokens — through VLLMClient.generate -> LocalServer -> ChatFrontend (JPEG decode, GPU front end)
+    -> engine; the completion's ids equal a direct Engine.generate on the same prompt and pixels."""
+    from karanta_ocr_amd import serving as S
+    from karanta_ocr_amd.clients import VLLMClient
+    cfg, w, eng = m2b
+    url = _jpeg_data_url(IP.synthetic_page(330, 1422, 1056))
+    front = S.ChatFrontend(cfg, IdTokenizer(cfg), max_pixels=MAXPIX_A, device_images=True)
+    srv = S.LocalServer(eng, front, log=lambda *_: None)
+    port = 18461
+    S.register_local_server(port, srv)
+    try:
+        req = _vision_request(url, "Below is the image of one page of a document.", 12)
+        parsed = front.parse(req)
+        assert parsed.grids == [(1, 82, 60)] and int((parsed.input_ids == cfg.image_token_id).sum()) == 1230
+        r = VLLMClient(port=port).generate(req["messages"], model="karantaocr", max_tokens=12, temperature=0.0)
+        assert set(r) == {"text", "finish_reason", "model", "usage", "metadata"}
+        assert r["usage"]["prompt_tokens"] == len(parsed.input_ids) and r["usage"]["completion_tokens"] >= 1
+    finally:
+        S.unregister_local_server(port)
+        srv.close()
+    # the same page decoded and preprocessed on the host (PIL), straight into the engine
+    pv, grid = IP.image_to_patches(IP.decode_data_url(url), max_pixels=MAXPIX_A)
+    assert grid == (1, 82, 60)
+    direct = eng.generate([PageRequest(parsed.input_ids, pv, [grid])], 12)
+    eos = set(cfg.eos_token_ids)
+    toks = [int(t) for t in direct.tokens[0] if int(t) not in eos]
+    assert r["text"] == "".join(f"<{t}>" for t in toks)
+    assert r["finish_reason"] == direct.finish_reasons[0]
+
+
+def test_config4_corpus_through_eight_bulk_clients_equals_solo_runs(m2b):
+    """BASELINE.json config 4's shape on one GPU: 64 page requests pulled from a queue by 8 worker threads, each with its
+    own VLLMClient (one client per Celery worker process in the reference, inference_worker.py:324-339), through the
+    continuous-batching server (8 decode slots); pages of three sizes, ragged max_tokens.  Every completion equals the
+    solo static run of its page (greedy decoding is a pure function of the page: a shorter limit is a prefix)."""
+    import queue
+    from karanta_ocr_amd import serving as S
+    from karanta_ocr_amd.clients import VLLMClient
+    cfg, w, eng = m2b
+    front = S.ChatFrontend(cfg, IdTokenizer(cfg), max_pixels=MAXPIX_A, device_images=True)
+    geoms = [(1024, 1024), (448, 616), (700, 504), (336, 336)]
+    n_pages, n_req, longest = 16, 64, 14
+    urls = [IP.encode_png_data_url(IP.synthetic_page(400 + i, *geoms[i % len(geoms)])) for i in range(n_pages)]
+    limits = [3 + (5 * k) % (longest - 2) for k in range(n_req)]
+    # solo reference: each distinct page once, at the longest limit
+    solo = {}
+    for i, url in enumerate(urls):
+        p = front.parse(_vision_request(url, f"page {i}", longest))
+        out = eng.generate([PageRequest(p.input_ids, None, p.grids, images=p.images)], longest)
+        solo[i] = (out.tokens[0], out.finish_reasons[0])
+    srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=True, max_tokens_cap=longest, chunk=4)
+    port = 18462
+    S.register_local_server(port, srv)
+    work: "queue.Queue" = queue.Queue()
+    for k in range(n_req):
+        work.put(k)
+    results, errors = {}, []
+
+    def worker():
+        client = VLLMClient(port=port, max_retries=0)
+        while True:
+            try:
+                k = work.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                i = k % n_pages
+                req = _vision_request(urls[i], f"page {i}", limits[k])
+                results[k] = client.generate(req["messages"], model="karantaocr", max_tokens=limits[k], temperature=0.0)
+            except Exception as e:  # noqa: BLE001
+                errors.append((k, repr(e)))
+
+    try:
+        ts = [threading.Thread(target=worker) for _ in range(8)]
+        [t.start() for t in ts]
+        [t.join(timeout=600) for t in ts]
+    finally:
+        S.unregister_local_server(port)
+        srv.close()
+    assert not errors, errors[:3]
+    assert len(results) == n_req and srv.pages_done == n_req
+    eos = set(cfg.eos_token_ids)
+    for k in range(n_req):
+        toks, reason = solo[k % n_pages]
+        lim = limits[k]
+        want = list(toks[:lim])
+        stopped = reason == "stop" and len(toks) <= lim
+        if stopped:
+            want = [t for t in want if int(t) not in eos]
+        assert results[k]["text"] == "".join(f"<{int(t)}>" for t in want), f"request {k} (page {k % n_pages}, limit {lim})"
+        assert results[k]["finish_reason"] == ("stop" if stopped else "length")
+        assert results[k]["usage"]["completion_tokens"] == len(want)
+    st, m = srv.metrics()
+    assert st == 200 and m["pages_done"] == n_req and m["latency_s"]["n"] == n_req
