@@ -99,10 +99,23 @@ def cpu_baseline(cfg, pv_page: np.ndarray, grid, ids: np.ndarray, t_out: int, we
         t0 = time.perf_counter()
         img = O.vit_forward(pv_page, [grid], weights, cfg.vision)
         t_vit = time.perf_counter() - t0
-        t_pre, t_dec = llm(weights, cfg, cfg.text.num_layers, img)
+        # the decoder's parameters as resident fp32 arrays — what a CPU implementation holds; left as bf16 bit patterns
+        # (how rank 0 keeps them for the upload) every call would re-expand them, 1.3 s per token for nothing
+        wl, note = weights, ""
+        try:
+            import psutil
+            need = 4 * sum(int(np.prod(v.shape)) for k, v in weights.items() if not k.startswith("model.visual."))
+            if psutil.virtual_memory().available > need + (8 << 30):
+                wl = {k: O._w(weights, k) for k in weights if not k.startswith("model.visual.")}
+            else:
+                note = " (decoder weights re-expanded from bf16 on every call: host memory too small to hold them in fp32)"
+        except Exception:
+            note = " (decoder weights re-expanded from bf16 on every call)"
+        t_pre, t_dec = llm(wl, cfg, cfg.text.num_layers, img)
+        del wl
         how = (f"FULL depth measured ({cfg.vision.depth} ViT blocks, {cfg.text.num_layers} decoder layers): vit {t_vit:.1f}s + prefill "
                f"{t_pre:.1f}s + decode {t_dec*1e3:.0f} ms/token (median of {N_DEC} tokens at ctx ~{len(ids)}); only T_out={t_out} is "
-               f"extrapolated (per-token x T_out)")
+               f"extrapolated (per-token x T_out){note}")
     else:
         small = dataclasses.replace(cfg, vision=dataclasses.replace(cfg.vision, depth=2),
                                     text=dataclasses.replace(cfg.text, num_layers=2))

@@ -1181,13 +1181,18 @@ class Engine:
     # ------------------------------------------------------------------ public API
     def generate(self, pages: Sequence[PageRequest], max_new_tokens: int, ignore_eos: bool = False,
                  use_graph: bool = True, return_logits: bool = False, sync_every: int = 32,
-                 pixel_values_device: Optional[torch.Tensor] = None, profile_every: int = 0) -> GenerateResult:
+                 pixel_values_device: Optional[torch.Tensor] = None, profile_every: int = 0,
+                 force_tokens: Optional[np.ndarray] = None) -> GenerateResult:
         """Greedy generation for a static batch of pages (temperature 0 — the reference's
         ``build_page_query`` default, /root/reference/karanta/pipeline.py:166-171).
 
         ``pixel_values_device``: all pages' patches already resident in HBM (fp32 ``[n, 1176]``), used
         instead of the per-page host arrays.  ``profile_every`` > 0: every that many decode steps one
-        step runs eagerly with HIP events around the dominant kernel (see :meth:`kernel_profile`)."""
+        step runs eagerly with HIP events around the dominant kernel (see :meth:`kernel_profile`).
+        ``force_tokens`` (int [B, >= max_new_tokens - 1], eager path: a parity-test instrument): teacher forcing — after
+        every sampling step the NEXT step's input embedding is replaced by that of the given token, while `tokens` /
+        `logits` still report the engine's own argmax and logits.  With a reference's tokens as the forced sequence
+        every step can be compared with the reference, also past a near-tie where free-running sequences part."""
         B = len(pages)
         if not 1 <= B <= self.B:
             raise KarantaHipError(f"batch {B} not in 1..{self.B}")
@@ -1216,6 +1221,21 @@ class Engine:
         self.stream.synchronize()
         t1 = time.perf_counter()
         lens = self.prefill(pages, n_img_tok, prep=prep)
+        forced = None
+        if force_tokens is not None:
+            ft = np.asarray(force_tokens, np.int64)
+            if ft.ndim != 2 or ft.shape[0] != B or ft.shape[1] < max_new_tokens - 1 or ft.min() < 0 or ft.max() >= self.cfg.text.vocab_size:
+                raise KarantaHipError(f"force_tokens must be [B={B}, >= {max_new_tokens - 1}] token ids")
+            forced = torch.from_numpy(np.ascontiguousarray(ft.T.astype(np.int32))).to(self.device)   # [steps, B]
+            use_graph = False
+
+        def force(k):     # the input of decode step k + 1 becomes the embedding of forced token k
+            if forced is not None and k < forced.shape[0]:
+                self.L.kr_embed_scatter(ptr(forced[k]), ptr(self.w.view("llm.embed")), 0, ptr(self.d_x), B,
+                                        self.cfg.text.hidden_size, self.s)
+
+        with torch.cuda.stream(self.stream):
+            force(0)
         logits_steps = []
         if return_logits:
             self.stream.synchronize()
@@ -1237,6 +1257,7 @@ class Engine:
                     # eager step; the first one also sets per-kernel attributes, so capture only
                     # after it (no attribute calls inside a stream capture)
                     self._decode_step_launches(B)
+                    force(steps_done)
                     if want_graph:
                         graph = self._graph_for(B)
                 steps_done += 1

@@ -66,3 +66,20 @@ def compare_generation(got_tokens: Sequence[int], got_logits: Optional[np.ndarra
             break                         # a legitimate flip at a near-tie: the sequences part here
         walked += 1
     return decisive, walked
+
+
+def compare_teacher_forced(got_tokens: Sequence[int], got_logits: np.ndarray, ref_tokens: Sequence[int], ref_logits: np.ndarray,
+                           tol: float, what: str = "") -> int:
+    """Parity of a TEACHER-FORCED engine run (Engine.generate(force_tokens = the oracle's tokens)): the engine saw the
+    oracle's prefix at every step, so every step compares — the full logit vector within 1.5 * tol, and the engine's
+    argmax equal to the oracle's wherever the oracle's top-2 margin exceeds 2 * tol.  Returns the decisive-step count."""
+    m = margins(ref_logits)
+    decisive = 0
+    for i in range(len(ref_tokens)):
+        err = float(np.abs(got_logits[i] - ref_logits[i]).max())
+        assert err < 1.5 * tol, f"{what} step {i}: logits off by {err:.4f} (1.5 tol = {1.5 * tol:.4f})"
+        if m[i] > 2 * tol:
+            assert int(got_tokens[i]) == int(ref_tokens[i]), \
+                f"{what} step {i}: engine {int(got_tokens[i])} vs oracle {int(ref_tokens[i])} at margin {m[i]:.3f} > 2 tol {2 * tol:.3f}"
+            decisive += 1
+    return decisive

@@ -17,8 +17,12 @@ the depth truncated to what the oracle finishes in seconds (tests/prodwidth.py),
       (/root/reference/bulk_processing/workers/inference_worker.py:324-339), every result equal to its solo run.
 
 Tolerance (floating point, stated): engine (bf16 storage, fp32 accumulate) vs the oracle at the same dtype policy —
-ViT merged output and logits within 2 % of the reference's range; tokens equal at every step whose oracle top-2 margin
-exceeds twice that (prodwidth.compare_generation).  Measured errors are written to gpurun_out/prodwidth_report.json.
+ViT merged output within 2 % of the reference's range, logits within TOL = 1 % of the logit range at the last prompt
+position and 1.5 % at every decode step (measured on MI355X: 0.5-0.6 %); tokens equal at every step whose oracle top-2
+margin exceeds 2 x TOL.  Two runs per model: free-running (the sequences must agree until a near-tie lets them part:
+prodwidth.compare_generation) and TEACHER-FORCED with the oracle's tokens (Engine.generate(force_tokens=...)), where
+every one of the steps compares and a minimum number of DECISIVE steps is asserted — a test that compared nothing
+fails.  Measured errors and margins are written to gpurun_out/prodwidth_report.json.
 """
 import base64
 import io
@@ -40,6 +44,7 @@ from oracle import qwen2vl_oracle as O  # noqa: E402  (checker only)
 from tests import prodwidth as PW  # noqa: E402
 
 REPORT = {}
+TOL_REL = 0.01        # of the logit range (max |logit| of the reference at the last prompt position)
 MAXPIX_A = 1003520
 MAXPIX_B = 12845056
 
@@ -98,14 +103,19 @@ def test_2b_width_vit_prefill_and_greedy_tokens_match_oracle(m2b):
     res = eng.generate([page], steps, ignore_eos=True, return_logits=True)
     o_tok, o_log = O.generate_greedy(cfg, w, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True, return_logits=True,
                                      image_embeds=ref_img)
-    tol = 0.02 * float(np.abs(o_log[0, 0]).max())
+    tol = TOL_REL * float(np.abs(o_log[0, 0]).max())
     errs = [float(np.abs(res.logits[0, i] - o_log[0, i]).max()) for i in range(steps)]
     assert errs[0] < tol, f"prefill logits off by {errs[0]} (tol {tol})"
     decisive, walked = PW.compare_generation(res.tokens[0], res.logits[0], o_tok[0], o_log[0], tol, "2B widths")
-    _record("2b_w_v4_l4", vit_err=vit_err, vit_range=scale, tol=tol, logit_err_per_step=errs[:walked + 1],
-            margins=PW.margins(o_log[0]).tolist(), decisive=decisive, walked=walked, tokens=[int(t) for t in res.tokens[0]],
-            oracle_tokens=[int(t) for t in o_tok[0]])
-    assert walked >= 9 and decisive >= 5, f"only {decisive} decisive / {walked} walked steps of {steps} could be compared"
+    # teacher-forced: every step compares, whatever the near-ties did to the free run
+    forced = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
+    f_errs = [float(np.abs(forced.logits[0, i] - o_log[0, i]).max()) for i in range(steps)]
+    f_decisive = PW.compare_teacher_forced(forced.tokens[0], forced.logits[0], o_tok[0], o_log[0], tol, "2B widths (forced)")
+    _record("2b_w_v4_l4", vit_err=vit_err, vit_range=scale, tol=tol, logit_err_per_step=errs[:walked + 1], forced_logit_err=f_errs,
+            margins=PW.margins(o_log[0]).tolist(), decisive=decisive, walked=walked, forced_decisive=f_decisive,
+            tokens=[int(t) for t in res.tokens[0]], oracle_tokens=[int(t) for t in o_tok[0]])
+    assert f_decisive >= 8, f"only {f_decisive} of {steps} teacher-forced steps were decisive"
+    assert walked >= 4 and decisive >= 3, f"free run: only {decisive} decisive / {walked} walked steps of {steps}"
     # ---- the replayed graph gives the eager tokens; a ragged batch of 3 gives page 0 its solo tokens
     graph = eng.generate([page], steps, ignore_eos=True)
     np.testing.assert_array_equal(graph.tokens[0], res.tokens[0])
@@ -140,13 +150,21 @@ def test_7b_width_batch_of_4_matches_oracle(m7b, weight_dtype):
             cache["img"] = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
         o_tok, o_log = O.generate_greedy(cfg, wref, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True, return_logits=True,
                                          image_embeds=cache["img"])
-        tol = 0.02 * float(np.abs(o_log[0, 0]).max())
+        tol = TOL_REL * float(np.abs(o_log[0, 0]).max())
         errs = [float(np.abs(res.logits[2, i] - o_log[0, i]).max()) for i in range(steps)]
         assert errs[0] < tol, f"prefill logits off by {errs[0]} (tol {tol})"
         decisive, walked = PW.compare_generation(res.tokens[2], res.logits[2], o_tok[0], o_log[0], tol, f"7B widths {weight_dtype}")
-        _record(f"7b_w_v2_l2_{weight_dtype}", tol=tol, logit_err_per_step=errs[:walked + 1], margins=PW.margins(o_log[0]).tolist(),
-                decisive=decisive, walked=walked)
-        assert walked >= 6 and decisive >= 3, f"only {decisive} decisive / {walked} walked steps of {steps} could be compared"
+        # teacher-forced: page 2 follows the oracle's tokens, the other pages their own (i.e. unchanged)
+        ft = np.stack([np.asarray(t[:steps - 1], np.int64) for t in res.tokens])
+        ft[2] = o_tok[0, :steps - 1]
+        forced = eng.generate(pages, steps, ignore_eos=True, return_logits=True, force_tokens=ft)
+        f_errs = [float(np.abs(forced.logits[2, i] - o_log[0, i]).max()) for i in range(steps)]
+        f_decisive = PW.compare_teacher_forced(forced.tokens[2], forced.logits[2], o_tok[0], o_log[0], tol, f"7B widths {weight_dtype} (forced)")
+        for k in (0, 1, 3):
+            np.testing.assert_array_equal(forced.tokens[k], res.tokens[k])       # self-forced pages: nothing changes
+        _record(f"7b_w_v2_l2_{weight_dtype}", tol=tol, logit_err_per_step=errs[:walked + 1], forced_logit_err=f_errs,
+                margins=PW.margins(o_log[0]).tolist(), decisive=decisive, walked=walked, forced_decisive=f_decisive)
+        assert f_decisive >= 4, f"only {f_decisive} of {steps} teacher-forced steps were decisive"
         graph = eng.generate(pages, steps, ignore_eos=True)
         for a, b in zip(graph.tokens, res.tokens):
             np.testing.assert_array_equal(a, b)
