@@ -282,7 +282,8 @@ def main():
     ap.add_argument("--guided", action="store_true",
                     help="every page carries a (permissive) guide: times the masked sampling pass + DFA advance in the decode graph")
     ap.add_argument("--logprobs", type=int, default=None, help="record top-k log-probabilities every step (0..20)")
-    ap.add_argument("--decode-splits", type=int, default=8)
+    ap.add_argument("--decode-splits", type=int, default=16,
+                    help="split-KV parts of the decode attention (16: 256 workgroups of 4 waves, every CU loads; r2: -4 %% per step vs 8)")
     ap.add_argument("--weights", default="bf16", choices=("bf16", "fp8"),
                     help="fp8: decoder Linears as e4m3fn codes + per-row scales (BASELINE.json config 5); activations stay bf16")
     ap.add_argument("--dry-run", action="store_true",

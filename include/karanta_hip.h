@@ -65,6 +65,9 @@ int kr_stream_synchronize(kr_stream s);
 int kr_event_create(void** ev);
 int kr_event_destroy(void* ev);
 int kr_event_record(void* ev, kr_stream s);
+/* hipStreamWaitEvent: inside a stream capture this forks / joins the graph (a second stream pulled in by an event of
+ * the capturing stream becomes a parallel branch; an event of that stream waited on by the capturing one is the join). */
+int kr_stream_wait_event(kr_stream s, void* ev);
 int kr_event_synchronize(void* ev);
 int kr_event_elapsed_ms(void* start, void* stop, float* ms);
 
@@ -279,6 +282,36 @@ int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float
                             const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                             kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
                             kr_stream s);
+
+/* FAST-RESIDUAL MODE (optional; the deterministic path above stays the parity mode).  Three entry points that remove
+ * the attention-merge launch from the decode step:
+ *   kr_linear_decode_narrow_x32 : kr_linear_decode_narrow (+ w_scale: fp8 codes when non-NULL) whose workgroup 0 ALSO
+ *       stores x_new as f32 to x_out_f32 [M, ldxf] — the start value of the residual accumulator;
+ *   kr_oproj_heads : o_proj with K split BY ATTENTION HEAD: workgroup (tile group, head) merges that head's split-KV
+ *       partials (attn_partials [M][heads][n_split][hd+4] f32, as kr_attn_decode_fused leaves them with out == NULL),
+ *       multiplies by W_o[rows, head columns] and adds the product to x_acc [M, ld_acc] f32 with float atomics
+ *       (`heads` adders per element; sums in arrival order: low f32 bits vary from run to run);
+ *   kr_linear_decode_wide_x32 : kr_linear_decode_wide (SILU8 / ARGMAX) reading its x rows from that f32 accumulator,
+ *       rounding them to bf16 once; workgroup 0 stores the rounded rows to x_out [M, ldxo] (may be NULL). */
+int kr_linear_decode_narrow_x32(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                kr_bf16* x_out, int64_t ldxo, float* x_out_f32, int64_t ldxf, const void* w_packed,
+                                const float* w_scale, const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps,
+                                const kr_bf16* residual, int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M,
+                                int N, int K, int waves, int ksplit, const float* cs_table, int cs_stride,
+                                const int32_t* prompt_len, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
+                                kr_bf16* vtcache, int heads, int kv_heads, int s_max, kr_stream s);
+int kr_oproj_heads(const float* attn_partials, int n_split, const void* w_packed, const float* w_scale, float* x_acc,
+                   int64_t ld_acc, int M, int N, int heads, kr_stream s);
+int kr_linear_decode_wide_x32(int mode, const float* x_f32, int64_t ldx, kr_bf16* x_out, int64_t ldxo, const void* w_packed,
+                              const float* w_scale, const kr_bf16* norm_w, float norm_eps, kr_bf16* out, float* out_f32,
+                              int64_t ldc, int M, int N, int K, int blocks, int waves, float* amax_val, int32_t* amax_idx,
+                              kr_stream s);
+
+/* One-shot request, consumed by the next kr_linear_decode_narrow* launch (ksplit 1) issued from this thread: that
+ * launch gets `blocks` extra workgroups whose only work is to read [ptr, ptr + bytes) with plain loads, so the range
+ * sits in the memory-side Infinity Cache when a later launch streams it (the narrow launches of a decode step occupy
+ * 64-96 of the 256 CUs).  bytes == 0 or blocks == 0 cancels. */
+int kr_decode_prefetch_next(const void* ptr, size_t bytes, int blocks);
 
 /* The same two kernels on fp8 (OCP e4m3fn) weights — BASELINE.json config 5: decoder Linears in fp8 with one f32 scale
  * per output row, activations bf16.  w_packed_fp8 = weights.pack_w16x64_fp8 (one 16-row x 64-column block = 1 KiB in

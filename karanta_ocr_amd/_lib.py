@@ -33,6 +33,7 @@ SIGNATURES = {
     "kr_event_destroy": [c_p],
     "kr_event_record": [c_p, c_p],
     "kr_event_synchronize": [c_p],
+    "kr_stream_wait_event": [c_p, c_p],
     "kr_event_elapsed_ms": [c_p, c_p, C.POINTER(f32)],
     "kr_graph_begin_capture": [c_p],
     "kr_graph_end_capture": [c_p, C.POINTER(c_p)],
@@ -71,6 +72,11 @@ SIGNATURES = {
     "kr_logprobs_topk": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_linear_decode_narrow": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                 i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
+    "kr_linear_decode_narrow_x32": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
+                                    i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
+    "kr_decode_prefetch_next": [c_p, C.c_size_t, i32],
+    "kr_oproj_heads": [c_p, i32, c_p, c_p, c_p, i64, i32, i32, i32, c_p],
+    "kr_linear_decode_wide_x32": [i32, c_p, i64, c_p, i64, c_p, c_p, c_p, f32, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
     "kr_attn_decode_merge": [c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],

@@ -56,6 +56,10 @@ int kr_event_record(void* ev, kr_stream s) {
     KR_CHECK_HIP(hipEventRecord((hipEvent_t)ev, kr_hs(s)));
     return KR_OK;
 }
+int kr_stream_wait_event(kr_stream s, void* ev) {
+    KR_CHECK_HIP(hipStreamWaitEvent(kr_hs(s), (hipEvent_t)ev, 0));
+    return KR_OK;
+}
 int kr_event_synchronize(void* ev) {
     KR_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev));
     return KR_OK;

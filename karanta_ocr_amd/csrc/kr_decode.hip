@@ -58,6 +58,15 @@ struct DecLinArgs {
     // fp8 (e4m3fn) weights: one f32 scale per output row (interleaved like the rows for SILU8), applied to the
     // accumulators at the top of every epilogue; NULL for bf16 weights
     const float* w_scale;
+    // f32 residual accumulator (fast-residual mode): the narrow NORM kernel's workgroup 0 also stores x_new as f32
+    // (x_out_f32, ldxf) — the buffer the per-head o_proj adds into with float atomics; the wide kernel then reads its x
+    // rows from that f32 buffer (template XF32) and workgroup 0 stores their bf16 rounding to wide_x_out.
+    float* x_out_f32; int64_t ldxf;
+    kr_bf16* wide_x_out; int64_t wide_ldxo;
+    int x_is_f32;                      // wide kernel: `x` points to f32 rows (ldx in floats)
+    // narrow kernel: workgroups blockIdx.x >= groups are PREFETCHERS — they touch [pf_ptr, pf_ptr + pf_bytes) with
+    // plain loads (the range lands in the memory-side Infinity Cache) on CUs the launch would otherwise leave idle
+    const char* pf_ptr; int64_t pf_bytes; int pf_blocks;
 };
 
 // One 64-wide K chunk of a 16-row weight tile in registers, and where its operands sit.
@@ -496,7 +505,7 @@ struct WideHot {
     int M, N, wide_blocks, wide_waves; float norm_eps;
 };
 
-template <int EPI, int NCH, bool ACTIVE, bool W8, int MT>
+template <int EPI, int NCH, bool ACTIVE, bool W8, int MT, bool XF32>
 __device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs& a, char* smem) {
     using WC = WChunk<W8>;
     constexpr int U = WideCfg<NCH, MT>::U, RL = WideCfg<NCH, MT>::RL;
@@ -513,15 +522,28 @@ __device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs
     // constant: s_waitcnt bookkeeping does not survive divergent control flow) ...
     constexpr bool FULL = NCH != 0;  // RL * 64 == K / 8 exactly
     bf16x8 xv[NR][RL], nwv[RL];
+    f32x4 xf[XF32 ? NR : 1][XF32 ? RL : 1][2];   // XF32: the rows arrive as f32 (residual accumulator), rounded below
     const bool has_norm = h.norm_w != nullptr;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int b = wave + r * W;
-        const kr_bf16* xp = h.x + (int64_t)(b < M ? b : 0) * h.ldx;
+        if constexpr (XF32) {
+            const float* xp = reinterpret_cast<const float*>(h.x) + (int64_t)(b < M ? b : 0) * h.ldx;
 #pragma unroll
-        for (int i = 0; i < RL; ++i) {
-            const int c = lane + i * 64;
-            if (FULL || c < kc) xv[r][i] = ld8(xp + c * 8);
+            for (int i = 0; i < RL; ++i) {
+                const int c = lane + i * 64;
+                if (FULL || c < kc) {
+                    xf[r][i][0] = *reinterpret_cast<const f32x4*>(xp + c * 8);
+                    xf[r][i][1] = *reinterpret_cast<const f32x4*>(xp + c * 8 + 4);
+                }
+            }
+        } else {
+            const kr_bf16* xp = h.x + (int64_t)(b < M ? b : 0) * h.ldx;
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                const int c = lane + i * 64;
+                if (FULL || c < kc) xv[r][i] = ld8(xp + c * 8);
+            }
         }
     }
     {
@@ -541,6 +563,23 @@ __device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs
         for (int u = 0; u < U; ++u) wbuf[u].load(wp, u);
     }
     __builtin_amdgcn_sched_barrier(0);  // everything above is issued before any of the norm arithmetic below
+    if constexpr (XF32) {
+        // the residual stream is a bf16 tensor: round the accumulated f32 rows once, here; workgroup 0 keeps the rounded
+        // rows for the kernels that take the residual as bf16 (the next layer's qkv prologue, a PLAIN down_proj)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int b = wave + r * W;
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                if (FULL || lane + i * 64 < kc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[r][i][j] = f2bf(xf[r][i][j >> 2][j & 3]);
+                    if (blockIdx.x == 0 && a.wide_x_out && b < M)
+                        *reinterpret_cast<bf16x8*>(a.wide_x_out + (int64_t)b * a.wide_ldxo + (lane + i * 64) * 8) = xv[r][i];
+                }
+            }
+        }
+    }
     // ---- x -> LDS, RMS-normalised when norm_w is given
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -577,7 +616,19 @@ __device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs
         for (int i = 0; i < RL; ++i) {
             const int c = lane + i * 64;
             if (c < kc) {
-                v[i] = ld8(h.x + (int64_t)b * h.ldx + c * 8);
+                if constexpr (XF32) {
+                    const float* xp = reinterpret_cast<const float*>(h.x) + (int64_t)b * h.ldx + c * 8;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(xp), t1 = *reinterpret_cast<const f32x4*>(xp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[i][j] = f2bf(t0[j]);
+                        v[i][4 + j] = f2bf(t1[j]);
+                    }
+                    if (blockIdx.x == 0 && a.wide_x_out)
+                        *reinterpret_cast<bf16x8*>(a.wide_x_out + (int64_t)b * a.wide_ldxo + c * 8) = v[i];
+                } else {
+                    v[i] = ld8(h.x + (int64_t)b * h.ldx + c * 8);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ss += bf2f(v[i][j]) * bf2f(v[i][j]);
             }
@@ -719,21 +770,21 @@ __device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs
     }
 }
 
-template <int EPI, int NCH, bool W8, int MT>
+template <int EPI, int NCH, bool W8, int MT, bool XF32>
 __global__ void __launch_bounds__(512) dec_wide_kernel(const kr_bf16* x, const kr_bf16* wp, const kr_bf16* norm_w, int64_t ldx, int M,
                                                        int N, int wide_blocks, int wide_waves, float norm_eps, const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WideHot h{x, wp, norm_w, ldx, M, N, wide_blocks, wide_waves, norm_eps};
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x + wide_blocks * wave < (N >> 4)) dec_wide_body<EPI, NCH, true, W8, MT>(h, a, smem);
-    else dec_wide_body<EPI, NCH, false, W8, MT>(h, a, smem);
+    if ((int)blockIdx.x + wide_blocks * wave < (N >> 4)) dec_wide_body<EPI, NCH, true, W8, MT, XF32>(h, a, smem);
+    else dec_wide_body<EPI, NCH, false, W8, MT, XF32>(h, a, smem);
 }
 
-template <int EPI, int NCH, bool W8, int MT>
-int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+template <int EPI, int NCH, bool W8, int MT, bool XF32>
+int launch_wide_x(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     const size_t lds = (size_t)a.M * (a.K * 2 + 16);
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_wide: x (%d rows, K=%d) needs %zu bytes of LDS", a.M, a.K, lds);
-    auto fn = &dec_wide_kernel<EPI, NCH, W8, MT>;
+    auto fn = &dec_wide_kernel<EPI, NCH, W8, MT, XF32>;
     static bool attr = false;
     if (!attr) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -742,6 +793,21 @@ int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.ldx, a.M, a.N, a.wide_blocks, a.wide_waves, a.norm_eps, a);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+// x as f32 (residual accumulator): instantiated for the epilogues that follow a per-head o_proj (SILU8: gate/up) and
+// the last layer's final norm (ARGMAX: lm_head); DEPI_PLAIN keeps its bf16 input
+template <int EPI, int NCH, bool W8, int MT>
+int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+    if (a.x_is_f32) {
+        if constexpr (EPI == DEPI_SILU8 || EPI == DEPI_ARGMAX) {
+            return launch_wide_x<EPI, NCH, W8, MT, true>(a, blocks, waves, s);
+        } else {
+            kr_set_error("kr_linear_decode_wide: f32 x rows are taken by the SILU8 and ARGMAX modes only");
+            return KR_ERR_ARG;
+        }
+    }
+    return launch_wide_x<EPI, NCH, W8, MT, false>(a, blocks, waves, s);
 }
 
 template <int EPI, int NCH, bool W8>
@@ -803,6 +869,24 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int g = blockIdx.x, ks = blockIdx.y;
+    if (a.pf_blocks > 0 && (int)blockIdx.x >= (int)gridDim.x - a.pf_blocks) {
+        // prefetcher workgroup: 16 loads of 16 bytes in flight per lane, results discarded (kept alive by the asm)
+        const int pb = blockIdx.x - ((int)gridDim.x - a.pf_blocks);
+        const int64_t n16 = a.pf_bytes >> 4, stride = (int64_t)a.pf_blocks * (WAVES * 64);
+        const u32x4* p = reinterpret_cast<const u32x4*>(a.pf_ptr);
+        u32x4 acc = {0u, 0u, 0u, 0u};
+        int64_t i = (int64_t)pb * (WAVES * 64) + threadIdx.x;
+        for (; i + 15 * stride < n16; i += 16 * stride) {
+            u32x4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = p[i + k * stride];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc ^= v[k];
+        }
+        for (; i < n16; i += stride) acc ^= p[i];
+        asm volatile("" ::"v"(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]));
+        return;
+    }
     const int M = hM, K = hK;
     const int nchunks = NCH ? NCH : (K >> 6), ntiles = hN >> 4, kc = K >> 3;
     const int cpb = hcpb;   // chunks per K split, computed on the host (a runtime integer division is ~30 instructions here)
@@ -924,6 +1008,16 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
                 }
             }
         }
+        if (a.x_out_f32 && g == 0 && ks == 0 && wave < M) {   // fast-residual mode: x_new also as the f32 accumulator's start value
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                if (FULL || lane + i * 64 < kc) {
+                    float* xo = a.x_out_f32 + (int64_t)wave * a.ldxf + (lane + i * 64) * 8;
+                    *reinterpret_cast<f32x4*>(xo) = (f32x4){bf2f(xv[i][0]), bf2f(xv[i][1]), bf2f(xv[i][2]), bf2f(xv[i][3])};
+                    *reinterpret_cast<f32x4*>(xo + 4) = (f32x4){bf2f(xv[i][4]), bf2f(xv[i][5]), bf2f(xv[i][6]), bf2f(xv[i][7])};
+                }
+            }
+        }
         if (wave < M) norm_row(wave, xv, nwv);
         for (int b = wave + WAVES; b < M; b += WAVES) {  // more rows than waves: the slow way (loads behind the weights)
             bf16x8 v[RL];
@@ -949,6 +1043,11 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[i][j] = f2bf(f[j]);
                         if (g == 0 && ks == 0) *reinterpret_cast<bf16x8*>(a.x_out + (int64_t)b * a.ldxo + c * 8) = v[i];
+                    }
+                    if (a.x_out_f32 && g == 0 && ks == 0) {
+                        float* xo = a.x_out_f32 + (int64_t)b * a.ldxf + c * 8;
+                        *reinterpret_cast<f32x4*>(xo) = (f32x4){bf2f(v[i][0]), bf2f(v[i][1]), bf2f(v[i][2]), bf2f(v[i][3])};
+                        *reinterpret_cast<f32x4*>(xo + 4) = (f32x4){bf2f(v[i][4]), bf2f(v[i][5]), bf2f(v[i][6]), bf2f(v[i][7])};
                     }
                 }
             }
@@ -1148,7 +1247,9 @@ int launch_narrow_m(DecLinArgs& a, int groups, kr_stream s) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    fn<<<dim3(groups, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.part_in, a.ldx, a.M, a.N, a.K, cpb, a.norm_eps, a);
+    KR_CHECK_ARG(a.pf_blocks == 0 || a.ksplit == 1, "kr_linear_decode_narrow: prefetch workgroups need ksplit 1");
+    fn<<<dim3(groups + a.pf_blocks, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.part_in, a.ldx, a.M, a.N, a.K, cpb,
+                                                                            a.norm_eps, a);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
@@ -1217,6 +1318,141 @@ int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
 }
 
 // =====================================================================================
+// o_proj split over the attention heads, merge of the split-KV partials in its prologue, float-atomic epilogue
+// =====================================================================================
+// The launch that replaces [attn_merge_kernel -> o_proj] in the fast-residual mode.  The merge of the attention's
+// split-KV partials is an all-to-all only because o_proj's K dimension spans all heads.  Split K BY HEAD instead:
+// workgroup (tg, h) merges head h alone (M x n_split records of 528 bytes: 34 KB at M = 8 — not the 400 KB every
+// workgroup of a merging o_proj prologue had to re-read), multiplies the merged [M, 128] slice by W_o[rows of tile
+// group tg, columns of head h] (2 K-chunks per 16-row tile, straight to VGPRs, no cross-wave reduction) and ADDS its
+// [M, rows] product to the f32 residual accumulator with global_atomic_add_f32 — `heads` adders per element, every
+// wave-instruction 256 contiguous bytes of one row (the shape the microarch guide measures at the full atomic rate;
+// 590 KB of adds per launch for the 2B model against 1.3 TB/s).  The accumulator was set to x_new (f32) by the qkv
+// launch; the gate/up launch reads it back and rounds it to bf16 once.  Float atomics add in arrival order, so the
+// low bits of the f32 sums vary from run to run: this is the engine's FAST mode; the deterministic slab path stays the
+// parity mode.
+template <bool W8, int TI, int NS>
+__global__ void __launch_bounds__(512) dec_oproj_heads_kernel(const float* __restrict__ ws, const char* __restrict__ wp,
+                                                              const float* __restrict__ w_scale, float* __restrict__ x_acc,
+                                                              int64_t ld_acc, int M, int heads, int n_split, int tw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using WC = WChunk<W8>;
+    constexpr int HD = 128, REC = HD + 4, XROW = HD * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tg = blockIdx.x, h = blockIdx.y;
+    const int nchunks = heads * 2;                        // K = heads * 128
+    float* outs = reinterpret_cast<float*>(smem + ((32 * XROW + 127) & ~127));   // [M][tw * 16] f32
+
+    // ---- 1. the partial records of head h (oldest loads: the merge waits for them)
+    const int ns = NS ? NS : n_split;
+    constexpr int MAXS = NS ? NS : 16;
+    const int b0 = tid >> 5, d4 = (tid & 31) << 2;        // thread -> (sequence b0 [+16], channels d4 .. d4+3)
+    f32x4 ro[2][MAXS], rm[2][MAXS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int b = b0 + 16 * mt;
+        if (mt == 0 || M > 16) {
+            const float* rec = ws + ((int64_t)(b < M ? b : 0) * heads + h) * ns * REC;
+#pragma unroll
+            for (int p = 0; p < MAXS; ++p) {
+                if (p < ns) {
+                    ro[mt][p] = *reinterpret_cast<const f32x4*>(rec + p * REC + d4);
+                    rm[mt][p] = *reinterpret_cast<const f32x4*>(rec + p * REC + HD);
+                }
+            }
+        }
+    }
+    // ---- 2. the weight fragments of this wave's tiles: tile tg * tw + wave + 8 i, chunks 2h and 2h + 1
+    WC wb[TI][2];
+    int tile[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int tl = wave + 8 * i;
+        tile[i] = tg * tw + (tl < tw ? tl : tw - 1);
+        const char* p = wp + ((int64_t)tile[i] * nchunks) * WC::BYTES + lane * 16;
+        wb[i][0].load(p, 2 * h);
+        wb[i][1].load(p, 2 * h + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. merge -> bf16 -> LDS x[b][128]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int b = b0 + 16 * mt;
+        if ((mt == 0 || M > 16) && b < M) {
+            float mm = -1e30f;
+#pragma unroll
+            for (int p = 0; p < MAXS; ++p)
+                if (p < ns) mm = fmaxf(mm, rm[mt][p][0]);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float ll = 0.f;
+#pragma unroll
+            for (int p = 0; p < MAXS; ++p) {
+                if (p < ns) {
+                    const float sc = __builtin_amdgcn_exp2f(rm[mt][p][0] - mm);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += ro[mt][p][j] * sc;
+                    ll += rm[mt][p][1] * sc;
+                }
+            }
+            const float inv = ll > 0.f ? 1.0f / ll : 0.f;   // same arithmetic as attn_merge_kernel / the in-launch merge
+            bf16x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = f2bf(acc[j] * inv);
+            *reinterpret_cast<bf16x4*>(smem + b * XROW + d4 * 2) = ov;
+        }
+    }
+    __syncthreads();
+    // ---- 4. [16 x 128] x [128 x M] per tile and batch column tile
+    const int cols = tw * 16;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && M <= 16) break;
+        const char* xl = smem + min(fr + 16 * mt, M - 1) * XROW;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + WC::x_byte(0, fg));
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xl + c * 128 + WC::x_byte(1, fg));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i][c].frag(0), x0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i][c].frag(1), x1, acc, 0, 0, 0);
+            }
+            apply_w_scale(w_scale, tile[i] * 16 + fg * 4, acc);
+            const int tl = wave + 8 * i, b = fr + 16 * mt;
+            if (tl < tw && b < M) *reinterpret_cast<f32x4*>(outs + b * cols + tl * 16 + fg * 4) = acc;
+        }
+    }
+    __syncthreads();
+    // ---- 5. add to the residual accumulator: consecutive lanes = consecutive floats of one row
+    float* dst = x_acc + (int64_t)tg * cols;
+    for (int e = tid; e < M * cols; e += 512) {
+        const int b = e / cols, c = e - b * cols;
+        atomicAdd(dst + (int64_t)b * ld_acc + c, outs[e]);
+    }
+}
+
+template <bool W8, int TI>
+int launch_oproj_heads(const float* ws, const void* wp, const float* w_scale, float* x_acc, int64_t ld_acc, int M, int N, int heads,
+                       int n_split, int tw, kr_stream s) {
+    const size_t lds = ((32 * (128 * 2 + 16) + 127) & ~127) + (size_t)M * tw * 16 * 4;
+    const dim3 grid((N / 16) / tw, heads);
+    if (n_split == 8)
+        dec_oproj_heads_kernel<W8, TI, 8><<<grid, 512, lds, kr_hs(s)>>>(ws, reinterpret_cast<const char*>(wp), w_scale, x_acc, ld_acc, M,
+                                                                        heads, n_split, tw);
+    else if (n_split == 16)
+        dec_oproj_heads_kernel<W8, TI, 16><<<grid, 512, lds, kr_hs(s)>>>(ws, reinterpret_cast<const char*>(wp), w_scale, x_acc, ld_acc, M,
+                                                                         heads, n_split, tw);
+    else
+        dec_oproj_heads_kernel<W8, TI, 0><<<grid, 512, lds, kr_hs(s)>>>(ws, reinterpret_cast<const char*>(wp), w_scale, x_acc, ld_acc, M,
+                                                                        heads, n_split, tw);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+// =====================================================================================
 // decode attention with in-launch merge
 // =====================================================================================
 // grid = (n_split, kv_heads, batch); WAVES waves; wave `part` = split*WAVES + wave walks 32-key units
@@ -1227,10 +1463,10 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
                                                                   const int32_t* __restrict__ ctx_len, int heads, int kv_heads,
                                                                   int group, int n_split, int s_max, float scale_log2e,
                                                                   kr_bf16* __restrict__ out, float* __restrict__ ws,
-                                                                  int* __restrict__ counters) {
+                                                                  int* __restrict__ counters, int ws_bytes) {
     // argument order: everything the first loads need sits in the 16 preloaded dwords (kernarg preload), so the
     // scalar load of ctx_len[b] leaves at once instead of behind a load of the argument tail
-    constexpr int HD = 128, DT = HD / 16, REC = HD + 4, NTHR = WAVES * 64;
+    constexpr int HD = 128, DT = HD / 16, REC = HD + 4;
     __shared__ __attribute__((aligned(16))) float o_s[WAVES][16][HD];
     __shared__ float m_s[WAVES][16], l_s[WAVES][16];
     __shared__ int last_s;
@@ -1343,41 +1579,78 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
         }
     }
     __syncthreads();
+    // element t < group * 32 = 4 consecutive channels d4 .. d4+3 of head gg: one 16-byte piece of the record
+    // [o[128], m, l, 0, 0] (REC floats) of this (sequence, head, split); a thread owns elements tid, tid + NTHR, ...
+    constexpr int NTHR = WAVES * 64, IT = (16 * 32 + NTHR - 1) / NTHR;
     const int bh0 = b * heads + kvh * group;
-    for (int e = tid; e < group * HD; e += NTHR) {
-        const int gg = e >> 7, d = e & 127;
-        float mm = m_s[0][gg];
+    const int nq = group * (HD / 4);
+    f32x4 acc4[IT];
+    float mm[IT], ll[IT];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) mm = fmaxf(mm, m_s[w][gg]);
-        float acc = 0.f, ll = 0.f;
+    for (int it = 0; it < IT; ++it) {
+        const int t = tid + it * NTHR, gg = t >> 5, d4 = (t & 31) << 2;
+        acc4[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mm[it] = -1e30f;
+        ll[it] = 0.f;
+        if (t < nq) {
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const float sc = __builtin_amdgcn_exp2f(m_s[w][gg] - mm);
-            acc += o_s[w][gg][d] * sc;
-            ll += l_s[w][gg] * sc;
-        }
-        if (n_split == 1 && out) {
-            out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
-        } else if (out) {
-            // in-launch merge: the records travel past the (per-XCD, non-coherent) L2 with agent-scope relaxed
-            // atomics, so no cache write-back / invalidate is needed around the arrival counter
-            float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * REC;
-            __hip_atomic_store(w + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 0) {
-                __hip_atomic_store(w + HD, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(w + HD + 1, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            float* w = ws + ((int64_t)(bh0 + gg) * n_split + split) * REC;
-            w[d] = acc;
-            if (d == 0) {
-                w[HD] = mm;
-                w[HD + 1] = ll;
+            for (int w = 0; w < WAVES; ++w) mm[it] = fmaxf(mm[it], m_s[w][gg]);
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const float sc = __builtin_amdgcn_exp2f(m_s[w][gg] - mm[it]);
+                const f32x4 ow = *reinterpret_cast<const f32x4*>(&o_s[w][gg][d4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc4[it][j] += ow[j] * sc;
+                ll[it] += l_s[w][gg] * sc;
             }
         }
     }
-    if (n_split == 1 || !out) return;  // out == NULL: a later launch (kr_attn_decode_merge) merges the partials
-    // ---- cross-workgroup merge by the last arriver.  Nobody waits: the other workgroups just leave.
+    auto store_out = [&](int t, const f32x4& a, float l) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        bf16x4 ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = f2bf(a[j] * inv);
+        *reinterpret_cast<bf16x4*>(out + (int64_t)(bh0 + (t >> 5)) * HD + ((t & 31) << 2)) = ov;
+    };
+    auto rec_of = [&](int t) { return ((int64_t)(bh0 + (t >> 5)) * n_split) * REC; };   // first record of element t's head (floats)
+    if (n_split == 1 && out) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+            if (tid + it * NTHR < nq) store_out(tid + it * NTHR, acc4[it], ll[it]);
+        return;
+    }
+    if (!out) {  // a later launch (kr_attn_decode_merge / the per-head o_proj prologue) merges the partials: plain stores
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int t = tid + it * NTHR, d4 = (t & 31) << 2;
+            if (t < nq) {
+                float* w = ws + rec_of(t) + (int64_t)split * REC;
+                *reinterpret_cast<f32x4*>(w + d4) = acc4[it];
+                if (d4 == 0) *reinterpret_cast<f32x4*>(w + HD) = (f32x4){mm[it], ll[it], 0.f, 0.f};
+            }
+        }
+        return;
+    }
+    // ---- in-launch merge by the last-arriving split of this (sequence, kv head).  Hand-off in the form the guide
+    // measures (MI355X_MICROARCH.md, visibility, "Valid forms" row 1): every payload byte leaves as a 16-byte sc1
+    // (write-through) store, every storing wave drains its stores (vmcnt(0)) before the workgroup barrier, ONE lane
+    // then adds to the group's counter; the workgroup whose add returns n_split - 1 is the last one and reads all
+    // records with 16-byte sc1 loads (never a plain load of these bytes), all requested at once.  Nobody waits:
+    // the other workgroups just leave.  Correct for any placement of the splits on XCDs / CUs.
+    // (Measured r2: 1.2200 ms per step against 1.2033 with the separate merge launch — the hand-off costs what the
+    // launch costs; kept for the ABI and as the tested example of the protocol.)
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, ws_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int t = tid + it * NTHR, d4 = (t & 31) << 2;
+        if (t < nq) {
+            const int off = (int)((rec_of(t) + (int64_t)split * REC + d4) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc4[it]), rsrc, off, 0, 16);
+            if (d4 == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){mm[it], ll[it], 0.f, 0.f}), rsrc,
+                                                       (int)((rec_of(t) + (int64_t)split * REC + HD) * 4), 0, 16);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have been acknowledged
     __syncthreads();
     if (tid == 0) {
@@ -1388,32 +1661,34 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
     __syncthreads();
     if (!last_s) return;
     constexpr int MAXS = 16;
-    for (int e = tid; e < group * HD; e += NTHR) {
-        const int gg = e >> 7, d = e & 127;
-        const float* w = ws + (int64_t)(bh0 + gg) * n_split * REC;
-        float m[MAXS], l[MAXS], o[MAXS];
+    for (int it = 0; it < IT; ++it) {
+        const int t = tid + it * NTHR, d4 = (t & 31) << 2;
+        if (t >= nq) continue;
+        u32x4 ro[MAXS], rm[MAXS];
 #pragma unroll
         for (int p = 0; p < MAXS; ++p) {
             if (p < n_split) {
-                m[p] = __hip_atomic_load(w + p * REC + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                l[p] = __hip_atomic_load(w + p * REC + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                o[p] = __hip_atomic_load(w + p * REC + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ro[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((rec_of(t) + (int64_t)p * REC + d4) * 4), 0, 16);
+                rm[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((rec_of(t) + (int64_t)p * REC + HD) * 4), 0, 16);
             }
         }
-        float mm = -1e30f;
+        float mt = -1e30f;
 #pragma unroll
         for (int p = 0; p < MAXS; ++p)
-            if (p < n_split) mm = fmaxf(mm, m[p]);
-        float acc = 0.f, ll = 0.f;
+            if (p < n_split) mt = fmaxf(mt, __builtin_bit_cast(f32x4, rm[p])[0]);
+        f32x4 at = {0.f, 0.f, 0.f, 0.f};
+        float lt = 0.f;
 #pragma unroll
         for (int p = 0; p < MAXS; ++p) {
             if (p < n_split) {
-                const float sc = __builtin_amdgcn_exp2f(m[p] - mm);
-                acc += o[p] * sc;
-                ll += l[p] * sc;
+                const f32x4 mlp = __builtin_bit_cast(f32x4, rm[p]), op = __builtin_bit_cast(f32x4, ro[p]);
+                const float sc = __builtin_amdgcn_exp2f(mlp[0] - mt);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) at[j] += op[j] * sc;
+                lt += mlp[1] * sc;
             }
         }
-        out[(int64_t)(bh0 + gg) * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+        store_out(t, at, lt);
     }
 }
 
@@ -1687,7 +1962,8 @@ extern "C" int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const k
 static int wide_impl(int mode, const kr_bf16* x, int64_t ldx, const void* w_packed, const float* w_scale, const kr_bf16* bias,
                      const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                      kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
-                     float* amax_val, int32_t* amax_idx, kr_stream s) {
+                     float* amax_val, int32_t* amax_idx, kr_stream s, bool x_is_f32 = false, kr_bf16* x_out = nullptr,
+                     int64_t ldxo = 0) {
     KR_CHECK_ARG(x && w_packed, "kr_linear_decode_wide: null pointer");
     KR_CHECK_ARG(M >= 1 && M <= 32, "kr_linear_decode_wide: M=%d must be in 1..32", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 512 == 0 && K <= 4096,
@@ -1695,6 +1971,7 @@ static int wide_impl(int mode, const kr_bf16* x, int64_t ldx, const void* w_pack
     KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_wide: ldx");
     KR_CHECK_ARG(blocks > 0 && waves >= 1 && waves <= 8, "kr_linear_decode_wide: blocks=%d waves=%d", blocks, waves);
     DecLinArgs a{};
+    a.x_is_f32 = x_is_f32 ? 1 : 0; a.wide_x_out = x_out; a.wide_ldxo = ldxo;
     a.x = x; a.ldx = ldx; a.wp = reinterpret_cast<const kr_bf16*>(w_packed); a.w_scale = w_scale; a.bias = bias;
     a.norm_w = norm_w; a.norm_eps = norm_eps;
     a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
@@ -1734,13 +2011,26 @@ extern "C" int kr_linear_decode_wide_fp8(int mode, const kr_bf16* x, int64_t ldx
                      blocks, waves, amax_val, amax_idx, s);
 }
 
+// One-shot request consumed by the NEXT narrow launch of this thread (kr_decode_prefetch_next): the launch gets
+// `blocks` extra workgroups that pull [ptr, ptr + bytes) into the Infinity Cache beside its own work.
+static thread_local const char* g_pf_ptr = nullptr;
+static thread_local int64_t g_pf_bytes = 0;
+static thread_local int g_pf_blocks = 0;
+extern "C" int kr_decode_prefetch_next(const void* ptr_, size_t bytes, int blocks) {
+    KR_CHECK_ARG((ptr_ || bytes == 0) && ((uintptr_t)ptr_ & 15) == 0 && blocks >= 0 && blocks <= 1024, "kr_decode_prefetch_next: bad args");
+    g_pf_ptr = reinterpret_cast<const char*>(ptr_);
+    g_pf_bytes = (int64_t)bytes;
+    g_pf_blocks = bytes >= 16 ? blocks : 0;
+    return KR_OK;
+}
+
 static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
                                        kr_bf16* x_out, int64_t ldxo, const void* w_packed, const float* w_scale, const kr_bf16* bias,
                                        const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                                        kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
                                        const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                                        kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
-                                       kr_stream s) {
+                                       kr_stream s, float* x_out_f32 = nullptr, int64_t ldxf = 0) {
     KR_CHECK_ARG(x && w_packed, "kr_linear_decode_narrow: null pointer");
     KR_CHECK_ARG(M >= 1 && M <= 32, "kr_linear_decode_narrow: M=%d must be in 1..32", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 64 == 0, "kr_linear_decode_narrow: N=%d K=%d (N%%16, K%%64)", N, K);
@@ -1756,6 +2046,11 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
     a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.ksplit = ksplit;
     a.part_in = part_in; a.x_out = x_out; a.ldxo = ldxo;
+    a.x_out_f32 = x_out_f32; a.ldxf = ldxf;
+    if (ksplit == 1) {   // a pending prefetch request rides on this launch
+        a.pf_ptr = g_pf_ptr; a.pf_bytes = g_pf_bytes; a.pf_blocks = g_pf_blocks;
+        g_pf_blocks = 0;
+    }
     a.cs_table = cs_table; a.cs_stride = cs_stride; a.prompt_len = prompt_len; a.ctx_len = ctx_len;
     a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
     a.heads = heads; a.kv_heads = kv_heads; a.s_max = s_max;
@@ -1819,17 +2114,29 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
     KR_CHECK_ARG(!out || n_split <= 16, "kr_attn_decode_fused: the in-launch merge takes at most 16 splits");
     KR_CHECK_ARG(!out || n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
-    // 8 waves per workgroup: n_split * 8 parts, so that a wave rarely has more than one 32-key unit to fetch
-    // (KARANTA_ATTN_WAVES=4: the 4-wave variant for n_split > 4, kept for A/B measurements)
-    static const bool waves4 = [] { const char* e = getenv("KARANTA_ATTN_WAVES"); return e && e[0] == '4'; }();
-    if (n_split <= 4 || !waves4)
-        attn_decode2_kernel<8><<<dim3(n_split, kv_heads, batch), 512, 0, kr_hs(s)>>>(
-            q, kcache, vtcache, ctx_len, heads, kv_heads, heads / kv_heads, n_split, s_max, scale * 1.4426950408889634f, out, workspace,
-            counters);
+    KR_CHECK_ARG(workspace || n_split == 1, "kr_attn_decode_fused: the split partials need a workspace");
+    // Workgroup shape: n_split x WAVES parts of 32-key units, so that at page contexts (1.4k .. 2.4k keys = 44 .. 76 units)
+    // a wave fetches ONE unit (one memory round trip).  r2 chain timings (B = 8, ctx 1906, launch + dependent-launch gap):
+    // 8 splits x 8 waves (128 workgroups) 7.8 us; 16 splits x 4 waves (256 workgroups, every CU loads) 5.8 us;
+    // 6 x 8 (two units per wave) 12.7 us.  Hence: up to 8 splits 8 waves, up to 16 splits 4 waves, beyond 2 waves
+    // (KARANTA_ATTN_WAVES = 2 / 4 / 8 overrides for A/B runs).
+    static const int waves_env = [] { const char* e = getenv("KARANTA_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+    const int waves = waves_env ? waves_env : (n_split <= 8 ? 8 : n_split <= 16 ? 4 : 2);
+    KR_CHECK_ARG(waves == 2 || waves == 4 || waves == 8, "kr_attn_decode_fused: KARANTA_ATTN_WAVES=%d (2, 4 or 8)", waves);
+    const int64_t ws_bytes = (int64_t)batch * heads * n_split * (hd + 4) * 4;
+    KR_CHECK_ARG(ws_bytes < ((int64_t)1 << 31), "kr_attn_decode_fused: workspace of %lld bytes", (long long)ws_bytes);
+    const dim3 grid(n_split, kv_heads, batch);
+    const float sl2 = scale * 1.4426950408889634f;
+    const int group = heads / kv_heads;
+    if (waves == 8)
+        attn_decode2_kernel<8><<<grid, 512, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
+                                                           workspace, counters, (int)ws_bytes);
+    else if (waves == 4)
+        attn_decode2_kernel<4><<<grid, 256, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
+                                                           workspace, counters, (int)ws_bytes);
     else
-        attn_decode2_kernel<4><<<dim3(n_split, kv_heads, batch), 256, 0, kr_hs(s)>>>(
-            q, kcache, vtcache, ctx_len, heads, kv_heads, heads / kv_heads, n_split, s_max, scale * 1.4426950408889634f, out, workspace,
-            counters);
+        attn_decode2_kernel<2><<<grid, 128, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
+                                                           workspace, counters, (int)ws_bytes);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
@@ -1842,6 +2149,7 @@ extern "C" int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int ba
         case 4: attn_merge_kernel<4><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
         case 8: attn_merge_kernel<8><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
         case 16: attn_merge_kernel<16><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
+        case 32: attn_merge_kernel<32><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
         default: attn_merge_kernel<0><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split);
     }
     KR_CHECK_LAUNCH();
@@ -1885,4 +2193,49 @@ extern "C" int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, 
                                                       ignore_eos, x_next);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+
+// ---- fast-residual mode entry points (see dec_oproj_heads_kernel)
+extern "C" int kr_oproj_heads(const float* attn_partials, int n_split, const void* w_packed, const float* w_scale, float* x_acc,
+                              int64_t ld_acc, int M, int N, int heads, kr_stream s) {
+    KR_CHECK_ARG(attn_partials && w_packed && x_acc, "kr_oproj_heads: null pointer");
+    KR_CHECK_ARG(M >= 1 && M <= 32 && heads >= 1 && n_split >= 1 && n_split <= 16, "kr_oproj_heads: M=%d heads=%d n_split=%d", M, heads, n_split);
+    KR_CHECK_ARG(N > 0 && N % 16 == 0 && ld_acc >= N, "kr_oproj_heads: N=%d ld_acc=%lld", N, (long long)ld_acc);
+    const int tiles = N / 16;
+    // tiles per workgroup: a divisor of the tile count that 8 waves cover in two rounds (<= 16), the largest one that
+    // still gives the launch >= 96 workgroups (2B: 12 tiles -> 8 x 12 heads = 96; 7B: 16 -> 14 x 28 = 392)
+    int tw = 0;
+    for (int t = 16; t >= 1 && !tw; --t)
+        if (tiles % t == 0 && (tiles / t) * heads >= 96) tw = t;
+    for (int t = 1; t <= 16 && !tw; ++t)
+        if (tiles % t == 0) tw = t;
+    KR_CHECK_ARG(tw >= 1, "kr_oproj_heads: N=%d", N);
+    if (w_scale)
+        return tw > 8 ? launch_oproj_heads<true, 2>(attn_partials, w_packed, w_scale, x_acc, ld_acc, M, N, heads, n_split, tw, s)
+                      : launch_oproj_heads<true, 1>(attn_partials, w_packed, w_scale, x_acc, ld_acc, M, N, heads, n_split, tw, s);
+    return tw > 8 ? launch_oproj_heads<false, 2>(attn_partials, w_packed, nullptr, x_acc, ld_acc, M, N, heads, n_split, tw, s)
+                  : launch_oproj_heads<false, 1>(attn_partials, w_packed, nullptr, x_acc, ld_acc, M, N, heads, n_split, tw, s);
+}
+
+extern "C" int kr_linear_decode_narrow_x32(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
+                                           kr_bf16* x_out, int64_t ldxo, float* x_out_f32, int64_t ldxf, const void* w_packed,
+                                           const float* w_scale, const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps,
+                                           const kr_bf16* residual, int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M,
+                                           int N, int K, int waves, int ksplit, const float* cs_table, int cs_stride,
+                                           const int32_t* prompt_len, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
+                                           kr_bf16* vtcache, int heads, int kv_heads, int s_max, kr_stream s) {
+    KR_CHECK_ARG(!x_out_f32 || (norm_w && ldxf >= K && (ldxf & 3) == 0), "kr_linear_decode_narrow_x32: x_out_f32 needs the norm prologue");
+    return narrow_impl(mode, x, ldx, part_in, n_part_in, x_out, ldxo, w_packed, w_scale, bias, norm_w, norm_eps, residual, ldr, out,
+                       out_f32, ldc, M, N, K, waves, ksplit, cs_table, cs_stride, prompt_len, ctx_len, q_out, kcache, vtcache, heads,
+                       kv_heads, s_max, s, x_out_f32, ldxf);
+}
+
+extern "C" int kr_linear_decode_wide_x32(int mode, const float* x_f32, int64_t ldx, kr_bf16* x_out, int64_t ldxo, const void* w_packed,
+                                         const float* w_scale, const kr_bf16* norm_w, float norm_eps, kr_bf16* out, float* out_f32,
+                                         int64_t ldc, int M, int N, int K, int blocks, int waves, float* amax_val, int32_t* amax_idx,
+                                         kr_stream s) {
+    KR_CHECK_ARG(x_f32 && (ldx & 3) == 0 && (!x_out || (ldxo >= K && (ldxo & 7) == 0)), "kr_linear_decode_wide_x32: x");
+    return wide_impl(mode, reinterpret_cast<const kr_bf16*>(x_f32), ldx, w_packed, w_scale, nullptr, norm_w, norm_eps, nullptr, 0, out,
+                     out_f32, ldc, M, N, K, blocks, waves, amax_val, amax_idx, s, true, x_out, ldxo);
 }

@@ -265,8 +265,9 @@ class DeviceGuide:
 
 class Engine:
     def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
-                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 4,
-                 weight_dtype: str = "bf16"):
+                 max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 16,
+                 weight_dtype: str = "bf16", fast_residual: Optional[bool] = None):
+        self._want_fast_residual = (os.environ.get("KARANTA_FAST_RESIDUAL", "0") == "1") if fast_residual is None else bool(fast_residual)
         if not torch.cuda.is_available():
             raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
         self.L = lib()
@@ -290,6 +291,8 @@ class Engine:
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
         self._prefetch_mode = int(os.environ.get("KARANTA_PREFETCH", "0"))
+        self._pf_blocks = int(os.environ.get("KARANTA_PREFETCH_BLOCKS", "256"))
+        self._pf_stream = None
         self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
@@ -346,6 +349,7 @@ class Engine:
         self.d_x = z(B, t.hidden_size)
         self.d_x2 = z(B, t.hidden_size)  # the other residual buffer (deferred split-K ping-pong)
         self.d_part = z(2, B, t.hidden_size, dtype=torch.float32)  # down_proj slabs of the deferred split
+        self.d_xacc = z(B, t.hidden_size, dtype=torch.float32)     # fast-residual mode: f32 residual accumulator
         self.d_qkv = z(B, t.qkv_dim)
         self.d_q = z(B, t.num_heads, t.head_dim)
         self.d_o = z(B, t.q_dim)
@@ -370,6 +374,10 @@ class Engine:
         self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
                            and t.hidden_size in (1536, 2048, 3584))
+        # FAST-RESIDUAL mode (KARANTA_FAST_RESIDUAL=1, Engine(fast_residual=True)): o_proj split by attention head with
+        # the split-KV merge in its prologue and float atomics into an f32 residual accumulator — one launch fewer per
+        # layer (no attn_merge_kernel).  Sums in arrival order: not bit-reproducible; the default stays deterministic.
+        self.fast_residual = bool(getattr(self, "_want_fast_residual", False)) and self.narrow_mode
         # gate/up and lm_head: one wave per 16-row tile (kr_linear_decode_wide) when K allows it
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
@@ -378,6 +386,7 @@ class Engine:
                                 and t.intermediate_size % 64 == 0):
             raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels with 32 rows of x in LDS: "
                                   "hidden_size % 512 == 0 and <= 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B)")
+        self.fast_residual = self.fast_residual and self.wide_mode
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
         # one argmax partial per wave of the lm_head launch; the launch geometry depends on the row count (8 waves above
@@ -416,6 +425,19 @@ class Engine:
         self.d_last = z(B, dtype=torch.int32)
         torch.cuda.synchronize(dev)
 
+    def _pf_events(self, layer: int):
+        """(fork, join) events of layer `layer`'s prefetch branch, and the side stream they need (created on first use)."""
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.device)
+            self._pf_ev = {}
+        ev = self._pf_ev.get(layer)
+        if ev is None:
+            a, b = C.c_void_p(), C.c_void_p()
+            self.L.kr_event_create(C.byref(a))
+            self.L.kr_event_create(C.byref(b))
+            ev = self._pf_ev[layer] = (a, b)
+        return ev
+
     @staticmethod
     def _waves(nchunks: int) -> int:
         return 16 if nchunks >= 64 else 8 if nchunks >= 16 else 4
@@ -448,7 +470,7 @@ class Engine:
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _dec_narrow(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=8, ksplit=1,
-                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None):
+                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, x_out_f32=None):
         """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32.
         w8 / w_scale: the fp8 copy of W and its row scales (kr_linear_decode_narrow_fp8)."""
         t = self.cfg.text
@@ -460,7 +482,10 @@ class Engine:
         tail = (ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
                 ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs), self.max_new, ptr(self.d_plen), ptr(self.d_ctx),
                 ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max, self.s)
-        if w8 is not None:
+        if x_out_f32 is not None:    # fast-residual mode: workgroup 0 also stores x_new as the f32 accumulator's start value
+            self.L.kr_linear_decode_narrow_x32(*head, ptr(x_out_f32), x_out_f32.stride(0), ptr(w8 if w8 is not None else W),
+                                               ptr(w_scale), *tail)
+        elif w8 is not None:
             self.L.kr_linear_decode_narrow_fp8(*head, ptr(w8), ptr(w_scale), *tail)
         else:
             self.L.kr_linear_decode_narrow(*head, ptr(W), *tail)
@@ -494,11 +519,19 @@ class Engine:
         wb, ww = self._wide_geometry(self.cfg.text.vocab_size, M)
         return wb * ww
 
-    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None):
-        """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
+    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None, x_f32=None, x_out=None):
+        """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream.
+        x_f32 (fast-residual mode): the rows come from the f32 residual accumulator instead of x; x_out receives their
+        bf16 rounding (workgroup 0)."""
         N, K = W.shape
         blocks, waves = self._wide_geometry(N, M)
         o = out if out is not None else out_f32
+        if x_f32 is not None:
+            self.L.kr_linear_decode_wide_x32(mode, ptr(x_f32), x_f32.stride(0), ptr(x_out), x_out.stride(0) if x_out is not None else 0,
+                                             ptr(w8 if w8 is not None else W), ptr(w_scale), ptr(norm_w), self.cfg.text.rms_norm_eps,
+                                             ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0, M, N, K, blocks, waves,
+                                             ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
+            return
         tail = (0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0, ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0,
                 M, N, K, blocks, waves, ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
         if w8 is not None:
@@ -1023,26 +1056,59 @@ class Engine:
                 a0 = w.layout[p + "ln1.w"][0]
                 a1 = w.layout[p + "down.w"][0] + 2 * int(np.prod(w.layout[p + "down.w"][1]))
                 L.kr_prefetch(w.arena.data_ptr() + a0, a1 - a0, 512, s)
+            joined = None
+            if self._prefetch_mode in (2, 3):
+                # SECOND GRAPH BRANCH: while this layer's latency-bound chain qkv -> attention ->
+                # merge -> o_proj runs (25 us moving 25 MB), a side stream pulls the layer's MLP weights (mode 2: gate/up +
+                # down, 82.5 MB of the 2B model; mode 3: down only) into the 256 MB Infinity Cache; the branch joins
+                # before the gate/up launch.  In a stream capture the event pair forks / joins the graph.
+                first = "gate_up.w" if self._prefetch_mode == 2 else "down.w"
+                a0 = w.layout[p + first][0]
+                a1 = w.layout[p + "down.w"][0] + 2 * int(np.prod(w.layout[p + "down.w"][1]))
+                if self.fp8 and w.has(p + "down.w8"):
+                    a0 = w.layout[p + ("gate_up.w8" if self._prefetch_mode == 2 else "down.w8")][0]
+                    a1 = w.layout[p + "down.s"][0]
+                ef, joined = self._pf_events(i)
+                L.kr_event_record(ef, s)
+                L.kr_stream_wait_event(self._pf_stream.cuda_stream, ef)
+                L.kr_prefetch(w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks, self._pf_stream.cuda_stream)
+                L.kr_event_record(joined, self._pf_stream.cuda_stream)
+            fast = self.fast_residual
+            xacc = self.d_xacc if fast else None     # qkv's workgroup 0 leaves x_new there as f32; o_proj adds into it
+            if self._prefetch_mode in (4, 5, 6) and self.narrow_mode:
+                # PIGGYBACK PREFETCH: the qkv launch occupies 64 of the 256 CUs; extra workgroups of the same launch pull
+                # this layer's down_proj weights (mode 4), gate/up + down (5) or gate/up (6) into the Infinity Cache
+                lo = "down.w" if self._prefetch_mode == 4 else "gate_up.w"
+                hi = "gate_up.w" if self._prefetch_mode == 6 else "down.w"
+                sfx = "8" if (self.fp8 and w.has(p + "down.w8")) else ""
+                a0 = w.layout[p + lo + sfx][0]
+                a1 = w.layout[p + hi + sfx][0] + (1 if sfx else 2) * int(np.prod(w.layout[p + hi + sfx][1]))
+                L.kr_decode_prefetch_next(w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks)
             if self.narrow_mode:
                 if pending:
                     self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
                                      norm_w=w.view(p + "ln1.w"), part_in=self.d_part, x_out=x_other, kc=kc, vc=vc,
-                                     **self._w8kw(p + "qkv.w"))
+                                     x_out_f32=xacc, **self._w8kw(p + "qkv.w"))
                     x, x_other = x_other, x
                     pending = False
                 else:
                     self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
-                                     norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, **self._w8kw(p + "qkv.w"))
+                                     norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, x_out_f32=xacc, **self._w8kw(p + "qkv.w"))
             else:
                 self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                           waves=self.wv_qkv, kc=kc, vc=vc)
-            if self.attn_fused_merge:  # the last split workgroup of each (sequence, kv head) merges: no merge launch
+            if self.attn_fused_merge and not fast:  # the last split workgroup of each (sequence, kv head) merges: no merge launch
                 L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o), ptr(self.d_ws), ptr(self.d_cnt),
                                        B, H, KVH, hd, self.s_max, self.n_split, hd ** -0.5, s)
             else:
                 L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
                                        self.s_max, self.n_split, hd ** -0.5, s)
-            if self.attn_fused_merge:
+            if fast:
+                # [merge of head h's partials + W_o[:, head h] + atomic add into the f32 residual]: no merge launch
+                w8o, sco = self._w8(p + "o.w")
+                L.kr_oproj_heads(ptr(self.d_ws), self.n_split, ptr(w8o if w8o is not None else w.view(p + "o.w")), ptr(sco),
+                                 ptr(self.d_xacc), self.d_xacc.stride(0), B, t.hidden_size, H, s)
+            elif self.attn_fused_merge:
                 if self.narrow_o:
                     self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8, **self._w8kw(p + "o.w"))
                 else:
@@ -1056,13 +1122,18 @@ class Engine:
                     self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8, **self._w8kw(p + "o.w"))
                 else:
                     self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
+            if joined is not None:
+                L.kr_stream_wait_event(s, joined)
             if self._prof_on:
                 # [e0][e1] gate/up [e2]: the empty bracket e0..e1 measures what two back-to-back event
                 # packets cost by themselves; it is subtracted from the bracket around the launch
                 (e0, e1), (e2, _) = self._prof_event_pair(), self._prof_event_pair()
                 L.kr_event_record(e0, s)
                 L.kr_event_record(e1, s)
-            if self.wide_mode:
+            if fast:   # reads the accumulated f32 residual, rounds it once; workgroup 0 leaves the bf16 rows in x
+                self._dec_wide(DEC_SILU8, None, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                               x_f32=self.d_xacc, x_out=x, **self._w8kw(p + "gate_up.w"))
+            elif self.wide_mode:
                 self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                                **self._w8kw(p + "gate_up.w"))
             else:
@@ -1429,6 +1500,18 @@ class Engine:
         """Host-side stop (length limit): the slot idles from the next step on."""
         with torch.cuda.stream(self.stream):
             self.d_fin[slot:slot + 1].fill_(1)
+
+    def set_fast_residual(self, on: bool):
+        """Switch between the deterministic decode step (split-KV merge launch + slab reductions) and the fast-residual
+        one (per-head o_proj with float atomics); captured graphs of the other mode are dropped."""
+        on = bool(on) and self.narrow_mode and self.wide_mode
+        if on != self.fast_residual:
+            self.stream.synchronize()
+            for g in self._graphs.values():
+                self.L.kr_graph_destroy(g)
+            self._graphs.clear()
+            self.fast_residual = on
+        return self.fast_residual
 
     def close(self):
         for g in self._graphs.values():

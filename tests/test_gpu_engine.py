@@ -559,7 +559,7 @@ def test_full_size_qwen2_vl_2b_properties():
     assert pages[0].grids[0] == (1, 70, 70)
     steps = 24
     eng = Engine(cfg, max_batch=3, s_max=1536, max_patches=sum(len(p.pixel_values) for p in pages),
-                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=8)
+                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=16)
     eng.load_weights(random_weights(cfg, 0, as_bits=True))
     try:
         together = eng.generate(pages, steps, ignore_eos=True)

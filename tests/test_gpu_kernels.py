@@ -1450,8 +1450,35 @@ def test_attn_partials_merged_by_o_proj_prologue(L, H, KVH, n_split):
     assert_close_bf16(host(Xd), ref_linear(bf16_round(attn), Wo, res=X), rel=2 ** -6, abs_=3e-2, what="o_proj with merge")
 
 
+@pytest.mark.parametrize("H,KVH", [(12, 2), (28, 4), (3, 1)])
+@pytest.mark.parametrize("n_split", [8, 16, 32])
+def test_attn_decode_partials_then_merge_launch(L, H, KVH, n_split):
+    """The engine's deterministic path: split-KV partials (8 splits x 8 waves, 16 x 4, 32 x 2 workgroup shapes) and the
+    merge launch, at the contexts of the bench's decode loop."""
+    rng = np.random.default_rng(H * 10 + n_split + 7)
+    hd, s_max = 128, 2560
+    ctxs = [0, 31, 32, 1393, 1906, 2431, 2559]
+    B = len(ctxs)
+    kc = np.zeros((B, KVH, s_max, hd), np.float32); vc = np.zeros((B, KVH, s_max, hd), np.float32)
+    for b, c in enumerate(ctxs):
+        kc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
+        vc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
+    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    q = rnd(rng, B, H, hd)
+    kc_d, vt_d, q_d = dev_bf16(kc), dev_bf16(vt), dev_bf16(q)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    ws = torch.full((B * H * n_split * (hd + 4),), 9.0, dtype=torch.float32, device=DEV)
+    o_d = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
+    L.kr_attn_decode_fused(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), 0, ptr(ws), 0, B, H, KVH, hd, s_max, n_split, hd ** -0.5, 0)
+    L.kr_attn_decode_merge(ptr(ws), ptr(o_d), B, H, hd, n_split, 0)
+    got = host(o_d)
+    for b, c in enumerate(ctxs):
+        ref = np_attention(q[b][:, None], kc[b, :, :c + 1], vc[b, :, :c + 1], hd ** -0.5, False)
+        assert_close_bf16(got[b:b + 1], ref, rel=2 ** -6, abs_=2e-2, what=f"partials + merge b={b} n_split={n_split}")
+
+
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4)])
-@pytest.mark.parametrize("n_split", [1, 4, 8])
+@pytest.mark.parametrize("n_split", [1, 4, 8, 16])
 @pytest.mark.parametrize("long_ctx", [False, True])
 def test_attn_decode_fused(L, H, KVH, n_split, long_ctx):
     rng = np.random.default_rng(H * 10 + n_split)
@@ -1684,3 +1711,108 @@ def test_logprobs_topk_matches_oracle(L, V, n_part, k):
         with pytest.raises(KarantaHipError):
             L.kr_logprobs_topk(ptr(ld), V, V, k, 2, ptr(pv), ptr(pi), ptr(ms), ptr(d_tok), ptr(d_ctx), ptr(d_plen), ptr(d_fin),
                                ptr(out), ptr(oi), H, HB, KS, B, 0)
+
+
+# ----------------------------------------------------------------------------- fast-residual mode kernels
+@pytest.mark.parametrize("H,d,n_split,M", [(12, 1536, 8, 8), (28, 3584, 8, 4), (2, 256, 4, 3), (12, 1536, 8, 21), (16, 2048, 16, 16),
+                                            (3, 384, 1, 5)])
+def test_oproj_heads_merges_and_accumulates(L, H, d, n_split, M):
+    """kr_oproj_heads = attn_merge_kernel + o_proj + residual add, with K split by head and float atomics: against the
+    merge formula in numpy (merged head rounded to bf16, as the separate merge launch leaves it) and an f64 matmul."""
+    rng = np.random.default_rng(H * 1000 + d + n_split + M)
+    hd = 128
+    ws = np.zeros((M, H, n_split, hd + 4), np.float32)
+    ws[..., :hd] = rng.standard_normal((M, H, n_split, hd)).astype(np.float32) * 3
+    ws[..., hd] = rng.uniform(-20, 5, (M, H, n_split)).astype(np.float32)          # running max (log2 domain)
+    ws[..., hd + 1] = rng.uniform(0.5, 40, (M, H, n_split)).astype(np.float32)     # running sum
+    if n_split > 1:
+        ws[0, 0, 1, hd + 1] = 0.0; ws[0, 0, 1, :hd] = 0.0; ws[0, 0, 1, hd] = -1e30   # a split without keys
+    Wo = rnd(rng, d, H * hd, scale=(H * hd) ** -0.5)
+    x0 = rng.standard_normal((M, d)).astype(np.float32)
+    mm = ws[..., hd].max(-1, keepdims=True)
+    sc = np.exp2(ws[..., hd] - mm)
+    merged = (ws[..., :hd] * sc[..., None]).sum(2) / (ws[..., hd + 1] * sc).sum(-1)[..., None]
+    merged = bf16_round(merged.astype(np.float32)).reshape(M, H * hd)
+    ref = x0.astype(np.float64) + merged.astype(np.float64) @ Wo.astype(np.float64).T
+    wsd, Wd = torch.from_numpy(ws).to(DEV), dev_bf16(pack_w16x64(Wo))
+    pad = 24
+    acc = torch.zeros(M, d + pad, dtype=torch.float32, device=DEV)
+    acc[:, :d] = torch.from_numpy(x0).to(DEV)
+    for rep in range(2):                                   # twice: the kernel ADDS (2 x product), nothing else is touched
+        L.kr_oproj_heads(ptr(wsd), n_split, ptr(Wd), 0, ptr(acc), d + pad, M, d, H, 0)
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    assert not got[:, d:].any()
+    want = ref + (ref - x0)
+    np.testing.assert_allclose(got[:, :d], want, rtol=2e-5, atol=2e-4 * np.abs(want).max())
+
+
+def test_oproj_heads_fp8_weights(L):
+    rng = np.random.default_rng(5)
+    H, d, n_split, M, hd = 12, 1536, 8, 8, 128
+    from karanta_ocr_amd.weights import fp8_e4m3_to_f32, pack_w16x64_fp8, quantize_fp8_rows
+    ws = np.zeros((M, H, n_split, hd + 4), np.float32)
+    ws[..., :hd] = rng.standard_normal((M, H, n_split, hd)).astype(np.float32)
+    ws[..., hd] = rng.uniform(-3, 3, (M, H, n_split)).astype(np.float32)
+    ws[..., hd + 1] = rng.uniform(0.5, 4, (M, H, n_split)).astype(np.float32)
+    q, sc8 = quantize_fp8_rows(rnd(rng, d, H * hd, scale=(H * hd) ** -0.5))
+    Wf = fp8_e4m3_to_f32(q) * sc8[:, None]
+    mm = ws[..., hd].max(-1, keepdims=True)
+    sc = np.exp2(ws[..., hd] - mm)
+    merged = bf16_round(((ws[..., :hd] * sc[..., None]).sum(2) / (ws[..., hd + 1] * sc).sum(-1)[..., None]).astype(np.float32))
+    ref = merged.reshape(M, H * hd).astype(np.float64) @ Wf.astype(np.float64).T
+    acc = torch.zeros(M, d, dtype=torch.float32, device=DEV)
+    qd = torch.from_numpy(np.ascontiguousarray(pack_w16x64_fp8(q))).to(DEV)
+    sd = torch.from_numpy(sc8.astype(np.float32)).to(DEV)
+    L.kr_oproj_heads(ptr(torch.from_numpy(ws).to(DEV)), n_split, ptr(qd), ptr(sd), ptr(acc), d, M, d, H, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(acc.cpu().numpy(), ref, rtol=2e-5, atol=2e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,K,blocks,waves", [(8, 1536, 256, 5), (16, 3584, 9, 8), (3, 512, 2, 3), (21, 1536, 256, 8)])
+def test_linear_wide_f32_rows_equal_the_rounded_bf16_rows(L, M, K, blocks, waves):
+    """kr_linear_decode_wide_x32 (x rows from the f32 residual accumulator) = kr_linear_decode_wide on their bf16 rounding,
+    bit for bit; workgroup 0 leaves the rounded rows in x_out."""
+    rng = np.random.default_rng(M + K)
+    ff = 16 * 37
+    xf = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    W = rnd(rng, 2 * ff, K, scale=K ** -0.5)
+    nw = bf16_round(1 + 0.1 * rng.standard_normal(K).astype(np.float32))
+    Wd, nwd = dev_bf16(pack_w16x64(W)), dev_bf16(nw)
+    xfd = torch.from_numpy(np.concatenate([xf, np.zeros((M, 8), np.float32)], 1)).to(DEV)      # ldx = K + 8 floats
+    xbd = dev_bf16(bf16_round(xf))
+    out_a = torch.zeros(M, ff, dtype=torch.bfloat16, device=DEV); out_b = torch.zeros_like(out_a)
+    x_out = torch.zeros(M, K + 16, dtype=torch.bfloat16, device=DEV)
+    av = torch.zeros(M, blocks * waves, device=DEV); ai = torch.zeros(M, blocks * waves, dtype=torch.int32, device=DEV)
+    L.kr_linear_decode_wide_x32(DEC_SILU8, ptr(xfd), K + 8, ptr(x_out), K + 16, ptr(Wd), 0, ptr(nwd), 1e-6, ptr(out_a), 0, ff, M,
+                                2 * ff, K, blocks, waves, ptr(av), ptr(ai), 0)
+    L.kr_linear_decode_wide(DEC_SILU8, ptr(xbd), K, ptr(Wd), 0, ptr(nwd), 1e-6, 0, 0, ptr(out_b), 0, ff, M, 2 * ff, K, blocks, waves,
+                            ptr(av), ptr(ai), 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host(out_a), host(out_b))
+    np.testing.assert_array_equal(host(x_out)[:, :K], bf16_round(xf))
+    assert not host(x_out)[:, K:].any()
+
+
+@pytest.mark.parametrize("M,K,parts", [(8, 1536, True), (8, 1536, False), (21, 2048, True), (16, 3584, True)])
+def test_linear_narrow_x32_also_leaves_x_new_as_f32(L, M, K, parts):
+    """kr_linear_decode_narrow_x32: the same product as kr_linear_decode_narrow, and workgroup 0 stores x_new (the bf16
+    residual row it normalises) as f32 too — the start value of the fast-residual accumulator — inside ldxf only."""
+    rng = np.random.default_rng(900 + M + K)
+    N = 16 * 9
+    x, W, nw = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    p = (rng.standard_normal((2, M, K)) * 0.5).astype(np.float32)
+    xd, Wd, nd, pd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw), torch.from_numpy(p).to(DEV)
+    xo = torch.full((M, K), 5.0, dtype=torch.bfloat16, device=DEV)
+    xf = torch.full((M, K + 4), 7.0, dtype=torch.float32, device=DEV)
+    out_a = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV); out_b = torch.zeros_like(out_a)
+    L.kr_linear_decode_narrow_x32(DEC_PLAIN, ptr(xd), K, ptr(pd) if parts else 0, 2 if parts else 0, ptr(xo) if parts else 0,
+                                  K if parts else 0, ptr(xf), K + 4, ptr(Wd), 0, 0, ptr(nd), 1e-6, 0, 0, ptr(out_a), 0, N, M, N, K, 8, 1,
+                                  0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(out_b), ldc=N, norm_w=ptr(nd), part_in=ptr(pd) if parts else 0,
+                x_out=ptr(xo) if parts else 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host(out_a), host(out_b))
+    got = xf.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :K], host(xo) if parts else x)
+    assert (got[:, K:] == 7.0).all()

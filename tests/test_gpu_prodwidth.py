@@ -67,7 +67,7 @@ def m2b():
         pytest.skip("no GPU")
     cfg = PW.truncated_config("Qwen2-VL-2B", 4, 4)
     w = random_weights(cfg, 7, as_bits=True)
-    eng = Engine(cfg, max_batch=8, s_max=2048, max_patches=3 * 4960, max_prompt_tokens=3 * 1400, decode_splits=8)
+    eng = Engine(cfg, max_batch=8, s_max=2048, max_patches=3 * 4960, max_prompt_tokens=3 * 1400, decode_splits=16)
     eng.load_weights(w)
     assert eng.wide_mode and eng.narrow_mode and eng.defer_down, "the production decode kernels must be the ones running"
     yield cfg, w, eng
@@ -116,6 +116,23 @@ def test_2b_width_vit_prefill_and_greedy_tokens_match_oracle(m2b):
             tokens=[int(t) for t in res.tokens[0]], oracle_tokens=[int(t) for t in o_tok[0]])
     assert f_decisive >= 8, f"only {f_decisive} of {steps} teacher-forced steps were decisive"
     assert walked >= 4 and decisive >= 3, f"free run: only {decisive} decisive / {walked} walked steps of {steps}"
+    # ---- the FAST-RESIDUAL decode step (per-head o_proj + float atomics, no merge launch): same tolerance, same decisive
+    # tokens against the oracle; not bit-identical to the deterministic step by construction (sum order)
+    assert eng.set_fast_residual(True)
+    try:
+        fast = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
+        fast_decisive = PW.compare_teacher_forced(fast.tokens[0], fast.logits[0], o_tok[0], o_log[0], tol, "2B widths (fast residual)")
+        dev = float(np.abs(fast.logits[0] - forced.logits[0]).max())
+        fast_graph = eng.generate([page], steps, ignore_eos=True)
+        m = PW.margins(o_log[0])
+        for i in range(steps):           # the replayed graph of the fast step follows the oracle wherever it is decisive
+            if m[i] <= 2 * tol:
+                break
+            assert int(fast_graph.tokens[0][i]) == int(o_tok[0, i]), f"fast graph step {i}"
+        _record("2b_w_v4_l4_fast_residual", decisive=fast_decisive, max_logit_dev_vs_deterministic=dev, tol=tol)
+        assert fast_decisive == f_decisive and dev < 0.5 * tol
+    finally:
+        eng.set_fast_residual(False)
     # ---- the replayed graph gives the eager tokens; a ragged batch of 3 gives page 0 its solo tokens
     graph = eng.generate([page], steps, ignore_eos=True)
     np.testing.assert_array_equal(graph.tokens[0], res.tokens[0])
@@ -140,7 +157,7 @@ def test_7b_width_batch_of_4_matches_oracle(m7b, weight_dtype):
     pages = [small[0], small[1], PageRequest(ids, pv, [grid]), small[2]]
     steps = 10
     eng = Engine(cfg, max_batch=4, s_max=2048, max_patches=sum(len(p.pixel_values) for p in pages),
-                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=8, weight_dtype=weight_dtype)
+                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=16, weight_dtype=weight_dtype)
     eng.load_weights(w)
     try:
         assert eng.wide_mode and eng.narrow_mode and eng.defer_down
