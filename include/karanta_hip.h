@@ -168,6 +168,13 @@ int kr_attn_varlen(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf1
                    int64_t nq_total, int q_heads, int kv_heads, int hd,
                    int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal,
                    kr_stream s);
+/* The same with the work list's query-block size stated: 128 (4-wave workgroups, what kr_attn_varlen assumes) or 256
+ * (8-wave workgroups: twice the queries per staged K / V^T tile; the list must have been built for that block size). */
+int kr_attn_varlen_q(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out,
+                     const int32_t* qblk, const int32_t* qblk_len, int n_qblk,
+                     int64_t nq_total, int q_heads, int kv_heads, int hd,
+                     int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal,
+                     int q_block, kr_stream s);
 
 /* ------------------------------------------------------------------ decoder: embedding, M-RoPE, KV cache */
 
@@ -312,6 +319,12 @@ int kr_linear_decode_wide_x32(int mode, const float* x_f32, int64_t ldx, kr_bf16
  * sits in the memory-side Infinity Cache when a later launch streams it (the narrow launches of a decode step occupy
  * 64-96 of the 256 CUs).  bytes == 0 or blocks == 0 cancels. */
 int kr_decode_prefetch_next(const void* ptr, size_t bytes, int blocks);
+
+/* One-shot, consumed by the next kr_linear_decode_narrow* launch of this thread: its part_in slabs have `rows` rows each
+ * ([n_part_in][rows][K]) instead of M — the launch covers a row range of a larger batch whose down_proj wrote the slabs
+ * (decode batches above 16 rows at hidden sizes whose 32 x rows do not fit the LDS run the norm-prologue launches once
+ * per 16-row range).  0 restores the default. */
+int kr_decode_part_rows_next(int rows);
 
 /* The same two kernels on fp8 (OCP e4m3fn) weights — BASELINE.json config 5: decoder Linears in fp8 with one f32 scale
  * per output row, activations bf16.  w_packed_fp8 = weights.pack_w16x64_fp8 (one 16-row x 64-column block = 1 KiB in

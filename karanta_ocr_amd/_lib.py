@@ -48,6 +48,7 @@ SIGNATURES = {
                     i32, i32, i32, c_p],
     "kr_rope2d_vision": [c_p, c_p, c_p, i64, i32, i32, i64, c_p],
     "kr_attn_varlen": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i64, i32, i32, i32, i64, i64, f32, i32, c_p],
+    "kr_attn_varlen_q": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i64, i32, i32, i32, i64, i64, f32, i32, i32, c_p],
     "kr_embed_scatter": [c_p, c_p, c_p, c_p, i64, i32, c_p],
     "kr_mrope": [c_p, c_p, c_p, i64, i32, i32, i64, c_p],
     "kr_kv_append": [c_p, c_p, i64, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p],
@@ -74,6 +75,7 @@ SIGNATURES = {
                                 i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
     "kr_linear_decode_narrow_x32": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                     i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
+    "kr_decode_part_rows_next": [i32],
     "kr_decode_prefetch_next": [c_p, C.c_size_t, i32],
     "kr_oproj_heads": [c_p, i32, c_p, c_p, c_p, i64, i32, i32, i32, c_p],
     "kr_linear_decode_wide_x32": [i32, c_p, i64, c_p, i64, c_p, c_p, c_p, f32, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],

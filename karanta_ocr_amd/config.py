@@ -214,8 +214,17 @@ TINY_W512 = replace(
     text=replace(TINY.text, hidden_size=512, intermediate_size=1024, num_heads=4, num_kv_heads=1),
 )
 
+# Test size at the 7B decoder WIDTH (3584: the K = 3584 decode kernels; 32 rows of x do not fit the LDS, so batches above 16
+# rows run the x-staging launches once per 16-row range), everything else small.
+TINY_W3584 = replace(
+    TINY,
+    name="tiny-w3584",
+    vision=replace(TINY.vision, hidden_size=3584),
+    text=replace(TINY.text, hidden_size=3584, intermediate_size=1024, num_heads=4, num_kv_heads=1),
+)
+
 CONFIGS: Dict[str, ModelConfig] = {
-    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, QWEN2_5_VL_3B, QWEN2_5_VL_7B, TINY, TINY_GQA, TINY_25, TINY_W512)
+    c.name: c for c in (QWEN2_VL_2B, QWEN2_VL_7B, QWEN2_5_VL_3B, QWEN2_5_VL_7B, TINY, TINY_GQA, TINY_25, TINY_W512, TINY_W3584)
 }
 
 

@@ -134,8 +134,6 @@ struct AttnCfg {
     static constexpr int KCH = HD / 8;               // 16-byte chunks per K row
     static constexpr int KROW = (HD == 128) ? 256 : (KCH + 1) * 16;  // LDS K row bytes (hd=80: 176, conflict-free)
     static constexpr int VROW = 136;                 // LDS V^T row bytes (64 keys + 8 B pad: conflict-free b64 reads)
-    static constexpr int K_PASSES = (64 * KCH + 255) / 256;
-    static constexpr int V_PASSES = (HD * 8 + 255) / 256;
 };
 
 template <int HD>
@@ -144,14 +142,19 @@ __device__ __forceinline__ int k_lds_off(int key, int c) {
     return key * AttnCfg<HD>::KROW + (c << 4);
 }
 
-template <int HD, bool CAUSAL>
-__global__ void __launch_bounds__(256) attn_varlen_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k,
+// NW = waves per workgroup: 4 (128 queries) or 8 (256 queries sharing one K / V^T tile image: half the tile staging per
+// query, and at 48.6 KB of LDS per workgroup two 8-wave workgroups (4 waves per SIMD) fit a CU where three 4-wave ones
+// (3 per SIMD) did).
+template <int HD, bool CAUSAL, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k,
                                                           const kr_bf16* __restrict__ vt, kr_bf16* __restrict__ out,
                                                           const int32_t* __restrict__ qblk,
                                                           const int32_t* __restrict__ qblk_len, int64_t nq_total,
                                                           int q_heads, int group, int64_t k_head_stride,
                                                           int64_t vt_head_stride, float scale_log2e) {
     using C = AttnCfg<HD>;
+    constexpr int NTHR = NW * 64;
+    constexpr int K_PASSES = (64 * C::KCH + NTHR - 1) / NTHR, V_PASSES = (HD * 8 + NTHR - 1) / NTHR;
     // two K / V^T tile images: tile t+1 is written while tile t is read, one barrier per tile
     constexpr int K_BYTES = 64 * C::KROW, V_BYTES = C::DT * 32 * C::VROW;
     __shared__ __attribute__((aligned(16))) char k_s2[2 * K_BYTES];
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(256) attn_varlen_kernel(const kr_bf16* __restr
 
     // zero the padded V^T rows once (hd=80: rows 80..95 are never staged)
     if (C::DT * 32 > HD) {
-        for (int e = tid; e < (C::DT * 32 - HD) * C::VROW / 8; e += 256) {
+        for (int e = tid; e < (C::DT * 32 - HD) * C::VROW / 8; e += NTHR) {
             reinterpret_cast<u32x2*>(v_s2 + HD * C::VROW)[e] = (u32x2){0u, 0u};
             reinterpret_cast<u32x2*>(v_s2 + V_BYTES + HD * C::VROW)[e] = (u32x2){0u, 0u};
         }
@@ -198,11 +201,11 @@ __global__ void __launch_bounds__(256) attn_varlen_kernel(const kr_bf16* __restr
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    bf16x8 kreg[C::K_PASSES], vreg[C::V_PASSES];
+    bf16x8 kreg[K_PASSES], vreg[V_PASSES];
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int p = 0; p < C::K_PASSES; ++p) {
-            const int idx = p * 256 + tid;
+        for (int p = 0; p < K_PASSES; ++p) {
+            const int idx = p * NTHR + tid;
             if (idx < 64 * C::KCH) {
                 const int key = idx / C::KCH, c = idx - key * C::KCH;
                 int kg = t * 64 + key;
@@ -211,23 +214,23 @@ __global__ void __launch_bounds__(256) attn_varlen_kernel(const kr_bf16* __restr
             }
         }
 #pragma unroll
-        for (int p = 0; p < C::V_PASSES; ++p) {
-            const int idx = p * 256 + tid;
+        for (int p = 0; p < V_PASSES; ++p) {
+            const int idx = p * NTHR + tid;
             if (idx < HD * 8) vreg[p] = ld8(vbase + (int64_t)t * (HD * 64) + idx * 8);
         }
     };
     auto store_tile = [&](char* k_s, char* v_s) {
 #pragma unroll
-        for (int p = 0; p < C::K_PASSES; ++p) {
-            const int idx = p * 256 + tid;
+        for (int p = 0; p < K_PASSES; ++p) {
+            const int idx = p * NTHR + tid;
             if (idx < 64 * C::KCH) {
                 const int key = idx / C::KCH, c = idx - key * C::KCH;
                 *reinterpret_cast<bf16x8*>(k_s + k_lds_off<HD>(key, c)) = kreg[p];
             }
         }
 #pragma unroll
-        for (int p = 0; p < C::V_PASSES; ++p) {
-            const int idx = p * 256 + tid;
+        for (int p = 0; p < V_PASSES; ++p) {
+            const int idx = p * NTHR + tid;
             if (idx < HD * 8) {
                 const int d = idx >> 3, c = idx & 7;
                 const u32x4 w = __builtin_bit_cast(u32x4, vreg[p]);
@@ -599,27 +602,44 @@ extern "C" int kr_qkv_prep(const kr_bf16* qkv, int64_t ld_qkv, int q_off, int k_
     return KR_OK;
 }
 
-extern "C" int kr_attn_varlen(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out, const int32_t* qblk,
-                              const int32_t* qblk_len, int n_qblk, int64_t nq_total, int q_heads, int kv_heads, int hd,
-                              int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal, kr_stream s) {
+static int attn_varlen_impl(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out, const int32_t* qblk,
+                            const int32_t* qblk_len, int n_qblk, int64_t nq_total, int q_heads, int kv_heads, int hd,
+                            int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal, int q_block, kr_stream s) {
     KR_CHECK_ARG(q && k && vt && out && qblk && qblk_len, "kr_attn_varlen: null pointer");
     KR_CHECK_ARG(hd == 80 || hd == 128, "kr_attn_varlen: hd=%d (only 80, 128)", hd);
     KR_CHECK_ARG(q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "kr_attn_varlen: heads");
+    KR_CHECK_ARG(q_block == 128 || q_block == 256, "kr_attn_varlen: q_block=%d (128 or 256)", q_block);
     if (n_qblk == 0) return KR_OK;
     dim3 grid(n_qblk, q_heads);
     const float sl = scale * 1.4426950408889634f;
     const int group = q_heads / kv_heads;
-#define KR_LAUNCH_ATTN(HD_, C_)                                                                                     \
-    attn_varlen_kernel<HD_, C_><<<grid, 256, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total, q_heads, group, \
-                                                            k_head_stride, vt_head_stride, sl)
+#define KR_LAUNCH_ATTN(HD_, C_, NW_)                                                                                       \
+    attn_varlen_kernel<HD_, C_, NW_><<<grid, NW_ * 64, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total, q_heads, group, \
+                                                                      k_head_stride, vt_head_stride, sl)
+#define KR_LAUNCH_ATTN_Q(HD_, C_) do { if (q_block == 256) KR_LAUNCH_ATTN(HD_, C_, 8); else KR_LAUNCH_ATTN(HD_, C_, 4); } while (0)
     if (hd == 80) {
-        if (causal) KR_LAUNCH_ATTN(80, true); else KR_LAUNCH_ATTN(80, false);
+        if (causal) KR_LAUNCH_ATTN_Q(80, true); else KR_LAUNCH_ATTN_Q(80, false);
     } else {
-        if (causal) KR_LAUNCH_ATTN(128, true); else KR_LAUNCH_ATTN(128, false);
+        if (causal) KR_LAUNCH_ATTN_Q(128, true); else KR_LAUNCH_ATTN_Q(128, false);
     }
+#undef KR_LAUNCH_ATTN_Q
 #undef KR_LAUNCH_ATTN
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+extern "C" int kr_attn_varlen(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out, const int32_t* qblk,
+                              const int32_t* qblk_len, int n_qblk, int64_t nq_total, int q_heads, int kv_heads, int hd,
+                              int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal, kr_stream s) {
+    return attn_varlen_impl(q, k, vt, out, qblk, qblk_len, n_qblk, nq_total, q_heads, kv_heads, hd, k_head_stride, vt_head_stride,
+                            scale, causal, 128, s);
+}
+
+extern "C" int kr_attn_varlen_q(const kr_bf16* q, const kr_bf16* k, const kr_bf16* vt, kr_bf16* out, const int32_t* qblk,
+                                const int32_t* qblk_len, int n_qblk, int64_t nq_total, int q_heads, int kv_heads, int hd,
+                                int64_t k_head_stride, int64_t vt_head_stride, float scale, int causal, int q_block, kr_stream s) {
+    return attn_varlen_impl(q, k, vt, out, qblk, qblk_len, n_qblk, nq_total, q_heads, kv_heads, hd, k_head_stride, vt_head_stride,
+                            scale, causal, q_block, s);
 }
 
 extern "C" int kr_kv_append(const kr_bf16* k, const kr_bf16* v, int64_t row_stride, const int32_t* tok_seq,

@@ -48,6 +48,21 @@ void kr_set_error(const char* fmt, ...);
 
 static inline hipStream_t kr_hs(kr_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute is per (function, DEVICE): a launcher keeps one flag per device, not per process, so the
+// attribute is also set the day one process drives several GPUs (one process per GPU is the engine's model; a
+// capture in progress never reaches this because the engine runs every launch eagerly once before capturing).
+#define KR_MAX_DEVICES 64
+struct KrPerDeviceOnce {
+    bool done[KR_MAX_DEVICES] = {};
+    bool need() {                       // true exactly once per device (the caller then sets its attributes)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KR_MAX_DEVICES) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------- bf16 <-> f32 (device)
 __device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
 __device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN kept

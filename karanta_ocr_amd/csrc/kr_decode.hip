@@ -67,6 +67,7 @@ struct DecLinArgs {
     // narrow kernel: workgroups blockIdx.x >= groups are PREFETCHERS — they touch [pf_ptr, pf_ptr + pf_bytes) with
     // plain loads (the range lands in the memory-side Infinity Cache) on CUs the launch would otherwise leave idle
     const char* pf_ptr; int64_t pf_bytes; int pf_blocks;
+    int part_rows;                     // rows per slab of part_in (0: = M)
 };
 
 // One 64-wide K chunk of a 16-row weight tile in registers, and where its operands sit.
@@ -785,10 +786,9 @@ int launch_wide_x(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     const size_t lds = (size_t)a.M * (a.K * 2 + 16);
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_wide: x (%d rows, K=%d) needs %zu bytes of LDS", a.M, a.K, lds);
     auto fn = &dec_wide_kernel<EPI, NCH, W8, MT, XF32>;
-    static bool attr = false;
-    if (!attr) {
+    static KrPerDeviceOnce attr;
+    if (attr.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     fn<<<blocks, waves * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.ldx, a.M, a.N, a.wide_blocks, a.wide_waves, a.norm_eps, a);
     KR_CHECK_LAUNCH();
@@ -859,7 +859,8 @@ constexpr int DEPI_PARTIAL = 16;  // internal: PLAIN with deferred split-K slabs
 template <int NT, int EPI, int WAVES, int NCH, int PKS, bool NORM, int U, bool W8, int MT>
 __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* hx, const kr_bf16* hwp, const kr_bf16* hnorm_w, const float* hpart_in,
                                                                 int64_t hldx, int hM, int hN, int hK, int hcpb, float hnorm_eps,
-                                                                const DecLinArgs a) {
+                                                                int hprows, const DecLinArgs a) {
+    // hprows: rows per slab of part_in ([PKS][hprows][K]); = M unless the launch covers a row range of a larger batch
     // hot fields as leading scalars: preloaded into SGPRs at wave start (see WideHot)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WC = WChunk<W8>;
@@ -929,7 +930,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
                 xv[i] = ld8(hx + (int64_t)b * hldx + c * 8);
 #pragma unroll
                 for (int k = 0; k < PKS; ++k) {
-                    const float* pp = hpart_in + ((int64_t)k * M + b) * K + c * 8;
+                    const float* pp = hpart_in + ((int64_t)k * hprows + b) * K + c * 8;
                     pv[k][i][0] = *reinterpret_cast<const f32x4*>(pp);
                     pv[k][i][1] = *reinterpret_cast<const f32x4*>(pp + 4);
                 }
@@ -1032,7 +1033,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
                         for (int j = 0; j < 8; ++j) f[j] = bf2f(v[i][j]);
 #pragma unroll
                         for (int k = 0; k < PKS; ++k) {
-                            const float* pp = hpart_in + ((int64_t)k * M + b) * K + c * 8;
+                            const float* pp = hpart_in + ((int64_t)k * hprows + b) * K + c * 8;
                             const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -1242,14 +1243,13 @@ int launch_narrow_m(DecLinArgs& a, int groups, kr_stream s) {
     const size_t lds = xbytes + (size_t)WAVES * NT * 256 * 4;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode_narrow: M=%d K=%d needs %zu bytes of LDS", a.M, a.K, lds);
     auto fn = &dec_narrow_kernel<NT, EPI, WAVES, NCH, PKS, NORM, U, W8, MT>;
-    static bool attr = false;
-    if (!attr) {
+    static KrPerDeviceOnce attr;
+    if (attr.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     KR_CHECK_ARG(a.pf_blocks == 0 || a.ksplit == 1, "kr_linear_decode_narrow: prefetch workgroups need ksplit 1");
     fn<<<dim3(groups + a.pf_blocks, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.part_in, a.ldx, a.M, a.N, a.K, cpb,
-                                                                            a.norm_eps, a);
+                                                                            a.norm_eps, a.part_rows > 0 ? a.part_rows : a.M, a);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
@@ -1878,10 +1878,9 @@ int launch_dec(DecLinArgs& a, int groups, int max_blocks, kr_stream s) {
     const size_t lds = xbytes + red;
     KR_CHECK_ARG(lds <= 160 * 1024, "kr_linear_decode: needs %zu bytes of LDS (M=%d K=%d ksplit=%d)", lds, a.M, a.K, a.ksplit);
     auto fn = &dec_linear_kernel<NT, EPI, WAVES>;
-    static bool attr = false;
-    if (!attr) {
+    static KrPerDeviceOnce attr;
+    if (attr.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     fn<<<dim3(grid_x, a.ksplit), WAVES * 64, lds, kr_hs(s)>>>(a);
     KR_CHECK_LAUNCH();
@@ -2024,6 +2023,15 @@ extern "C" int kr_decode_prefetch_next(const void* ptr_, size_t bytes, int block
     return KR_OK;
 }
 
+// One-shot: the next narrow launch reads its deferred-split slabs as [n][rows][K] (a launch over a ROW RANGE of a larger
+// batch: the slabs were written for the whole batch).
+static thread_local int g_part_rows = 0;
+extern "C" int kr_decode_part_rows_next(int rows) {
+    KR_CHECK_ARG(rows >= 0 && rows <= 32, "kr_decode_part_rows_next: rows=%d", rows);
+    g_part_rows = rows;
+    return KR_OK;
+}
+
 static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
                                        kr_bf16* x_out, int64_t ldxo, const void* w_packed, const float* w_scale, const kr_bf16* bias,
                                        const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
@@ -2047,6 +2055,9 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
     a.M = M; a.N = N; a.K = K; a.ksplit = ksplit;
     a.part_in = part_in; a.x_out = x_out; a.ldxo = ldxo;
     a.x_out_f32 = x_out_f32; a.ldxf = ldxf;
+    a.part_rows = g_part_rows;
+    g_part_rows = 0;
+    KR_CHECK_ARG(a.part_rows == 0 || (part_in && a.part_rows >= M), "kr_linear_decode_narrow: part rows %d < M %d", a.part_rows, M);
     if (ksplit == 1) {   // a pending prefetch request rides on this launch
         a.pf_ptr = g_pf_ptr; a.pf_bytes = g_pf_bytes; a.pf_blocks = g_pf_blocks;
         g_pf_blocks = 0;

@@ -458,11 +458,10 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     const int tiles_n = (N + 255) / 256;
     const int64_t nwg = tiles_m * tiles_n;
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KrPerDeviceOnce attr_set;
+    if (attr_set.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     gemm_pipe_kernel<EPI, WPACK, W8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
                                                                             (unsigned)nwg, w_scale);
@@ -478,11 +477,10 @@ int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
     const int tiles_n = (N + G::BN - 1) / G::BN;
     const int64_t nwg = tiles_m * tiles_n;
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KrPerDeviceOnce attr_set;
+    if (attr_set.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK, G>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     gemm_kernel<EPI, WPACK, G><<<(unsigned)nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
                                                                                       tiles_n, (unsigned)nwg);

@@ -1,0 +1,58 @@
+"""Timing of the varlen attention kernel on page-sized segments: ViT (hd 80, full, 8 images of 70x70 patches) and decoder
+prefill (hd 128, causal GQA 12/2, 8 prompts of 1394 tokens), 128- vs 256-query workgroups.
+    python karanta_ocr_amd/csrc/tools/attn_microbench.py"""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from karanta_ocr_amd import positions as POS  # noqa: E402
+from karanta_ocr_amd._lib import lib, ptr  # noqa: E402
+
+L = lib()
+dev = "cuda:0"
+st = torch.cuda.Stream()
+S = st.cuda_stream
+
+
+def run(lens, H, KVH, hd, causal, q_block, reps=10):
+    n = sum(lens)
+    k_row0 = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    nb = [(x + 63) // 64 for x in lens]
+    vt0 = np.concatenate([[0], np.cumsum(nb)[:-1]])
+    plan = POS.make_attn_plan(lens, k_row0, vt0, causal, q_block=q_block)
+    torch.manual_seed(1234)     # the same operands for both block sizes: their outputs must then be bit-identical
+    q = (torch.randn(H, n, hd, device=dev) * 0.5).bfloat16()
+    k = (torch.randn(KVH, n, hd, device=dev) * 0.5).bfloat16()
+    vt = (torch.randn(KVH, plan.n_vt_blocks, hd, 64, device=dev)).bfloat16()
+    o = torch.zeros(n, H * hd, device=dev).bfloat16()
+    qb, ql = torch.from_numpy(plan.qblk).to(dev), torch.from_numpy(plan.qblk_len).to(dev)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
+
+    def launch():
+        L.kr_attn_varlen_q(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(qb), ptr(ql), plan.qblk.shape[0], n, H, KVH, hd, n * hd,
+                           plan.n_vt_blocks * hd * 64, hd ** -0.5, 1 if causal else 0, q_block, S)
+    launch(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        L.kr_event_record(e0, S)
+        for _ in range(reps):
+            launch()
+        L.kr_event_record(e1, S)
+        L.kr_event_synchronize(e1)
+        ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+        best = min(best, ms.value / reps)
+    flops = sum(4.0 * x * x * hd * H * (0.5 if causal else 1.0) for x in lens)
+    return best, flops / best / 1e9, o
+
+
+if __name__ == "__main__":
+    for name, (lens, H, KVH, hd, causal) in {"vit 8 x 4900, 16 heads x 80": ([4900] * 8, 16, 16, 80, False),
+                                              "prefill 8 x 1394, 12/2 heads x 128 causal": ([1394] * 8, 12, 2, 128, True),
+                                              "vit 1 x 19276": ([19276], 16, 16, 80, False)}.items():
+        outs = {}
+        for qb in (128, 256):
+            ms, tf, o = run(lens, H, KVH, hd, causal, qb)
+            outs[qb] = o
+            print(f"{name:45s} q_block {qb}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s", flush=True)
+        print("    max |diff| between the two block sizes:", float((outs[128].float() - outs[256].float()).abs().max()), flush=True)

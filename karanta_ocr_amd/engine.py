@@ -382,11 +382,14 @@ class Engine:
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
         self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
-        if self.B > 16 and not (self.wide_mode and self.narrow_mode and self.narrow_o and t.hidden_size <= 2048
-                                and t.intermediate_size % 64 == 0):
-            raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels with 32 rows of x in LDS: "
-                                  "hidden_size % 512 == 0 and <= 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B)")
-        self.fast_residual = self.fast_residual and self.wide_mode
+        if self.B > 16 and not (self.wide_mode and self.narrow_mode and self.narrow_o and t.intermediate_size % 64 == 0):
+            raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
+        # Above 16 rows the decode linears hold two 16-row column tiles per weight fragment, with all 32 normalised x rows
+        # in LDS — which fits up to hidden_size 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B).  Wider models (the 7B: 32 x 3584 bf16 =
+        # 229 KB against 160 KB of LDS) run the launches that stage x (qkv, gate/up, lm_head) ONCE PER 16-ROW RANGE: their
+        # weights stream twice per step, the others (o_proj, down_proj: x fragments straight from L2) once.
+        self.row_split = self.B > 16 and t.hidden_size > 2048
+        self.fast_residual = self.fast_residual and self.wide_mode and not self.row_split
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
         # one argmax partial per wave of the lm_head launch; the launch geometry depends on the row count (8 waves above
@@ -470,7 +473,7 @@ class Engine:
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _dec_narrow(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=8, ksplit=1,
-                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, x_out_f32=None):
+                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, x_out_f32=None, part_rows=0, row0=0):
         """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32.
         w8 / w_scale: the fp8 copy of W and its row scales (kr_linear_decode_narrow_fp8)."""
         t = self.cfg.text
@@ -479,9 +482,14 @@ class Engine:
         ldc = o.stride(-2) if o is not None else 0  # slabs of the deferred split are [ksplit][M][ldc] with the CURRENT M, packed in d_part
         head = (mode, ptr(x), x.stride(0), ptr(part_in), 2 if part_in is not None else 0, ptr(x_out),
                 x_out.stride(0) if x_out is not None else 0)
+        # row0: the launch covers batch rows row0 .. row0 + M - 1 (every per-sequence array is handed over from that row)
         tail = (ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
-                ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs), self.max_new, ptr(self.d_plen), ptr(self.d_ctx),
-                ptr(self.d_q), kc, vc, t.num_heads, t.num_kv_heads, self.s_max, self.s)
+                ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs[row0:]) if self.d_cs is not None else 0, self.max_new,
+                ptr(self.d_plen[row0:]), ptr(self.d_ctx[row0:]), ptr(self.d_q[row0:]),
+                kc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if kc else 0,
+                vc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if vc else 0, t.num_heads, t.num_kv_heads, self.s_max, self.s)
+        if part_rows:
+            self.L.kr_decode_part_rows_next(int(part_rows))
         if x_out_f32 is not None:    # fast-residual mode: workgroup 0 also stores x_new as the f32 accumulator's start value
             self.L.kr_linear_decode_narrow_x32(*head, ptr(x_out_f32), x_out_f32.stride(0), ptr(w8 if w8 is not None else W),
                                                ptr(w_scale), *tail)
@@ -514,12 +522,19 @@ class Engine:
         waves = self.wide_waves or (8 if M > 16 else min(8, -(-tiles // self.wide_blocks)))
         return min(self.wide_blocks, -(-tiles // waves)), waves
 
+    def _row_ranges(self, B: int):
+        """(first row, rows) of the launches that stage x rows in LDS: the whole batch, or 16-row ranges (row_split)."""
+        if self.row_split and B > 16:
+            return [(0, 16), (16, B - 16)]
+        return [(0, B)]
+
     def _amax_parts(self, M: int) -> int:
         """Argmax partials the lm_head launch writes per row at batch M (= its stride in d_amax_*): workgroups x waves."""
         wb, ww = self._wide_geometry(self.cfg.text.vocab_size, M)
         return wb * ww
 
-    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None, x_f32=None, x_out=None):
+    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None, x_f32=None, x_out=None,
+                  amax_row0: int = 0):
         """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream.
         x_f32 (fast-residual mode): the rows come from the f32 residual accumulator instead of x; x_out receives their
         bf16 rounding (workgroup 0)."""
@@ -532,8 +547,9 @@ class Engine:
                                              ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0, M, N, K, blocks, waves,
                                              ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
             return
+        av, ai = self.d_amax_v.view(-1)[amax_row0 * blocks * waves:], self.d_amax_i.view(-1)[amax_row0 * blocks * waves:]
         tail = (0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0, ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0,
-                M, N, K, blocks, waves, ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
+                M, N, K, blocks, waves, ptr(av), ptr(ai), self.s)
         if w8 is not None:
             self.L.kr_linear_decode_wide_fp8(mode, ptr(x), x.stride(0), ptr(w8), ptr(w_scale), *tail)
         else:
@@ -697,9 +713,9 @@ class Engine:
                               ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
                               ptr(self.v_q), self.v_q.stride(0), ptr(self.v_k), self.v_k.stride(0),
                               ptr(self.v_vt), self.v_vt.stride(0), H, H, hd, s)
-                L.kr_attn_varlen(ptr(self.v_q), ptr(self.v_k), ptr(self.v_vt), ptr(self.v_o), ptr(qblk), ptr(qlen),
-                                 plan.qblk.shape[0], self.v_q.shape[1], H, H, hd, self.v_k.stride(0),
-                                 self.v_vt.stride(0), hd ** -0.5, 0, s)
+                L.kr_attn_varlen_q(ptr(self.v_q), ptr(self.v_k), ptr(self.v_vt), ptr(self.v_o), ptr(qblk), ptr(qlen),
+                                   plan.qblk.shape[0], self.v_q.shape[1], H, H, hd, self.v_k.stride(0),
+                                   self.v_vt.stride(0), hd ** -0.5, 0, plan.q_block, s)
                 self._gemm(self.v_o, w.view(p + "proj.w"), self.v_x, n, bias=w.view(p + "proj.b"), res=self.v_x)
                 L.kr_layernorm(ptr(self.v_x), ptr(w.view(p + "ln2.w")), ptr(w.view(p + "ln2.b")), ptr(self.v_h), n, D, 1e-6, s)
                 self._gemm(self.v_h, w.view(p + "fc1.w"), self.v_f, n, bias=w.view(p + "fc1.b"), epi=EPI_QUICK_GELU)
@@ -731,9 +747,9 @@ class Engine:
                           ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
                           ptr(self.v_q), self.v_q.stride(0), ptr(self.v_k), self.v_k.stride(0),
                           ptr(self.v_vt), self.v_vt.stride(0), H, H, hd, s)
-            L.kr_attn_varlen(ptr(self.v_q), ptr(self.v_k), ptr(self.v_vt), ptr(self.v_o), ptr(qblk), ptr(qlen),
-                             plan.qblk.shape[0], self.v_q.shape[1], H, H, hd, self.v_k.stride(0),
-                             self.v_vt.stride(0), hd ** -0.5, 0, s)
+            L.kr_attn_varlen_q(ptr(self.v_q), ptr(self.v_k), ptr(self.v_vt), ptr(self.v_o), ptr(qblk), ptr(qlen),
+                               plan.qblk.shape[0], self.v_q.shape[1], H, H, hd, self.v_k.stride(0),
+                               self.v_vt.stride(0), hd ** -0.5, 0, plan.q_block, s)
             self._gemm(self.v_o, w.view(p + "proj.w"), self.v_x, n, bias=w.view(p + "proj.b"), res=self.v_x)
             L.kr_rmsnorm(ptr(self.v_x), D, ptr(w.view(p + "ln2.w")), ptr(self.v_h), n, D, 1e-6, s)
             self._gemm(self.v_h, w.view(p + "gate_up.w"), self.v_f, n, bias=w.view(p + "gate_up.b"), epi=EPI_SILU_MUL8)
@@ -955,9 +971,9 @@ class Engine:
                               ptr(blk_tok0), ptr(blk_ntok), ptr(blk_kr), ptr(blk_vb), len(plan.blk_tok0),
                               ptr(self.p_q), self.p_q.stride(0), ptr(kc), k_head_stride, ptr(vc), vt_head_stride,
                               H, KVH, hd, s)
-                L.kr_attn_varlen(ptr(self.p_q), ptr(kc), ptr(vc), ptr(self.p_o), ptr(qblk), ptr(qlen),
-                                 plan.qblk.shape[0], self.p_q.shape[1], H, KVH, hd, k_head_stride, vt_head_stride,
-                                 hd ** -0.5, 1, s)
+                L.kr_attn_varlen_q(ptr(self.p_q), ptr(kc), ptr(vc), ptr(self.p_o), ptr(qblk), ptr(qlen),
+                                   plan.qblk.shape[0], self.p_q.shape[1], H, KVH, hd, k_head_stride, vt_head_stride,
+                                   hd ** -0.5, 1, plan.q_block, s)
                 self._gemm(self.p_o, w.view(p + "o.w"), self.p_x, M, res=self.p_x, packed=True, **self._w8kw(p + "o.w"))
                 L.kr_rmsnorm(ptr(self.p_x), d, ptr(w.view(p + "ln2.w")), ptr(self.p_h), M, d, t.rms_norm_eps, s)
                 self._gemm(self.p_h, w.view(p + "gate_up.w"), self.p_act, M, epi=EPI_SILU_MUL8, packed=True, **self._w8kw(p + "gate_up.w"))
@@ -1006,12 +1022,15 @@ class Engine:
         x = self.d_x if x is None else x
         j = slot0  # rows j .. j+B-1 of every per-sequence array (the slot scheduler prefills single slots)
         logits = self.d_logits[j:] if (self._want_logits or self._sampling or self._logprobs is not None) else None
+        ranges = self._row_ranges(B)
         if self.wide_mode:
-            self._dec_wide(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits)
+            for r0, m in ranges:
+                self._dec_wide(DEC_ARGMAX, x[j + r0:], w.view("llm.lm_head"), m, norm_w=w.view("llm.norm.w"),
+                               out_f32=None if logits is None else logits[r0:], amax_row0=r0)
         else:
             self._dec(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits,
                       waves=self.wv_wide)
-        n_part = self._amax_parts(B) if self.wide_mode else self.n_amax
+        n_part = self._amax_parts(ranges[0][1]) if self.wide_mode else self.n_amax   # the stride the lm_head launches wrote with
         if self._sampling:
             # temperature > 0 somewhere in the batch: the partial argmax is redone on logits / T + Gumbel noise
             # (rows with T = 0 get their plain argmax back)
@@ -1085,15 +1104,21 @@ class Engine:
                 a1 = w.layout[p + hi + sfx][0] + (1 if sfx else 2) * int(np.prod(w.layout[p + hi + sfx][1]))
                 L.kr_decode_prefetch_next(w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks)
             if self.narrow_mode:
+                ranges = self._row_ranges(B)
                 if pending:
-                    self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
-                                     norm_w=w.view(p + "ln1.w"), part_in=self.d_part, x_out=x_other, kc=kc, vc=vc,
-                                     x_out_f32=xacc, **self._w8kw(p + "qkv.w"))
+                    slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packed them
+                    for r0, m in ranges:
+                        self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
+                                         norm_w=w.view(p + "ln1.w"), part_in=slabs[:, r0:], x_out=x_other[r0:], kc=kc, vc=vc,
+                                         x_out_f32=None if xacc is None else xacc[r0:], part_rows=B if len(ranges) > 1 else 0,
+                                         row0=r0, **self._w8kw(p + "qkv.w"))
                     x, x_other = x_other, x
                     pending = False
                 else:
-                    self._dec_narrow(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"),
-                                     norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, x_out_f32=xacc, **self._w8kw(p + "qkv.w"))
+                    for r0, m in ranges:
+                        self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
+                                         norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, x_out_f32=None if xacc is None else xacc[r0:],
+                                         row0=r0, **self._w8kw(p + "qkv.w"))
             else:
                 self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                           waves=self.wv_qkv, kc=kc, vc=vc)
@@ -1134,8 +1159,9 @@ class Engine:
                 self._dec_wide(DEC_SILU8, None, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                                x_f32=self.d_xacc, x_out=x, **self._w8kw(p + "gate_up.w"))
             elif self.wide_mode:
-                self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
-                               **self._w8kw(p + "gate_up.w"))
+                for r0, m in self._row_ranges(B):
+                    self._dec_wide(DEC_SILU8, x[r0:], w.view(p + "gate_up.w"), m, out=self.d_act[r0:], norm_w=w.view(p + "ln2.w"),
+                                   **self._w8kw(p + "gate_up.w"))
             else:
                 self._dec(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                           waves=self.wv_wide)
@@ -1504,7 +1530,7 @@ class Engine:
     def set_fast_residual(self, on: bool):
         """Switch between the deterministic decode step (split-KV merge launch + slab reductions) and the fast-residual
         one (per-head o_proj with float atomics); captured graphs of the other mode are dropped."""
-        on = bool(on) and self.narrow_mode and self.wide_mode
+        on = bool(on) and self.narrow_mode and self.wide_mode and not self.row_split
         if on != self.fast_residual:
             self.stream.synchronize()
             for g in self._graphs.values():

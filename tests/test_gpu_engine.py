@@ -327,17 +327,21 @@ def test_fp8_weight_engine_matches_oracle_on_dequantised_weights():
 
 
 @pytest.mark.gpu
-def test_batches_above_16_rows_equal_solo_generation():
-    """max_batch up to 32 (two 16-row column tiles in the decode linears; hidden_size <= 2048): 21 ragged pages decoded
-    together give each page the tokens it gets alone; the slot scheduler runs 20 slots; wider models are refused."""
+@pytest.mark.parametrize("name", ["tiny-w512", "tiny-w3584"])
+def test_batches_above_16_rows_equal_solo_generation(name):
+    """max_batch up to 32: 21 ragged pages decoded together give each page the tokens it gets alone; the slot scheduler
+    runs 20 slots.  tiny-w512: two 16-row column tiles per weight fragment, all x rows in LDS (hidden_size <= 2048).
+    tiny-w3584 (the 7B decoder width, BASELINE config 3's 32-rows-per-GPU variant): 32 x rows of 3584 do not fit the LDS,
+    the x-staging launches (qkv, gate/up, lm_head) run once per 16-row range, o_proj / down_proj on two column tiles."""
     from karanta_ocr_amd._lib import KarantaHipError
     from karanta_ocr_amd.config import CONFIGS
     from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
     from karanta_ocr_amd.weights import random_weights
-    cfg = CONFIGS["tiny-w512"]
+    cfg = CONFIGS[name]
     w = random_weights(cfg, 909)
     eng = Engine(cfg, max_batch=21, s_max=512, max_patches=4096, max_prompt_tokens=4096, decode_splits=2)
     eng.load_weights(w)
+    assert eng.row_split == (name == "tiny-w3584") and eng.defer_down == (name == "tiny-w3584")
     rng = np.random.default_rng(77)
     pages = []
     for i in range(21):
@@ -351,6 +355,18 @@ def test_batches_above_16_rows_equal_solo_generation():
     for i in (0, 7, 15, 16, 17, 20):
         alone = eng.generate([pages[i]], 10, ignore_eos=True)
         np.testing.assert_array_equal(alone.tokens[0], together.tokens[i])
+    # a page of the SECOND 16-row range against the oracle, teacher-forced inside the full batch (rows 16 .. 20 go through
+    # the second pass of every x-staging launch)
+    from tests.prodwidth import compare_teacher_forced
+    k = 17
+    o_tok, o_log = O.generate_greedy(cfg, w, pages[k].input_ids[None], pages[k].pixel_values, pages[k].grids, 10, policy="bf16",
+                                     ignore_eos=True, return_logits=True)
+    ft = np.stack([np.asarray(t[:9], np.int64) for t in together.tokens])
+    ft[k] = o_tok[0, :9]
+    forced = eng.generate(pages, 10, ignore_eos=True, return_logits=True, force_tokens=ft)
+    tol = 0.02 * float(np.abs(o_log[0, 0]).max())
+    n_dec = compare_teacher_forced(forced.tokens[k], forced.logits[k], o_tok[0], o_log[0], tol, f"{name} row {k} of 21")
+    assert n_dec >= 3, f"only {n_dec} decisive steps"
     sch = SlotScheduler(eng, max_tokens_cap=10, chunk=3)
     res = sch.run([SlotRequest(p, 4 + i % 7, tag=i) for i, p in enumerate(pages)])
     for i in (0, 3, 8, 16, 19, 20):        # EOS-aware solo runs (the tiny vocabulary hits an EOS id now and then)

@@ -454,7 +454,7 @@ def np_attention(q, k, v, scale, causal, q_pos0=0):
     return out.reshape(nq, H * hd).astype(np.float32)
 
 
-def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256):
+def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256, q_block=None):
     """Fused qkv rows -> kr_qkv_prep -> kr_attn_varlen, against numpy, for ragged segments."""
     rng = np.random.default_rng(seed)
     n = sum(lens)
@@ -465,6 +465,9 @@ def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256):
     sin = np.concatenate([np.sin(ang)] * 2, -1).astype(np.float32)
     if as_cache:
         plan = POS.prefill_attn_plan(lens, list(range(len(lens))), KVH, s_max)
+        if q_block is not None and q_block != plan.q_block:
+            plan = POS.make_attn_plan(lens, [i * KVH * s_max for i in range(len(lens))], [i * KVH * (s_max // 64) for i in range(len(lens))],
+                                      True, q_block=q_block)
         B = len(lens)
         k_out = torch.zeros(B, KVH, s_max, hd, dtype=torch.bfloat16, device=DEV)
         vt_out = torch.zeros(B, KVH, s_max // 64, hd, 64, dtype=torch.bfloat16, device=DEV)
@@ -472,7 +475,7 @@ def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256):
     else:
         assert KVH == H
         plan = POS.make_attn_plan(lens, np.concatenate([[0], np.cumsum(lens)[:-1]]),
-                                  np.concatenate([[0], np.cumsum([(x + 63) // 64 for x in lens])[:-1]]), causal)
+                                  np.concatenate([[0], np.cumsum([(x + 63) // 64 for x in lens])[:-1]]), causal, q_block=q_block)
         k_out = torch.zeros(KVH, n, hd, dtype=torch.bfloat16, device=DEV)
         vt_out = torch.full((KVH, plan.n_vt_blocks, hd, 64), 3.0, dtype=torch.bfloat16, device=DEV)
         k_hs, vt_hs = n * hd, plan.n_vt_blocks * hd * 64
@@ -484,8 +487,12 @@ def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256):
     L.kr_qkv_prep(ptr(qkv_d), qd + 2 * kd, 0, qd, qd + kd, ptr(cos_d), ptr(sin_d), ptr(args[0]), ptr(args[1]), ptr(args[2]),
                   ptr(args[3]), len(plan.blk_tok0), ptr(q_out), n * hd, ptr(k_out), k_hs, ptr(vt_out), vt_hs, H, KVH, hd, 0)
     scale = hd ** -0.5
-    L.kr_attn_varlen(ptr(q_out), ptr(k_out), ptr(vt_out), ptr(o), ptr(args[4]), ptr(args[5]), plan.qblk.shape[0], n, H,
-                     KVH, hd, k_hs, vt_hs, scale, 1 if causal else 0, 0)
+    if plan.q_block == 128:      # the entry point without a block size = 128-query work lists
+        L.kr_attn_varlen(ptr(q_out), ptr(k_out), ptr(vt_out), ptr(o), ptr(args[4]), ptr(args[5]), plan.qblk.shape[0], n, H,
+                         KVH, hd, k_hs, vt_hs, scale, 1 if causal else 0, 0)
+    else:
+        L.kr_attn_varlen_q(ptr(q_out), ptr(k_out), ptr(vt_out), ptr(o), ptr(args[4]), ptr(args[5]), plan.qblk.shape[0], n, H,
+                           KVH, hd, k_hs, vt_hs, scale, 1 if causal else 0, plan.q_block, 0)
     # ---- reference
     q = qkv[:, :qd].reshape(n, H, hd)
     k = qkv[:, qd:qd + kd].reshape(n, KVH, hd)
@@ -517,9 +524,10 @@ def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256):
     assert_close_bf16(host(o), ref, rel=2 ** -6, abs_=2e-2, what="attention out")
 
 
-@pytest.mark.parametrize("lens", [[24], [64], [130, 5, 200], [129], [1, 63, 65]])
-def test_vit_attention_hd80(L, lens):
-    run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens))
+@pytest.mark.parametrize("q_block", [128, 256])
+@pytest.mark.parametrize("lens", [[24], [64], [130, 5, 200], [129], [1, 63, 65], [257, 300]])
+def test_vit_attention_hd80(L, lens, q_block):
+    run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens), q_block=q_block)
 
 
 @pytest.mark.parametrize("lens", [[4900], [4920, 1408]])
@@ -534,10 +542,11 @@ def test_prefill_attention_hd128_page_sized_prompt(L):
     run_prep_attn(L, [1394, 77], H=12, KVH=2, hd=128, causal=True, seed=1394, as_cache=True, s_max=1408)
 
 
+@pytest.mark.parametrize("q_block", [128, 256])
 @pytest.mark.parametrize("lens", [[36], [130, 5, 200], [257]])
 @pytest.mark.parametrize("H,KVH", [(2, 1), (6, 2), (3, 3)])
-def test_prefill_attention_hd128_causal_gqa(L, lens, H, KVH):
-    run_prep_attn(L, lens, H=H, KVH=KVH, hd=128, causal=True, seed=sum(lens) + H, as_cache=True, s_max=320)
+def test_prefill_attention_hd128_causal_gqa(L, lens, H, KVH, q_block):
+    run_prep_attn(L, lens, H=H, KVH=KVH, hd=128, causal=True, seed=sum(lens) + H, as_cache=True, s_max=320, q_block=q_block)
 
 
 def test_attention_online_softmax_rescale_branch(L):
