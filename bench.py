@@ -276,7 +276,7 @@ def main():
     ap.add_argument("--page", type=int, default=1024, help="synthetic page side in pixels")
     ap.add_argument("--page-width", type=int, default=None, help="page width when not square (config 5: --page 2200 --page-width 1700)")
     ap.add_argument("--max-pixels", type=int, default=1003520, help="grid A (transformers class default)")
-    ap.add_argument("--profile-every", type=int, default=512, help="one eager decode step with HIP events around the gate/up launch every N steps")
+    ap.add_argument("--profile-every", type=int, default=1000, help="one eager decode step with HIP events around the gate/up launch every N steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--guided", action="store_true",

@@ -1208,7 +1208,7 @@ class Engine:
         if reset:
             self._prof_next = 0
         t = self.cfg.text
-        B = self._last_batch
+        B = self._row_ranges(self._last_batch)[0][1]
         nbytes = 2 * (2 * t.intermediate_size * t.hidden_size + t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
         raw = float(np.mean(vals)) if vals else 0.0
         null = float(np.mean(nulls)) if nulls else 0.0
@@ -1223,6 +1223,7 @@ class Engine:
         t, w, L = self.cfg.text, self.w, self.L
         e0, e1 = self._prof_event_pair()
         self._prof_next -= 1
+        B = self._row_ranges(B)[0][1]     # one launch of the step = one 16-row range when the batch is split by rows
         def chain(n):
             for _ in range(n):
                 for i in range(t.num_layers):
