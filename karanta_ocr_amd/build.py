@@ -24,7 +24,13 @@ HEADERS = [os.path.join(CSRC, "kr_common.h"), os.path.join(os.path.dirname(HERE)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast",
          # leading scalar kernel arguments arrive in SGPRs at wave start (kr_decode.hip: WideHot)
-         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         # MFMA results straight into VGPRs: gfx950's register file is unified, but by default the backend keeps MFMA
+         # accumulators in the AGPR half and copies them (v_accvgpr_read / _write) for every VALU use — 1680 such copies in
+         # kr_attention.hip (112 per 64-key tile of the ViT attention, a quarter of its VALU work), 3298 in kr_gemm.hip;
+         # with this option there are none and the kernels need 25-30 % fewer registers (attn_varlen<128> 336 -> 254:
+         # two waves per SIMD instead of one; the 128x128 GEMM 184 -> 126)
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc() -> str:

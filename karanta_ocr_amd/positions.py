@@ -124,12 +124,13 @@ class AttnPlan:
 
 
 def pick_q_block(lens: Sequence[int]) -> int:
-    """256-query workgroups (8 waves sharing one staged K / V^T tile) for page-sized segments — r2 microbench, outputs
-    bit-identical: ViT 8 x 4900 tokens 1.46 -> 1.39 ms per block, one 19 276-token page 2.75 -> 2.37 ms, causal prefill
-    8 x 1394 tokens 0.181 -> 0.116 ms per layer; 128-query workgroups for short segments (Qwen2.5-VL's 64-token
-    windows would leave 6 of the 8 waves without queries)."""
+    """Queries per attention workgroup: 128 (4 waves) or 256 (8 waves sharing one staged K / V^T tile).  r2 microbench
+    (outputs bit-identical either way; build with MFMA results in VGPRs): ViT 8 x 4900 tokens 1.339 ms (128) vs 1.377 (256)
+    per block; causal prefill 8 x 1394 tokens 0.107 vs 0.118 ms per layer; ONE 19 276-token page (config 5) 2.511 vs
+    2.344 ms.  The 8-wave shape pays where a segment has hundreds of K / V tiles to stage; short segments (Qwen2.5-VL's
+    64-token windows) would leave most of its waves without queries."""
     lens = [int(n) for n in lens if int(n) > 0]
-    return 256 if lens and sum(lens) / len(lens) >= 512 else 128
+    return 256 if lens and sum(lens) / len(lens) >= 8192 else 128
 
 
 def make_attn_plan(lens: Sequence[int], k_row0: Sequence[int], vt_blk0: Sequence[int], causal: bool,

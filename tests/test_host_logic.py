@@ -321,8 +321,9 @@ def test_load_checkpoint_bf16_and_fp8_compressed_tensors(tmp_path):
 
 def test_attn_plan_picks_the_workgroup_shape():
     P = POS
-    assert P.vit_attn_plan([(1, 70, 70)]).q_block == 256 and P.segments_attn_plan([64] * 40).q_block == 128
-    assert P.prefill_attn_plan([1394, 77], [0, 1], 2, 1408).q_block == 256
+    assert P.vit_attn_plan([(1, 70, 70)]).q_block == 128 and P.segments_attn_plan([64] * 40).q_block == 128
+    assert P.vit_attn_plan([(1, 158, 122)]).q_block == 256            # config 5's 19 276-patch page
+    assert P.prefill_attn_plan([1394, 77], [0, 1], 2, 1408).q_block == 128
     p128, p256 = P.make_attn_plan([300], [0], [0], False, q_block=128), P.make_attn_plan([300], [0], [0], False, q_block=256)
     assert p128.qblk[:, 1].tolist() == [128, 128, 44] and p256.qblk[:, 1].tolist() == [256, 44]
     with pytest.raises(ValueError):
