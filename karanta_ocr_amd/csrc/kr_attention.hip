@@ -254,6 +254,9 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
         // ---- S^T = K Q^T.  All K fragments of the tile are requested before the first MFMA (fetched just in time,
         // two at a time, each pair of MFMAs waited on its own LDS round trip).  (Holding the V^T fragments across
         // the softmax as well costs the second wave per SIMD at hd 80: measured 15 % slower.)
+        // (r2: requesting one 32-key half at a time does not lower the register peak — 186 either way, it sits in the
+        // softmax / PV phase — and forcing 3 waves per SIMD with __launch_bounds__ spills 28 registers into the loop:
+        // 1.65 ms per ViT block against 1.42 on the same box.)
         bf16x8 kf[2][C::KS];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
