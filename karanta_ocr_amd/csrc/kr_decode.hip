@@ -810,13 +810,239 @@ int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     return launch_wide_x<EPI, NCH, W8, MT, false>(a, blocks, waves, s);
 }
 
+// =====================================================================================
+// wide layers at 17..32 rows when 32 x rows do not fit the LDS (K = 3584: the 7B width): K IN TWO HALVES
+// =====================================================================================
+// 32 rows x 3584 bf16 = 229 KB against 160 KB of LDS.  The workgroup stages the rows' FIRST half of K (32 x 1792 bf16 =
+// 115 KB), every wave streams that half of each of its weight tiles into per-tile accumulators, then (one barrier) the
+// second half is staged over the first and the tiles' second halves follow.  Weights are read once; per wave the
+// stream is [tile 0, chunks 0..27] [tile 1, chunks 0..27] ... [tile 0, chunks 28..55] ...: 56 KB contiguous pieces.
+// The RMS statistic needs whole rows: the prologue loads both halves of the wave's 4 rows (the oldest loads, ahead of
+// the weight ring), keeps the first half in registers for staging and re-reads the second half (L2) when its turn comes.
+// Ring depth 7 (28 chunks per half = 4 x 7: slots stay static).  TMAX = tiles a wave may own (lm_head of the 7B model
+// on 256 x 8 waves: 9504 tiles -> 5).
+template <int EPI, bool W8>
+__global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, const kr_bf16* wpk, const kr_bf16* norm_w, int64_t ldx, int M,
+                                                          int N, int wide_blocks, int wide_waves, float norm_eps, const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using WC = WChunk<W8>;
+    constexpr int NCH = 56, CH = 28, U = 7, KHALF = CH * 64, HC = KHALF / 8;   // 224 16-byte pieces per half row
+    constexpr int NR = 4, RLH = 4, TMAX = 5, MT = 2;
+    constexpr int XROW = KHALF * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = wide_waves, nblk = wide_blocks;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ntiles = N >> 4, stride = nblk * W;
+    const bool has_norm = norm_w != nullptr;
+    const int t0 = blockIdx.x + nblk * wave;
+
+    // ---- rows wave, wave + W, ...: first half kept, second half only for the statistic
+    bf16x8 x0[NR][RLH], x1[NR][RLH], nw0[RLH];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int b = wave + r * W;
+        const kr_bf16* xp = x + (int64_t)(b < M ? b : 0) * ldx;
+#pragma unroll
+        for (int i = 0; i < RLH; ++i) {
+            const int c = min(lane + i * 64, HC - 1);
+            x0[r][i] = ld8(xp + c * 8);
+            x1[r][i] = ld8(xp + KHALF + c * 8);
+        }
+    }
+    {
+        const kr_bf16* np = has_norm ? norm_w : x;
+#pragma unroll
+        for (int i = 0; i < RLH; ++i) nw0[i] = ld8(np + min(lane + i * 64, HC - 1) * 8);
+    }
+    // ---- weight ring, first half of the first tile
+    WC wbuf[U];
+    const char* wbase = reinterpret_cast<const char*>(wpk) + lane * 16;
+    auto tile_ptr = [&](int i, int kh) {   // half kh of this wave's i-th tile (clamped: an absent tile re-reads the last one)
+        const int t = min(t0 + stride * i, ntiles - 1);
+        return wbase + ((int64_t)t * NCH + kh * CH) * WC::BYTES;
+    };
+    const int my_tiles = t0 < ntiles ? (ntiles - 1 - t0) / stride + 1 : 0;   // <= TMAX by the host's geometry check
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wbuf[u].load(tile_ptr(0, 0), u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float rs[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < RLH; ++i) {
+            if (lane + i * 64 < HC) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += bf2f(x0[r][i][j]) * bf2f(x0[r][i][j]) + bf2f(x1[r][i][j]) * bf2f(x1[r][i][j]);
+            }
+        }
+        ss = wave_sum(ss);
+        rs[r] = rsqrtf(ss / (float)(2 * KHALF) + norm_eps);
+    }
+    auto stage = [&](const bf16x8 (&xr)[NR][RLH], const bf16x8 (&nw)[RLH]) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int b = wave + r * W;
+            if (b < M) {
+#pragma unroll
+                for (int i = 0; i < RLH; ++i) {
+                    const int c = lane + i * 64;
+                    if (c < HC) {
+                        bf16x8 o = xr[r][i];
+                        if (has_norm) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[i][j]) * bfround(bf2f(xr[r][i][j]) * rs[r]));
+                        }
+                        *reinterpret_cast<bf16x8*>(smem + b * XROW + c * 16) = o;
+                    }
+                }
+            }
+        }
+    };
+    stage(x0, nw0);
+    __syncthreads();
+
+    f32x4 acc[TMAX][MT];
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const char* xl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xl[mt] = smem + min(fr + 16 * mt, M - 1) * XROW;
+
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        if (kh == 1) {
+            __syncthreads();                 // every wave has read the first half
+            // second half of the rows: re-read (they are in L2), normalise with the statistic of the whole row
+#pragma unroll
+            for (int i = 0; i < RLH; ++i) nw0[i] = ld8((has_norm ? norm_w : x) + (has_norm ? KHALF : 0) + min(lane + i * 64, HC - 1) * 8);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int b = wave + r * W;
+                const kr_bf16* xp = x + (int64_t)(b < M ? b : 0) * ldx + KHALF;
+#pragma unroll
+                for (int i = 0; i < RLH; ++i) x1[r][i] = ld8(xp + min(lane + i * 64, HC - 1) * 8);
+            }
+            stage(x1, nw0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < TMAX; ++i) {
+            if (i < my_tiles) {
+                const char* wp = tile_ptr(i, kh);
+                // what the ring runs on into: this wave's next tile in this half, else its first tile's second half
+                const bool next_tile = i + 1 < my_tiles;
+                const char* wpn = next_tile ? tile_ptr(i + 1, kh) : tile_ptr(0, 1);
+                const bool more = next_tile || kh == 0;
+                for (int cc = 0; cc < CH; cc += U) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int c = cc + u;
+                        if ((u & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                        const bf16x8 w0 = wbuf[u].frag(0), w1 = wbuf[u].frag(1);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xl[mt] + c * 128 + WC::x_byte(0, fg));
+                            const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xl[mt] + c * 128 + WC::x_byte(1, fg));
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa, acc[i][mt], 0, 0, 0);
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xb, acc[i][mt], 0, 0, 0);
+                        }
+                        const int cn = c + U;
+                        if (cn < CH) {
+                            wbuf[u].load(wp, cn);
+                        } else if (more) {
+                            wbuf[u].load(wpn, cn - CH);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogues, tile by tile (the same arithmetic as dec_wide_body)
+    float rbv[MT];
+    int rbi[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        rbv[mt] = -INFINITY;
+        rbi[mt] = 0x7fffffff;
+    }
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+        if (i >= my_tiles) break;
+        const int t = t0 + stride * i;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int b = fr + 16 * mt;
+            apply_w_scale(a.w_scale, t * 16 + fg * 4, acc[i][mt]);
+            if (EPI == DEPI_SILU8) {
+                float u4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u4[j] = __shfl_xor(acc[i][mt][j], 32, 64);
+                if (b < M && fg < 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[i][mt][j]) * u4[j]);
+                    *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
+                }
+            } else {   // ARGMAX
+                const int n = t * 16 + fg * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) better(rbv[mt], rbi[mt], acc[i][mt][j], n + j);
+                if (a.out_f32 && b < M) *reinterpret_cast<f32x4*>(a.out_f32 + (int64_t)b * a.ldc + n) = acc[i][mt];
+            }
+        }
+    }
+    if (EPI == DEPI_ARGMAX) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int b = fr + 16 * mt;
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                const float ov = __shfl_xor(rbv[mt], o, 64);
+                const int oi = __shfl_xor(rbi[mt], o, 64);
+                better(rbv[mt], rbi[mt], ov, oi);
+            }
+            if (fg == 0 && b < M) {   // a wave without tiles leaves (-inf, INT_MAX): the sampler reads every slot
+                a.amax_val[(int64_t)b * stride + t0] = rbv[mt];
+                a.amax_idx[(int64_t)b * stride + t0] = rbi[mt];
+            }
+        }
+    }
+}
+
+template <int EPI, bool W8>
+int launch_wide_kh(DecLinArgs& a, int blocks, int waves, kr_stream s) {
+    if constexpr (EPI == DEPI_SILU8 || EPI == DEPI_ARGMAX) {
+        KR_CHECK_ARG(waves == 8, "kr_linear_decode_wide: 17..32 rows at K = 3584 run 8 waves per workgroup (got %d)", waves);
+        KR_CHECK_ARG(((a.N >> 4) + blocks * waves - 1) / (blocks * waves) <= 5,
+                     "kr_linear_decode_wide: %d tiles over %d x %d waves is more than 5 tiles per wave", a.N >> 4, blocks, waves);
+        KR_CHECK_ARG(!a.x_is_f32 && !a.bias && !a.residual, "kr_linear_decode_wide: K-halves take bf16 x, no bias / residual");
+        const size_t lds = (size_t)32 * (28 * 64 * 2 + 16);
+        auto fn = &dec_wide_kh_kernel<EPI, W8>;
+        static KrPerDeviceOnce attr;
+        if (attr.need()) {
+            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        fn<<<blocks, 512, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.ldx, a.M, a.N, a.wide_blocks, a.wide_waves, a.norm_eps, a);
+        KR_CHECK_LAUNCH();
+        return KR_OK;
+    } else {
+        kr_set_error("kr_linear_decode_wide: M=%d > 16 at K = 3584 is built for the SILU8 and ARGMAX modes", a.M);
+        return KR_ERR_ARG;
+    }
+}
+
 template <int EPI, int NCH, bool W8>
 int launch_wide_w(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     if (a.M > 16) {  // two column tiles: only instantiated where 32 rows of x fit the LDS
         if constexpr (NCH == 56) {
-            kr_set_error("kr_linear_decode_wide: M=%d > 16 needs K <= 2048 (K=%d)", a.M, a.K);
-            return KR_ERR_ARG;
-        } else {
+            return launch_wide_kh<EPI, W8>(a, blocks, waves, s);      // 32 x rows do not fit the LDS: K in two halves
+        } else {   // (the generic K instantiation checks the LDS size itself: 32 rows fit up to K = 2048)
             return launch_wide_m<EPI, NCH, W8, 2>(a, blocks, waves, s);
         }
     }

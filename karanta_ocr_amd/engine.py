@@ -385,10 +385,13 @@ class Engine:
         if self.B > 16 and not (self.wide_mode and self.narrow_mode and self.narrow_o and t.intermediate_size % 64 == 0):
             raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
         # Above 16 rows the decode linears hold two 16-row column tiles per weight fragment, with all 32 normalised x rows
-        # in LDS — which fits up to hidden_size 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B).  Wider models (the 7B: 32 x 3584 bf16 =
-        # 229 KB against 160 KB of LDS) run the launches that stage x (qkv, gate/up, lm_head) ONCE PER 16-ROW RANGE: their
-        # weights stream twice per step, the others (o_proj, down_proj: x fragments straight from L2) once.
+        # in LDS — which fits up to hidden_size 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B).  At the 7B width (32 x 3584 bf16 = 229 KB
+        # against 160 KB of LDS) the wide launches (gate/up, lm_head) stage K in two halves (dec_wide_kh_kernel: weights
+        # still read once) and the qkv launch, whose norm prologue keeps whole rows per wave, runs ONCE PER 16-ROW RANGE
+        # (33 MB of 14 GB streamed twice); o_proj / down_proj read their x fragments straight from L2 on two column tiles.
         self.row_split = self.B > 16 and t.hidden_size > 2048
+        if self.row_split and t.hidden_size != 3584:
+            raise KarantaHipError("max_batch > 16 at hidden_size > 2048 is built for the 7B width (3584)")
         self.fast_residual = self.fast_residual and self.wide_mode and not self.row_split
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
@@ -523,7 +526,7 @@ class Engine:
         return min(self.wide_blocks, -(-tiles // waves)), waves
 
     def _row_ranges(self, B: int):
-        """(first row, rows) of the launches that stage x rows in LDS: the whole batch, or 16-row ranges (row_split)."""
+        """(first row, rows) of the qkv launches: the whole batch, or 16-row ranges when 32 x rows do not fit (row_split)."""
         if self.row_split and B > 16:
             return [(0, 16), (16, B - 16)]
         return [(0, B)]
@@ -1022,15 +1025,12 @@ class Engine:
         x = self.d_x if x is None else x
         j = slot0  # rows j .. j+B-1 of every per-sequence array (the slot scheduler prefills single slots)
         logits = self.d_logits[j:] if (self._want_logits or self._sampling or self._logprobs is not None) else None
-        ranges = self._row_ranges(B)
         if self.wide_mode:
-            for r0, m in ranges:
-                self._dec_wide(DEC_ARGMAX, x[j + r0:], w.view("llm.lm_head"), m, norm_w=w.view("llm.norm.w"),
-                               out_f32=None if logits is None else logits[r0:], amax_row0=r0)
+            self._dec_wide(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits)
         else:
             self._dec(DEC_ARGMAX, x[j:], w.view("llm.lm_head"), B, norm_w=w.view("llm.norm.w"), out_f32=logits,
                       waves=self.wv_wide)
-        n_part = self._amax_parts(ranges[0][1]) if self.wide_mode else self.n_amax   # the stride the lm_head launches wrote with
+        n_part = self._amax_parts(B) if self.wide_mode else self.n_amax   # the stride the lm_head launch wrote with
         if self._sampling:
             # temperature > 0 somewhere in the batch: the partial argmax is redone on logits / T + Gumbel noise
             # (rows with T = 0 get their plain argmax back)
@@ -1159,9 +1159,8 @@ class Engine:
                 self._dec_wide(DEC_SILU8, None, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                                x_f32=self.d_xacc, x_out=x, **self._w8kw(p + "gate_up.w"))
             elif self.wide_mode:
-                for r0, m in self._row_ranges(B):
-                    self._dec_wide(DEC_SILU8, x[r0:], w.view(p + "gate_up.w"), m, out=self.d_act[r0:], norm_w=w.view(p + "ln2.w"),
-                                   **self._w8kw(p + "gate_up.w"))
+                self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
+                               **self._w8kw(p + "gate_up.w"))
             else:
                 self._dec(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
                           waves=self.wv_wide)
@@ -1208,7 +1207,7 @@ class Engine:
         if reset:
             self._prof_next = 0
         t = self.cfg.text
-        B = self._row_ranges(self._last_batch)[0][1]
+        B = self._last_batch
         nbytes = 2 * (2 * t.intermediate_size * t.hidden_size + t.hidden_size + B * t.hidden_size + B * t.intermediate_size)
         raw = float(np.mean(vals)) if vals else 0.0
         null = float(np.mean(nulls)) if nulls else 0.0
@@ -1223,7 +1222,6 @@ class Engine:
         t, w, L = self.cfg.text, self.w, self.L
         e0, e1 = self._prof_event_pair()
         self._prof_next -= 1
-        B = self._row_ranges(B)[0][1]     # one launch of the step = one 16-row range when the batch is split by rows
         def chain(n):
             for _ in range(n):
                 for i in range(t.num_layers):

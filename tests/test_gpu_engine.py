@@ -332,7 +332,8 @@ def test_batches_above_16_rows_equal_solo_generation(name):
     """max_batch up to 32: 21 ragged pages decoded together give each page the tokens it gets alone; the slot scheduler
     runs 20 slots.  tiny-w512: two 16-row column tiles per weight fragment, all x rows in LDS (hidden_size <= 2048).
     tiny-w3584 (the 7B decoder width, BASELINE config 3's 32-rows-per-GPU variant): 32 x rows of 3584 do not fit the LDS,
-    the x-staging launches (qkv, gate/up, lm_head) run once per 16-row range, o_proj / down_proj on two column tiles."""
+    gate/up and lm_head stage K in two halves (dec_wide_kh_kernel), the qkv launch runs once per 16-row range, o_proj /
+    down_proj on two column tiles."""
     from karanta_ocr_amd._lib import KarantaHipError
     from karanta_ocr_amd.config import CONFIGS
     from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler

@@ -930,12 +930,51 @@ def test_linear_wide_at_the_bench_shapes(L):
         assert i_[b, best] == int(np.flatnonzero(ref[b] == ref[b].max())[0]) and a_[b, best] == ref[b].max()
 
 
-def test_linear_wide_rejects_33_rows_and_k3584_above_16(L):
+@pytest.mark.parametrize("M", [17, 21, 32])
+@pytest.mark.parametrize("N,blocks", [(16 * 37, 3), (16 * 300, 11), (16 * 90, 256), (16 * 1200, 32)])
+def test_linear_wide_k_halves_at_the_7b_width(L, M, N, blocks):
+    """17..32 rows at K = 3584 (32 x rows do not fit the LDS): dec_wide_kh_kernel stages K in two halves.  Fused RMSNorm +
+    SiLU*mul against the numpy reference, and — exact on integers — the logits and the per-wave argmax partials of every
+    row (1..5 tiles per wave, waves without tiles, the ring running from one tile's half into the next)."""
+    rng = np.random.default_rng(M + N + blocks)
+    K, waves = 3584, 8
+    ff = N // 2 - (N // 2) % 8
+    x2, Wp, nw = rnd(rng, M, K, scale=2.0), rnd(rng, 2 * ff, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    xn = bf16_round(O.rms_norm(x2, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(run_wide(L, DEC_SILU8, x2, Wp, blocks, waves, norm_w=nw), ref_linear(xn, Wp, epi=EPI_SILU_MUL8),
+                      what="wide silu8, K halves")
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    W[:, K // 2 + 40:] = 0                      # a wrong half / chunk order shows
+    W[::3, 100:300] = 1
+    W[1::5, 1800:1900] = -1
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    n_part = blocks * waves
+    av = torch.zeros(M, n_part, device=DEV); ai = torch.zeros(M, n_part, dtype=torch.int32, device=DEV)
+    lg = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    L.kr_linear_decode_wide(DEC_ARGMAX, ptr(xd), K, ptr(Wd), 0, 0, 1e-6, 0, 0, 0, ptr(lg), N, M, N, K, blocks, waves, ptr(av), ptr(ai), 0)
+    torch.cuda.synchronize()
+    ref = ref_linear(x, W)
+    np.testing.assert_array_equal(lg.cpu().numpy(), ref)
+    a_, i_ = av.cpu().numpy(), ai.cpu().numpy()
+    for b in range(M):
+        best = int(np.lexsort((i_[b], -a_[b]))[0])
+        assert i_[b, best] == int(np.flatnonzero(ref[b] == ref[b].max())[0]) and a_[b, best] == ref[b].max()
+    if N // 16 < n_part:                        # waves without a tile leave (-inf, INT_MAX)
+        assert np.isneginf(a_[:, N // 16:]).all() and (i_[:, N // 16:] == 0x7fffffff).all()
+
+
+def test_linear_wide_rejects_33_rows_and_unsupported_17_row_shapes(L):
     x = torch.zeros(33, 3584, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(KarantaHipError):
         L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 512, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 33, 16, 512, 1, 4, 0, 0, 0)
-    with pytest.raises(KarantaHipError):     # 17 rows of K = 3584 do not go with the row registers / LDS
-        L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 3584, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 17, 16, 3584, 1, 4, 0, 0, 0)
+    with pytest.raises(KarantaHipError):     # 17 rows at K = 3584: SILU8 / ARGMAX only (K halves), 8 waves, <= 5 tiles per wave
+        L.kr_linear_decode_wide(DEC_PLAIN, ptr(x), 3584, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 17, 16, 3584, 1, 8, 0, 0, 0)
+    with pytest.raises(KarantaHipError):
+        L.kr_linear_decode_wide(DEC_SILU8, ptr(x), 3584, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 17, 32, 3584, 1, 4, 0, 0, 0)
+    with pytest.raises(KarantaHipError):
+        L.kr_linear_decode_wide(DEC_SILU8, ptr(x), 3584, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16 * 50, 17, 32 * 50, 3584, 1, 8, 0, 0, 0)
+    with pytest.raises(KarantaHipError):     # 32 rows at K = 3072: they do not fit the LDS and there is no K-halves build
+        L.kr_linear_decode_wide(DEC_SILU8, ptr(x), 3072, ptr(x), 0, 0, 1e-6, 0, 0, ptr(x), 0, 16, 32, 32, 3072, 1, 8, 0, 0, 0)
 
 
 def test_linear_wide_argmax_and_sample(L):
