@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--page", type=int, default=1024)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans (encoded once, cycled)")
     ap.add_argument("--admit", type=int, default=8, help="pages one admission may prefill together")
+    ap.add_argument("--admit-min", type=int, default=4, help="free slots (and waiting requests) an admission waits for while others decode")
+    ap.add_argument("--admit-max-wait", type=int, default=4, help="... but never longer than this many scheduler steps")
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU front end")
     ap.add_argument("--guided", action="store_true", help="every request carries the pipeline's guided_regex")
     args = ap.parse_args()
@@ -62,7 +64,7 @@ def main():
                  max_patches=args.admit * n_patch, max_prompt_tokens=args.admit * P)
     eng.load_weights(random_weights(cfg, 0, as_bits=True))
     srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=True, max_tokens_cap=args.t_max, chunk=args.chunk,
-                        honor_temperature=False)
+                        honor_temperature=False, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait)
     port = 8791
     S.register_local_server(port, srv)
     guided = (r"---\nprimary_language: (?:[a-z]{2}|null)\nis_rotation_valid: (?:True|False|true|false)\n"
@@ -109,6 +111,7 @@ def main():
         "workload": f"{args.model}, {args.pages} requests over {args.distinct} synthetic {args.page}x{args.page} PNG scans through "
                     f"VLLMClient.generate -> LocalServer(continuous), {args.workers} worker threads, {B} decode slots, "
                     f"max_tokens U[{args.t_min},{args.t_max}] (mean {np.mean(limits):.0f}), prompt {P} tokens, "
+                    f"admit_min {args.admit_min} (max wait {args.admit_max_wait} x {args.chunk} steps), "
                     f"{'host PIL' if args.host_images else 'GPU'} image front end, {'guided_regex' if args.guided else 'greedy'}, "
                     f"random-init weights",
         "pages_per_s": round(args.pages / wall, 3), "tokens_per_s": round(sum(toks) / wall, 1), "wall_s": round(wall, 2),

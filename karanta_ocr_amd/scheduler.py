@@ -43,7 +43,8 @@ class SlotScheduler:
 
     def __init__(self, engine, max_tokens_cap: int, chunk: int = 16, eos_token_ids: Optional[Sequence[int]] = None,
                  max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False,
-                 overlap: bool = False, guided: bool = False, logprobs: Optional[int] = None):
+                 overlap: bool = False, guided: bool = False, logprobs: Optional[int] = None, admit_min: int = 1,
+                 admit_max_wait: int = 4):
         if max_tokens_cap < 1 or chunk < 1:
             raise ValueError("max_tokens_cap and chunk must be >= 1")
         self.engine = engine
@@ -59,6 +60,11 @@ class SlotScheduler:
         # (Engine.admit_begin / admit_ready / admit_end); one admission in flight at a time
         self.overlap = bool(overlap) and all(hasattr(engine, m) for m in ("admit_begin", "admit_ready", "admit_end"))
         self._inflight = None                        # (handle, requests, slots)
+        # Admission batching: while sequences are decoding, wait until `admit_min` slots are free (and as many requests
+        # wait) before interrupting the decode graph with an admission — one ViT + prefill over several pages runs its
+        # GEMMs at several times the rows of a single page — but never longer than `admit_max_wait` scheduler steps.
+        self.admit_min, self.admit_max_wait = max(1, int(admit_min)), max(0, int(admit_max_wait))
+        self._held = 0                               # scheduler steps the oldest admissible request has been held back
         self.steps = 0                               # decode steps run
         self.slot_steps_busy = 0                     # sum over steps of occupied slots (utilisation numerator)
         # a slot may run up to chunk - 1 steps past its limit before the host looks: size the history for that
@@ -147,6 +153,12 @@ class SlotScheduler:
     # ------------------------------------------------------------------ internals
     def _admit(self, begin_only: bool = False) -> List[SlotResult]:
         free = [j for j in range(self.n_slots) if j not in self.active]
+        if self.active and self.waiting and free and self.admit_min > 1:
+            ready = min(len(free), len(self.waiting))
+            if ready < min(self.admit_min, self.n_slots) and self._held < self.admit_max_wait:
+                self._held += 1
+                return []
+        self._held = 0
         batch: List[SlotRequest] = []
         tok_budget = self.max_prompt_tokens
         patch_budget = self.max_patches

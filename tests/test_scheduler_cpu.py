@@ -227,3 +227,29 @@ def test_oversized_request_fails_alone_with_a_client_error():
     assert res[2].error is None and res[2].tokens.tolist() == [99]
     assert ("admit", (0, 1)) in eng.log                                        # the two that fit went in together
     assert eng.budgets == [10 + 4, 5 + 4]
+
+
+def test_admission_batching_waits_for_several_free_slots_but_not_forever():
+    """admit_min = 2: while something decodes, one free slot alone does not trigger an admission (requests entering
+    together share one ViT + prefill launch sequence); after admit_max_wait scheduler steps the wait ends; results are
+    what they are without batching."""
+    script = {0: [1] * 30, 1: [2, 99], 2: [3] * 8 + [99], 3: [4, 99], 4: [5, 5, 99]}
+    reqs = lambda: [SlotRequest(Page([k, 0]), 40, tag=k) for k in range(5)]
+    plain = SlotScheduler(FakeEngine(2, script), max_tokens_cap=40, chunk=2).run(reqs())
+    eng = FakeEngine(2, script)
+    sch = SlotScheduler(eng, max_tokens_cap=40, chunk=2, admit_min=2, admit_max_wait=3)
+    res = sch.run(reqs())
+    for a, b in zip(plain, res):
+        assert a.tokens.tolist() == b.tokens.tolist() and a.finish_reason == b.finish_reason
+    admits = [e[1] for e in eng.log if e[0] == "admit"]
+    assert admits[0] == (0, 1)                                   # nothing decoding: no waiting
+    # request 1 finishes at once; slot 1 is free while slot 0 decodes its 30 tokens: the next admission is held back
+    # for 3 scheduler steps, then goes alone (only one slot can be free)
+    steps_between = [e for e in eng.log[eng.log.index(("admit", (0, 1))) + 1:]]
+    first_admit_after = next(i for i, e in enumerate(steps_between) if e[0] == "admit")
+    assert first_admit_after == 4, steps_between[:6]            # 1 harvest step + 3 held steps of decoding before it
+    eng2 = FakeEngine(4, script)
+    sch2 = SlotScheduler(eng2, max_tokens_cap=40, chunk=2, admit_min=2, admit_max_wait=50)
+    sch2.run(reqs())
+    assert all(len(e[1]) >= 2 or i == len([x for x in eng2.log if x[0] == "admit"]) - 1
+               for i, e in enumerate([x for x in eng2.log if x[0] == "admit"]))
