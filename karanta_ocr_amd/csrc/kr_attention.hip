@@ -127,6 +127,23 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
 //   O^T[d][q]   += V^T (A operand, LDS) x P^T (B operand = the S^T accumulators, converted in
 //   place to bf16: no LDS round trip, the MFMA k-order permutation is absorbed by reading V^T
 //   keys in the same order)                                               HD/32 x 4 MFMA
+// Diagnostic build only (-DKR_ATTN_STAMPS, tools/build_variant.py): s_memtime stamps around the segments of one tile
+// iteration, summed per wave and left in a buffer of their own; no shipped build contains a stamp.
+#ifdef KR_ATTN_STAMPS
+__device__ unsigned long long kr_attn_dbg[8 * 8];
+#define KR_STAMP(var)                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0)
+extern "C" int kr_attn_debug_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kr_attn_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+#else
+#define KR_STAMP(var)
+#endif
+#ifndef KR_ATTN_VPRE
+#define KR_ATTN_VPRE(HD) ((HD) == 80 ? 3 : 0)
+#endif
 template <int HD>
 struct AttnCfg {
     static constexpr int KS = HD / 16;               // QK^T k-steps
@@ -143,10 +160,14 @@ __device__ __forceinline__ int k_lds_off(int key, int c) {
 }
 
 // NW = waves per workgroup: 4 (128 queries) or 8 (256 queries sharing one K / V^T tile image: half the tile staging per
-// query, and at 48.6 KB of LDS per workgroup two 8-wave workgroups (4 waves per SIMD) fit a CU where three 4-wave ones
-// (3 per SIMD) did).
+// query).  Either way the registers (~200-254) allow two waves per SIMD — amdgpu_waves_per_eu(2) makes the compiler keep
+// that — and the loop is bound by vector-ALU ISSUE slots (per 64-key tile and wave: 32 v_exp + 32 v_fma + 16 v_max3 +
+// 16 v_cvt_pk + addresses, about as many cycles as the tile's 22 (hd 80) / 32 (hd 128) MFMAs hold the matrix pipe), so
+// what the r2 work removed were instructions and waits, not bytes: see the comments at the staging lambdas, at ONES
+// and at the permlane swap.  -DKR_ATTN_STAMPS (tools/build_variant.py) builds the per-segment cycle stamps this was
+// read from.
 template <int HD, bool CAUSAL, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k,
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) attn_varlen_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k,
                                                           const kr_bf16* __restrict__ vt, kr_bf16* __restrict__ out,
                                                           const int32_t* __restrict__ qblk,
                                                           const int32_t* __restrict__ qblk_len, int64_t nq_total,
@@ -154,15 +175,23 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
                                                           int64_t vt_head_stride, float scale_log2e) {
     using C = AttnCfg<HD>;
     constexpr int NTHR = NW * 64;
-    constexpr int K_PASSES = (64 * C::KCH + NTHR - 1) / NTHR, V_PASSES = (HD * 8 + NTHR - 1) / NTHR;
-    // two K / V^T tile images: tile t+1 is written while tile t is read, one barrier per tile
-    constexpr int K_BYTES = 64 * C::KROW, V_BYTES = C::DT * 32 * C::VROW;
-    __shared__ __attribute__((aligned(16))) char k_s2[2 * K_BYTES];
-    __shared__ __attribute__((aligned(16))) char v_s2[2 * V_BYTES];
+    // staging: the tile's 16-byte chunks, K rows then V^T rows, as ONE list dealt to the threads in whole passes
+    constexpr int K_CH = 64 * C::KCH, V_CH = HD * 8, T_CH = K_CH + V_CH, PASSES = (T_CH + NTHR - 1) / NTHR;
+    constexpr int VPRE = KR_ATTN_VPRE(HD);  // V^T tiles prefetched across the softmax
+    // two tile images [K | V^T]: tile t+1 is written while tile t is read, one barrier per tile
+    constexpr int K_BYTES = 64 * C::KROW, V_BYTES = C::DT * 32 * C::VROW, IMG = K_BYTES + V_BYTES;
+    __shared__ __attribute__((aligned(16))) char img_s[2 * IMG];
+#ifdef KR_ATTN_LDS_PAD
+    __shared__ char lds_pad[KR_ATTN_LDS_PAD];
+    if (nq_total < 0) lds_pad[threadIdx.x] = 1, out[0] = lds_pad[threadIdx.x ^ 1];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
-    const int bi = blockIdx.x, head = blockIdx.y, kvh = head / group;
+    // head is the fastest index of the 1-D grid: the workgroups of one query block start together (the plan lists the
+    // blocks heaviest first, so a causal launch is scheduled longest-job-first over ALL heads), and with workgroups
+    // dealt round-robin to the 8 XCDs each L2 holds the K / V^T of heads h = xcd (mod 8) only
+    const int bi = blockIdx.x / q_heads, head = blockIdx.x - bi * q_heads, kvh = head / group;
     const int64_t q_row0 = qblk[4 * bi + 0];
     const int n_q = qblk[4 * bi + 1];
     const int64_t k_row0 = (int64_t)qblk[4 * bi + 2];
@@ -173,11 +202,16 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
     if (CAUSAL) kv_len = min(kv_len, q_pos0 + n_q);
     const int n_tiles = (kv_len + 63) >> 6;
 
-    // zero the padded V^T rows once (hd=80: rows 80..95 are never staged)
-    if (C::DT * 32 > HD) {
+    // The padded V^T rows (hd=80: rows 80..95, never staged) are written once: row HD to ONES, the rest to zero.  The PV
+    // MFMAs compute those rows anyway, so O^T row HD comes out as sum_k P[k][q] — the softmax denominator, summed over
+    // the same bf16 P the numerator uses, rescaled with O, for no instruction at all: the 32 adds per tile it replaces
+    // were an eighth of the loop's vector-ALU issue slots, which — not the matrix pipe — bound this kernel.
+    constexpr bool ONES = C::DT * 32 > HD;
+    if (ONES) {
         for (int e = tid; e < (C::DT * 32 - HD) * C::VROW / 8; e += NTHR) {
-            reinterpret_cast<u32x2*>(v_s2 + HD * C::VROW)[e] = (u32x2){0u, 0u};
-            reinterpret_cast<u32x2*>(v_s2 + V_BYTES + HD * C::VROW)[e] = (u32x2){0u, 0u};
+            const unsigned v = e < 16 ? 0x3F803F80u : 0u;  // 64 keys x bf16 1.0 = the first 16 8-byte units
+            reinterpret_cast<u32x2*>(img_s + K_BYTES + HD * C::VROW)[e] = (u32x2){v, v};
+            reinterpret_cast<u32x2*>(img_s + IMG + K_BYTES + HD * C::VROW)[e] = (u32x2){v, v};
         }
     }
 
@@ -201,69 +235,90 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    bf16x8 kreg[K_PASSES], vreg[V_PASSES];
+    // Every thread takes exactly one chunk in every pass, in the loop ALWAYS (a tile index past the end re-loads the last
+    // tile, a list index past the end the last chunk: the same bytes to the same place), and a chunk goes to LDS as two
+    // 8-byte halves whether it is a K chunk (16-byte aligned) or a V^T chunk (rows of 136 B: 8-byte aligned).  No
+    // lane-predicated or tile-count-dependent branch is left around a load or its wait.  With them (r1 / early r2) the
+    // compiler had to assume a load into the same registers might still be in flight on the path that skipped the
+    // stores, put s_waitcnt vmcnt(0) in front of the LAST load of every tile — i.e. waited for the five loads issued
+    // just before it — and the stamped build (-DKR_ATTN_STAMPS) showed 1500-2400 of the ~4300 cycles per tile in
+    // "load issue".
+    bf16x8 treg[PASSES];
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int p = 0; p < K_PASSES; ++p) {
-            const int idx = p * NTHR + tid;
-            if (idx < 64 * C::KCH) {
-                const int key = idx / C::KCH, c = idx - key * C::KCH;
-                int kg = t * 64 + key;
-                kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
-                kreg[p] = ld8(kbase + (int64_t)kg * HD + c * 8);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < V_PASSES; ++p) {
-            const int idx = p * NTHR + tid;
-            if (idx < HD * 8) vreg[p] = ld8(vbase + (int64_t)t * (HD * 64) + idx * 8);
+        for (int p = 0; p < PASSES; ++p) {
+            int idx = p * NTHR + tid;
+            idx = idx < T_CH ? idx : T_CH - 1;
+            const int key = idx / C::KCH, c = idx - key * C::KCH;
+            int kg = t * 64 + key;
+            kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
+            const kr_bf16* kp = kbase + (int64_t)kg * HD + c * 8;
+            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;
+            treg[p] = ld8(idx < K_CH ? kp : vp);
         }
     };
-    auto store_tile = [&](char* k_s, char* v_s) {
+    auto store_tile = [&](char* img) {
 #pragma unroll
-        for (int p = 0; p < K_PASSES; ++p) {
-            const int idx = p * NTHR + tid;
-            if (idx < 64 * C::KCH) {
-                const int key = idx / C::KCH, c = idx - key * C::KCH;
-                *reinterpret_cast<bf16x8*>(k_s + k_lds_off<HD>(key, c)) = kreg[p];
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < V_PASSES; ++p) {
-            const int idx = p * NTHR + tid;
-            if (idx < HD * 8) {
-                const int d = idx >> 3, c = idx & 7;
-                const u32x4 w = __builtin_bit_cast(u32x4, vreg[p]);
-                u32x2* dstp = reinterpret_cast<u32x2*>(v_s + d * C::VROW + c * 16);
-                dstp[0] = (u32x2){w[0], w[1]};
-                dstp[1] = (u32x2){w[2], w[3]};
-            }
+        for (int p = 0; p < PASSES; ++p) {
+            int idx = p * NTHR + tid;
+            idx = idx < T_CH ? idx : T_CH - 1;
+            const int key = idx / C::KCH, c = idx - key * C::KCH;
+            const int j = idx - K_CH;
+            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + (j >> 3) * C::VROW + (j & 7) * 16;
+            const u32x4 w = __builtin_bit_cast(u32x4, treg[p]);
+            u32x2* dstp = reinterpret_cast<u32x2*>(img + off);
+            dstp[0] = (u32x2){w[0], w[1]};
+            dstp[1] = (u32x2){w[2], w[3]};
         }
     };
 
     if (n_tiles > 0) {
-        load_tile(0);
-        store_tile(k_s2, v_s2);
-        if (n_tiles > 1) load_tile(1);
-    }
+    load_tile(0);
+    store_tile(img_s);
+    // every load so far (Q fragments, tile 0) has landed; saying so keeps "Q may be in flight" out of the loop header
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    load_tile(n_tiles > 1 ? 1 : 0);
     __syncthreads();
+#ifdef KR_ATTN_STAMPS
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     for (int t = 0; t < n_tiles; ++t) {
-        const char* k_s = k_s2 + (t & 1) * K_BYTES;
-        const char* v_s = v_s2 + (t & 1) * V_BYTES;
+        KR_STAMP(st0);
+        const char* k_s = img_s + (t & 1) * IMG;
+        const char* v_s = k_s + K_BYTES;
 
-        // ---- S^T = K Q^T.  All K fragments of the tile are requested before the first MFMA (fetched just in time,
-        // two at a time, each pair of MFMAs waited on its own LDS round trip).  (Holding the V^T fragments across
-        // the softmax as well costs the second wave per SIMD at hd 80: measured 15 % slower.)
-        // (r2: requesting one 32-key half at a time does not lower the register peak — 186 either way, it sits in the
-        // softmax / PV phase — and forcing 3 waves per SIMD with __launch_bounds__ spills 28 registers into the loop:
-        // 1.65 ms per ViT block against 1.42 on the same box.)
+        // ---- S^T = K Q^T.  All K fragments of the tile are requested before the first MFMA.
+        // (r2: requesting one 32-key half at a time does not lower the register peak, and forcing 3 waves per SIMD
+        // with __launch_bounds__ spills into the loop: 1.65 ms per ViT block against 1.42 on the same box.)
+        // causal: a wave whose 32 queries all sit before this tile's first key has nothing to add (every score would be
+        // masked: p = 0 exactly), it only takes part in the staging — waves 0 and 1 of a block skip its last tile
+        if (!CAUSAL || t * 64 <= q_pos0 + wave * 32 + 31) {
         bf16x8 kf[2][C::KS];
+        if (HD == 128) {
+            // k_lds_off(32 sub + lq, 2 ks + lh) = 8192 sub + [256 lq + ((lh ^ (lq & 15)) << 4)] ^ (ks << 5): ONE lane
+            // constant, and the xor is taken after the image offset is added (bits 5-7 of IMG are 0), so that the
+            // compiler cannot hoist eight per-k-step addresses out of the loop and hold them in registers it lacks
+            static_assert(HD != 128 || (IMG & 0xe0) == 0, "image offset must leave the swizzle bits alone");
+            const int base = (t & 1) * IMG + lq * 256 + ((lh ^ (lq & 15)) << 4);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const char* kp = img_s + (base ^ (ks << 5));
+                kf[0][ks] = *reinterpret_cast<const bf16x8*>(kp);
+                kf[1][ks] = *reinterpret_cast<const bf16x8*>(kp + 32 * 256);
+            }
+        } else {
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
-                kf[sub][ks] = *reinterpret_cast<const bf16x8*>(k_s + k_lds_off<HD>(sub * 32 + lq, 2 * ks + lh));
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks)
+                    kf[sub][ks] = *reinterpret_cast<const bf16x8*>(k_s + k_lds_off<HD>(sub * 32 + lq, 2 * ks + lh));
+        }
         __builtin_amdgcn_sched_barrier(0);
+        KR_STAMP(st1);
+#ifdef KR_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         f32x16 s[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -273,6 +328,25 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
             for (int ks = 0; ks < C::KS; ++ks)
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[ks], s[sub], 0, 0, 0);
         }
+#ifdef KR_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        // V^T fragments of the first VPRE 32-row tiles of O^T are requested here, behind the QK^T MFMAs: their LDS
+        // round trips run under the softmax instead of in front of each PV MFMA (the register file has the room since
+        // the accumulators stopped being copied: 186 -> ~230 of the 256 two waves per SIMD allow)
+        bf16x8 vf[C::DT][4];
+        auto load_v = [&](int dt) {
+            const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int kb = f * 16 + 4 * lh;  // keys kb..kb+3 and kb+8..kb+11
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
+                vf[dt][f] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+            }
+        };
+#pragma unroll
+        for (int dt = 0; dt < VPRE; ++dt) load_v(dt);
         // ---- mask, online softmax (lane = query; rows = keys).  The softmax is the VALU-bound part of this
         // kernel (PMC: vector ALU ~70 % busy, MFMA 22 %), so: masks only on tiles that need one (wave-uniform
         // test), the scale folded into one fma per score, P converted to bf16 pairwise, and a LAZY running max:
@@ -296,7 +370,20 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
+#ifdef KR_ATTN_SHFL
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#else
+        {   // the other half-wave's maximum: one v_permlane32_swap (vector ALU) instead of an LDS round trip
+            const unsigned mb = __builtin_bit_cast(unsigned, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+        }
+#endif
+        mx *= scale_log2e;  // scale > 0: max commutes with it
+#ifdef KR_ATTN_STAMPS
+        asm volatile("" : "+v"(mx));
+#endif
+        KR_STAMP(st2);
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new - m_run > 8.0f)) {  // first tile (m_run = -1e30), then rarely
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -317,7 +404,7 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     pv[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][h8 * 8 + j], scale_log2e, -m_run));
-                    psum += pv[j];
+                    if (!ONES) psum += pv[j];
                 }
                 pf[sub][h8] = __builtin_convertvector(pv, bf16x8);
             }
@@ -325,27 +412,48 @@ __global__ void __launch_bounds__(NW * 64) attn_varlen_kernel(const kr_bf16* __r
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-            const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
+            if (dt + VPRE < C::DT) load_v(dt + VPRE);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    const int kb = sub * 32 + ss * 16 + 4 * lh;  // keys kb..kb+3 and kb+8..kb+11
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
-                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][ss], o[dt], 0, 0, 0);
-                }
+                for (int ss = 0; ss < 2; ++ss)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][sub * 2 + ss], pf[sub][ss], o[dt], 0, 0, 0);
         }
+        }
+#ifdef KR_ATTN_STAMPS
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) asm volatile("" : "+v"(o[dt]));
+#endif
+        KR_STAMP(st3);
         // tile t+1 (in registers since the previous barrier) -> the other image; it was last read during tile
         // t-1, which every wave left at the previous barrier
-        if (t + 1 < n_tiles) store_tile(k_s2 + ((t + 1) & 1) * K_BYTES, v_s2 + ((t + 1) & 1) * V_BYTES);
+        store_tile(img_s + ((t + 1) & 1) * IMG);
+        KR_STAMP(st4);
         __syncthreads();
-        if (t + 2 < n_tiles) load_tile(t + 2);
+        KR_STAMP(st5);
+        load_tile(t + 2 < n_tiles ? t + 2 : n_tiles - 1);
+        KR_STAMP(st6);
+#ifdef KR_ATTN_STAMPS
+        acc[0] += st1 - st0; acc[1] += st2 - st1; acc[2] += st3 - st2; acc[3] += st4 - st3; acc[4] += st5 - st4; acc[5] += st6 - st5;
+#endif
     }
+#ifdef KR_ATTN_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) kr_attn_dbg[wave * 8 + i] = acc[i];
+        kr_attn_dbg[wave * 8 + 6] = (unsigned long long)n_tiles;
+    }
+#endif
+    }  // n_tiles > 0
 
     // ---- normalise and store: lane = query, 4 consecutive d per register quad
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (ONES) {  // O^T row HD: tile HD/32, row HD%32 = 16 -> register 8 of the lanes lh = 0
+        static_assert(!ONES || HD % 32 == 16, "ones row register");
+        l_tot = __shfl(o[HD / 32][8], lq, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (!q_valid) return;
     kr_bf16* op = out + (q_row0 + ql) * ((int64_t)q_heads * HD) + (int64_t)head * HD;
@@ -613,7 +721,8 @@ static int attn_varlen_impl(const kr_bf16* q, const kr_bf16* k, const kr_bf16* v
     KR_CHECK_ARG(q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "kr_attn_varlen: heads");
     KR_CHECK_ARG(q_block == 128 || q_block == 256, "kr_attn_varlen: q_block=%d (128 or 256)", q_block);
     if (n_qblk == 0) return KR_OK;
-    dim3 grid(n_qblk, q_heads);
+    KR_CHECK_ARG((int64_t)n_qblk * q_heads < (1ll << 31), "kr_attn_varlen: %d query blocks x %d heads", n_qblk, q_heads);
+    dim3 grid((unsigned)(n_qblk * q_heads));
     const float sl = scale * 1.4426950408889634f;
     const int group = q_heads / kv_heads;
 #define KR_LAUNCH_ATTN(HD_, C_, NW_)                                                                                       \

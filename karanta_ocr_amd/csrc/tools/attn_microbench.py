@@ -43,7 +43,28 @@ def run(lens, H, KVH, hd, causal, q_block, reps=10):
         ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
         best = min(best, ms.value / reps)
     flops = sum(4.0 * x * x * hd * H * (0.5 if causal else 1.0) for x in lens)
+    stamps(q_block)
     return best, flops / best / 1e9, o
+
+
+SEGMENTS = ("K reads", "QK^T + max", "exp + PV", "tile -> LDS", "barrier", "load issue")
+
+
+def stamps(q_block):
+    """Diagnostic builds only (tools/build_variant.py ... -DKR_ATTN_STAMPS, KARANTA_HIP_LIB=...): cycles per tile and per
+    segment of the middle workgroup's waves.  SHARES are what to read, not totals: the stamps fence overlaps."""
+    try:
+        fn = C.CDLL(os.environ["KARANTA_HIP_LIB"]).kr_attn_debug_read
+    except (KeyError, AttributeError, OSError):
+        return
+    buf = (C.c_ulonglong * 64)()
+    if fn(buf) != 0:
+        return
+    for w in range(q_block // 32):
+        nt = max(1, buf[w * 8 + 6])
+        seg = [buf[w * 8 + i] / nt for i in range(6)]
+        print(f"      wave {w}: {nt} tiles, s_memtime ticks / tile  " + "  ".join(f"{n} {v:.0f}" for n, v in zip(SEGMENTS, seg))
+              + f"  sum {sum(seg):.0f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -123,20 +123,21 @@ class AttnPlan:
     q_block: int = 128     # queries per work-list entry: 128 (4-wave workgroups) or 256 (8-wave, kr_attn_varlen_q)
 
 
-def pick_q_block(lens: Sequence[int]) -> int:
-    """Queries per attention workgroup: 128 (4 waves) or 256 (8 waves sharing one staged K / V^T tile).  r2 microbench
-    (outputs bit-identical either way; build with MFMA results in VGPRs): ViT 8 x 4900 tokens 1.339 ms (128) vs 1.377 (256)
-    per block; causal prefill 8 x 1394 tokens 0.107 vs 0.118 ms per layer; ONE 19 276-token page (config 5) 2.511 vs
-    2.344 ms.  The 8-wave shape pays where a segment has hundreds of K / V tiles to stage; short segments (Qwen2.5-VL's
-    64-token windows) would leave most of its waves without queries."""
+def pick_q_block(lens: Sequence[int], causal: bool = False) -> int:
+    """Queries per attention workgroup: 128 (4 waves) or 256 (8 waves sharing one staged K / V^T tile).  r2 microbench on
+    the final kernel (outputs bit-identical either way): ViT 8 x 4900 tokens 1.154 ms (128) vs 1.127 (256) per block; ONE
+    19 276-token page (config 5) 2.166 vs 2.071 ms; causal prefill 8 x 1394 tokens 0.082 vs 0.096 ms per layer — its
+    query blocks see 1 .. 22 key tiles, and half as many, twice as long workgroups schedule worse.  The 8-wave shape
+    pays where a full-attention segment has dozens of K / V tiles to stage; short segments (Qwen2.5-VL's 64-token
+    windows) would leave most of its waves without queries."""
     lens = [int(n) for n in lens if int(n) > 0]
-    return 256 if lens and sum(lens) / len(lens) >= 8192 else 128
+    return 256 if (not causal) and lens and sum(lens) / len(lens) >= 2048 else 128
 
 
 def make_attn_plan(lens: Sequence[int], k_row0: Sequence[int], vt_blk0: Sequence[int], causal: bool,
                    q_block: Optional[int] = None) -> AttnPlan:
     if q_block is None:
-        q_block = pick_q_block(lens)
+        q_block = pick_q_block(lens, causal)
     if q_block not in (128, 256):
         raise ValueError(f"q_block {q_block} (128 or 256)")
     blk_tok0, blk_ntok, blk_kr, blk_vb, qblk, qlen = [], [], [], [], [], []
@@ -155,6 +156,12 @@ def make_attn_plan(lens: Sequence[int], k_row0: Sequence[int], vt_blk0: Sequence
             qlen.append((n, j))
         tok += n
         nvb += (n + 63) // 64
+    # heaviest query blocks first: the kernel walks this table in order (head fastest), so a causal launch — whose
+    # blocks see 1 .. n/64 key tiles — is scheduled longest-job-first and its tail is one light block, not a heavy one
+    work = [min(n, j + nq) if causal else n for (_, nq, _, _), (n, j) in zip(qblk, qlen)]
+    order = sorted(range(len(qblk)), key=lambda i: -((work[i] + 63) // 64))   # stable: ties keep token order
+    qblk = [qblk[i] for i in order]
+    qlen = [qlen[i] for i in order]
     return AttnPlan(
         np.asarray(blk_tok0, np.int32), np.asarray(blk_ntok, np.int32), np.asarray(blk_kr, np.int64),
         np.asarray(blk_vb, np.int64), np.asarray(qblk, np.int32).reshape(-1, 4),

@@ -98,20 +98,26 @@ def test_attn_plan_vit():
     np.testing.assert_array_equal(plan.blk_ntok, [24, 64, 64, 64, 4, 4])
     np.testing.assert_array_equal(plan.blk_vt_blk, [0, 1, 2, 3, 4, 5])
     np.testing.assert_array_equal(plan.blk_k_row0, [0, 24, 88, 152, 216, 220])
-    # q blocks of <=128 rows: (24), (128, 68), (4)
-    np.testing.assert_array_equal(plan.qblk[:, 0], [0, 24, 152, 220])
-    np.testing.assert_array_equal(plan.qblk[:, 1], [24, 128, 68, 4])
-    np.testing.assert_array_equal(plan.qblk[:, 2], [0, 24, 24, 220])
-    np.testing.assert_array_equal(plan.qblk[:, 3], [0, 1, 1, 5])
-    np.testing.assert_array_equal(plan.qblk_len, [[24, 0], [196, 0], [196, 128], [4, 0]])
+    # q blocks of <=128 rows: (24), (128, 68), (4) — listed heaviest first (key tiles 4, 4, 1, 1), ties in token order
+    np.testing.assert_array_equal(plan.qblk[:, 0], [24, 152, 0, 220])
+    np.testing.assert_array_equal(plan.qblk[:, 1], [128, 68, 24, 4])
+    np.testing.assert_array_equal(plan.qblk[:, 2], [24, 24, 0, 220])
+    np.testing.assert_array_equal(plan.qblk[:, 3], [1, 1, 0, 5])
+    np.testing.assert_array_equal(plan.qblk_len, [[196, 0], [196, 128], [24, 0], [4, 0]])
 
 
 def test_attn_plan_prefill():
     plan = POS.prefill_attn_plan([130, 5], [0, 1], kv_heads=2, s_max=256)
     np.testing.assert_array_equal(plan.blk_k_row0, [0, 64, 128, 512])
     np.testing.assert_array_equal(plan.blk_vt_blk, [0, 1, 2, 8])
+    # causal: the block at query 128 sees 3 key tiles, the one at 0 sees 2, the short sequence 1 — heaviest first
     np.testing.assert_array_equal(plan.qblk[:, 2], [0, 0, 512])
-    np.testing.assert_array_equal(plan.qblk_len, [[130, 0], [130, 128], [5, 0]])
+    np.testing.assert_array_equal(plan.qblk_len, [[130, 128], [130, 0], [5, 0]])
+    big = POS.prefill_attn_plan([1394] * 3, [0, 1, 2], kv_heads=2, s_max=1408)
+    tiles = (np.minimum(big.qblk_len[:, 0], big.qblk_len[:, 1] + big.qblk[:, 1]) + 63) // 64
+    assert (np.diff(tiles) <= 0).all() and tiles[0] == 22 and tiles[-1] == 2
+    assert sorted(map(tuple, big.qblk[:, :2].tolist())) == sorted((s * 1394 + j, min(128, 1394 - j)) for s in range(3)
+                                                                  for j in range(0, 1394, 128))
 
 
 def test_bf16_helpers():
@@ -321,9 +327,11 @@ def test_load_checkpoint_bf16_and_fp8_compressed_tensors(tmp_path):
 
 def test_attn_plan_picks_the_workgroup_shape():
     P = POS
-    assert P.vit_attn_plan([(1, 70, 70)]).q_block == 128 and P.segments_attn_plan([64] * 40).q_block == 128
+    assert P.vit_attn_plan([(1, 70, 70)]).q_block == 256 and P.segments_attn_plan([64] * 40).q_block == 128
+    assert P.vit_attn_plan([(1, 28, 28)]).q_block == 128              # 784 patches: a few K / V tiles only
     assert P.vit_attn_plan([(1, 158, 122)]).q_block == 256            # config 5's 19 276-patch page
     assert P.prefill_attn_plan([1394, 77], [0, 1], 2, 1408).q_block == 128
+    assert P.prefill_attn_plan([8000], [0], 2, 8192).q_block == 128   # causal: always the 4-wave shape
     p128, p256 = P.make_attn_plan([300], [0], [0], False, q_block=128), P.make_attn_plan([300], [0], [0], False, q_block=256)
     assert p128.qblk[:, 1].tolist() == [128, 128, 44] and p256.qblk[:, 1].tolist() == [256, 44]
     with pytest.raises(ValueError):
