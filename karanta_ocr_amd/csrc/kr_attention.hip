@@ -54,12 +54,16 @@ __global__ void __launch_bounds__(256) rope_inplace_kernel(kr_bf16* __restrict__
 // =====================================================================================
 // prep: rotary + re-layout (+ V transpose through LDS) for 64-token blocks
 // =====================================================================================
-// grid = (n_blocks, q_heads + kv_heads).  Block i covers tokens blk_tok0[i] .. +blk_ntok[i] (<= 64)
+// grid = (n_blocks, ceil((q_heads + kv_heads) / PREP_G)).  Block i covers tokens blk_tok0[i] .. +blk_ntok[i] (<= 64)
 // of the flattened activation `qkv` (row stride ld_qkv); they belong to one segment/sequence and
-// start at a multiple of 64 inside it, so the block owns one whole V^T block.
+// start at a multiple of 64 inside it, so the block owns one whole V^T block.  Head slot y of the PREP_G the block takes:
 //   y <  q_heads : rotate q head y            -> q_out[y][tok][hd]
 //   y >= q_heads : rotate k head, copy V^T    -> k rows (k_row0[i] + j), V^T block vt_blk[i]
 // Column offsets of q / k / v inside a qkv row are given in elements.
+// A thread keeps the cos / sin of its (token, 8-channel chunk) in registers across the block's head slots: with one
+// head per block (r1) the fp32 tables were 4x the bytes of the activations they rotate and the ViT launch ran at
+// 2.5 TB/s of useful traffic (240 us per layer for 8 pages).
+constexpr int PREP_G = 8;
 template <int HD>
 __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict__ qkv, int64_t ld_qkv, int q_off,
                                                        int k_off, int v_off, const float* __restrict__ cos,
@@ -70,25 +74,19 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
                                                        const int64_t* __restrict__ blk_vt_blk, kr_bf16* __restrict__ q_out,
                                                        int64_t q_head_stride, kr_bf16* __restrict__ k_out,
                                                        int64_t k_head_stride, kr_bf16* __restrict__ vt_out,
-                                                       int64_t vt_head_stride, int q_heads) {
+                                                       int64_t vt_head_stride, int q_heads, int n_slots) {
     constexpr int HC = HD / 16;  // 8-element chunks in half a head
     __shared__ __attribute__((aligned(16))) kr_bf16 vt_s[HD][64 + 8];
     const int i = blockIdx.x;
-    const int y = blockIdx.y;
+    const int y0 = blockIdx.y * PREP_G, y1 = min(y0 + PREP_G, n_slots);
     const int tok0 = blk_tok0[i], ntok = blk_ntok[i];
-    const bool is_q = y < q_heads;
-    const int head = is_q ? y : y - q_heads;
-    const int col = (is_q ? q_off : k_off) + head * HD;
-    kr_bf16* dst = is_q ? q_out + (int64_t)head * q_head_stride + (int64_t)tok0 * HD
-                        : k_out + (int64_t)head * k_head_stride + blk_k_row0[i] * HD;
-    // ---- rotary on 64 tokens x HD
+    const int64_t k_row0 = blk_k_row0[i];
+    // ---- rotary on 64 tokens x HD, all head slots of the block
     for (int e = threadIdx.x; e < 64 * HC; e += 256) {
         const int j = e / HC, c = e - j * HC;
         if (j >= ntok) continue;
         const int64_t tok = tok0 + j;
-        const kr_bf16* p = qkv + tok * ld_qkv + col;
         const int d0 = c * 8, d1 = d0 + HD / 2;
-        const bf16x8 a = ld8(p + d0), b = ld8(p + d1);
         float c0[8], s0[8], c1[8], s1[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -97,23 +95,36 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
             c1[jj] = cos[tok * HD + d1 + jj];
             s1[jj] = sin[tok * HD + d1 + jj];
         }
-        st8(dst + (int64_t)j * HD + d0, rope8(a, b, c0, s0, -1.f));
-        st8(dst + (int64_t)j * HD + d1, rope8(b, a, c1, s1, 1.f));
+        const kr_bf16* row = qkv + tok * ld_qkv;
+#pragma unroll 2
+        for (int y = y0; y < y1; ++y) {
+            const bool is_q = y < q_heads;
+            const int head = is_q ? y : y - q_heads;
+            const kr_bf16* p = row + (is_q ? q_off : k_off) + head * HD;
+            kr_bf16* dst = is_q ? q_out + (int64_t)head * q_head_stride + tok * HD
+                                : k_out + (int64_t)head * k_head_stride + (k_row0 + j) * HD;
+            const bf16x8 a = ld8(p + d0), b = ld8(p + d1);
+            st8(dst + d0, rope8(a, b, c0, s0, -1.f));
+            st8(dst + d1, rope8(b, a, c1, s1, 1.f));
+        }
     }
-    if (is_q) return;
-    // ---- V: [64 tok][HD] -> LDS transposed -> V^T block [HD][64], zero padded past ntok
-    for (int e = threadIdx.x; e < 64 * (HD / 8); e += 256) {
-        const int j = e / (HD / 8), c = e - j * (HD / 8);
-        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-        if (j < ntok) v = *reinterpret_cast<const u32x4*>(qkv + (int64_t)(tok0 + j) * ld_qkv + v_off + head * HD + c * 8);
+    // ---- V of the block's k-head slots: [64 tok][HD] -> LDS transposed -> V^T block [HD][64], zero padded past ntok
+    for (int y = max(y0, q_heads); y < y1; ++y) {
+        const int head = y - q_heads;
+        for (int e = threadIdx.x; e < 64 * (HD / 8); e += 256) {
+            const int j = e / (HD / 8), c = e - j * (HD / 8);
+            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+            if (j < ntok) v = *reinterpret_cast<const u32x4*>(qkv + (int64_t)(tok0 + j) * ld_qkv + v_off + head * HD + c * 8);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) vt_s[c * 8 + jj][j] = (kr_bf16)((v[jj >> 1] >> ((jj & 1) * 16)) & 0xffffu);
-    }
-    __syncthreads();
-    kr_bf16* vt = vt_out + (int64_t)head * vt_head_stride + blk_vt_blk[i] * (int64_t)(HD * 64);
-    for (int e = threadIdx.x; e < HD * 8; e += 256) {
-        const int d = e >> 3, c = e & 7;
-        *reinterpret_cast<u32x4*>(vt + d * 64 + c * 8) = *reinterpret_cast<const u32x4*>(&vt_s[d][c * 8]);
+            for (int jj = 0; jj < 8; ++jj) vt_s[c * 8 + jj][j] = (kr_bf16)((v[jj >> 1] >> ((jj & 1) * 16)) & 0xffffu);
+        }
+        __syncthreads();
+        kr_bf16* vt = vt_out + (int64_t)head * vt_head_stride + blk_vt_blk[i] * (int64_t)(HD * 64);
+        for (int e = threadIdx.x; e < HD * 8; e += 256) {
+            const int d = e >> 3, c = e & 7;
+            *reinterpret_cast<u32x4*>(vt + d * 64 + c * 8) = *reinterpret_cast<const u32x4*>(&vt_s[d][c * 8]);
+        }
+        __syncthreads();
     }
 }
 
@@ -700,15 +711,16 @@ extern "C" int kr_qkv_prep(const kr_bf16* qkv, int64_t ld_qkv, int q_off, int k_
     KR_CHECK_ARG(hd == 80 || hd == 128, "kr_qkv_prep: hd=%d (only 80, 128)", hd);
     KR_CHECK_ARG((ld_qkv & 7) == 0 && (q_off & 7) == 0 && (k_off & 7) == 0 && (v_off & 7) == 0, "kr_qkv_prep: alignment");
     if (n_blk == 0) return KR_OK;
-    dim3 grid(n_blk, q_heads + kv_heads);
+    const int n_slots = q_heads + kv_heads;
+    dim3 grid(n_blk, (n_slots + PREP_G - 1) / PREP_G);
     if (hd == 80)
         qkv_prep_kernel<80><<<grid, 256, 0, kr_hs(s)>>>(qkv, ld_qkv, q_off, k_off, v_off, cos, sin, blk_tok0, blk_ntok,
                                                         blk_k_row0, blk_vt_blk, q_out, q_head_stride, k_out,
-                                                        k_head_stride, vt_out, vt_head_stride, q_heads);
+                                                        k_head_stride, vt_out, vt_head_stride, q_heads, n_slots);
     else
         qkv_prep_kernel<128><<<grid, 256, 0, kr_hs(s)>>>(qkv, ld_qkv, q_off, k_off, v_off, cos, sin, blk_tok0, blk_ntok,
                                                          blk_k_row0, blk_vt_blk, q_out, q_head_stride, k_out,
-                                                         k_head_stride, vt_out, vt_head_stride, q_heads);
+                                                         k_head_stride, vt_out, vt_head_stride, q_heads, n_slots);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

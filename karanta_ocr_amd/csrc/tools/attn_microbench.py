@@ -67,7 +67,44 @@ def stamps(q_block):
               + f"  sum {sum(seg):.0f}", flush=True)
 
 
+def run_prep(lens, H, KVH, hd, reps=10):
+    """kr_qkv_prep (rotary + re-layout + V transpose) on the same segments: useful bytes = qkv rows read + q/k/V^T written."""
+    n = sum(lens)
+    k_row0 = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    nb = [(x + 63) // 64 for x in lens]
+    vt0 = np.concatenate([[0], np.cumsum(nb)[:-1]])
+    plan = POS.make_attn_plan(lens, k_row0, vt0, False)
+    ld = (H + 2 * KVH) * hd
+    qkv = torch.randn(n, ld, device=dev).bfloat16()
+    cos = torch.rand(n, hd, device=dev); sin = torch.rand(n, hd, device=dev)
+    q = torch.empty(H, n, hd, device=dev).bfloat16(); k = torch.empty(KVH, n, hd, device=dev).bfloat16()
+    vt = torch.empty(KVH, plan.n_vt_blocks, hd, 64, device=dev).bfloat16()
+    t_ = lambda a: torch.from_numpy(a).to(dev)
+    b0, bn, bk, bv = t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0), t_(plan.blk_vt_blk)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
+
+    def launch():
+        L.kr_qkv_prep(ptr(qkv), ld, 0, H * hd, (H + KVH) * hd, ptr(cos), ptr(sin), ptr(b0), ptr(bn), ptr(bk), ptr(bv),
+                      plan.blk_tok0.shape[0], ptr(q), n * hd, ptr(k), n * hd, ptr(vt), plan.n_vt_blocks * hd * 64, H, KVH, hd, S)
+    launch(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        L.kr_event_record(e0, S)
+        for _ in range(reps):
+            launch()
+        L.kr_event_record(e1, S)
+        L.kr_event_synchronize(e1)
+        ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+        best = min(best, ms.value / reps)
+    return best, 2.0 * n * ld * 2 / best / 1e6
+
+
 if __name__ == "__main__":
+    for name, (lens, H, KVH, hd) in {"qkv_prep vit 8 x 4900, 16 heads x 80": ([4900] * 8, 16, 16, 80),
+                                     "qkv_prep prefill 8 x 1394, 12/2 heads x 128": ([1394] * 8, 12, 2, 128)}.items():
+        ms, gbs = run_prep(lens, H, KVH, hd)
+        print(f"{name:45s}            : {ms:8.3f} ms  {gbs:7.0f} GB/s (activations in + out)", flush=True)
     for name, (lens, H, KVH, hd, causal) in {"vit 8 x 4900, 16 heads x 80": ([4900] * 8, 16, 16, 80, False),
                                               "prefill 8 x 1394, 12/2 heads x 128 causal": ([1394] * 8, 12, 2, 128, True),
                                               "vit 1 x 19276": ([19276], 16, 16, 80, False)}.items():
