@@ -203,7 +203,8 @@ template <int EPI, bool WPACK, typename G>
 __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
                                                    const kr_bf16* __restrict__ W, const kr_bf16* __restrict__ bias,
                                                    const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C,
-                                                   int64_t ldc, int64_t M, int N, int K, int tiles_n, unsigned nwg) {
+                                                   int64_t ldc, int64_t M, int N, int K, int tiles_n, unsigned nwg,
+                                                   int ptiles_n, unsigned qbase) {
     constexpr int BM = G::BM, BN = G::BN, NTHR = G::WM * G::WN * 64;
     constexpr int WTM = BM / G::WM, WTN = BN / G::WN;  // wave tile
     constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -215,8 +216,16 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
     const int wr = wave / G::WN, wc = wave % G::WN;
 
     const unsigned wg = xcd_remap(blockIdx.x, nwg);
-    const int64_t m0 = (int64_t)(wg / tiles_n) * BM;
-    const int n0 = (int)(wg % tiles_n) * BN;
+    int64_t m0 = (int64_t)(wg / tiles_n) * BM;
+    int n0 = (int)(wg % tiles_n) * BN;
+    if (ptiles_n > 0) {
+        // TAIL of a 256x256-tile launch (launch_gemm_pipe): this grid is the quarters (128x128) of the 256x256 tiles
+        // qbase, qbase + 1, ... of that launch's m-major tile list — the tiles of its last, mostly empty round
+        const unsigned parent = qbase + (wg >> 2), sub = wg & 3u;
+        m0 = (int64_t)(parent / (unsigned)ptiles_n) * 256 + (sub >> 1) * 128;
+        n0 = (int)(parent % (unsigned)ptiles_n) * 256 + (int)(sub & 1u) * 128;
+        if (m0 >= M) return;  // the parent straddled the end of M (whole workgroup: before any barrier)
+    }
 
     f32x4 acc[NT][MT];  // [nt][mt]: rows (regs) = n, col (lane&15) = m
 #pragma unroll
@@ -450,14 +459,38 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, fr, fg, smem + wave * (128 * 128));
 }
 
+template <int EPI, bool WPACK>
+int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, kr_stream s);
+inline int kr_cu_count();
+
+// One 512-thread workgroup per CU at a time: a launch of T tiles takes ceil(T / CUs) ROUNDS, and the page-sized GEMMs
+// sit badly on that grid — ViT proj / fc2 at 8 pages are 770 tiles = 3 rounds + 2 tiles (a fourth round for 0.3 % of
+// the work), prefill o_proj / down_proj 264 tiles = 1 round + 8.  When the last round would be at most half full its
+// tiles are cut into 128x128 quarters and run as a second launch of the two-barrier kernel (same k order: the same
+// bits), which fills the chip with 4x as many, co-resident, short workgroups.  KARANTA_GEMM_TAIL=0 disables it.
 template <int EPI, bool WPACK, bool W8 = false>
 int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
                      kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s, const float* w_scale = nullptr) {
     constexpr int LDS = PSTAGES * PBUF;
     const int64_t tiles_m = (M + 255) / 256;
     const int tiles_n = (N + 255) / 256;
-    const int64_t nwg = tiles_m * tiles_n;
+    int64_t nwg = tiles_m * tiles_n;
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
+    unsigned tail = 0;
+    if constexpr (!W8) {
+        const int cus = kr_cu_count();
+        const char* env = getenv("KARANTA_GEMM_TAIL");
+        const int64_t t = nwg % cus;
+        // measured (tools/gemm_microbench.py, r2): a lone last round is cheaper than a full one (its few tiles have the
+        // chip's clocks and memory system to themselves), so the split pays where a tile is long — K >= 1536: prefill
+        // down_proj 414 -> 353 us, o_proj 81 -> 74, ViT fc2 460 -> 442, merger fc1 469 -> 435 — or the tail tiny (ViT proj,
+        // 2 tiles: 135 -> 127); at K = 1280 with 6-8 tail tiles it is neutral to slightly worse (fc1 521 -> 533)
+        if (nwg > cus && t > 0 && 2 * t <= cus && (K >= 1536 || t <= 4) && !(env && atoi(env) == 0)) {
+            tail = (unsigned)t;
+            nwg -= t;
+        }
+    }
     static KrPerDeviceOnce attr_set;
     if (attr_set.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8>),
@@ -466,6 +499,9 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     gemm_pipe_kernel<EPI, WPACK, W8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
                                                                             (unsigned)nwg, w_scale);
     KR_CHECK_LAUNCH();
+    if constexpr (!W8) {
+        if (tail) return launch_gemm_tail<EPI, WPACK>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg, tail, s);
+    }
     return KR_OK;
 }
 
@@ -483,9 +519,39 @@ int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     gemm_kernel<EPI, WPACK, G><<<(unsigned)nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
-                                                                                      tiles_n, (unsigned)nwg);
+                                                                                      tiles_n, (unsigned)nwg, 0, 0u);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+// The quarters of the 256x256 tiles [tile0, tile0 + n_tiles) of a launch_gemm_pipe tile list, as 128x128 workgroups.
+template <int EPI, bool WPACK>
+int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, kr_stream s) {
+    using G = G128;
+    constexpr int LDS = 2 * (G::BM + G::BN) * BK * 2;
+    static KrPerDeviceOnce attr_set;
+    if (attr_set.need()) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK, G>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
+    const unsigned nwg = 4 * n_tiles;
+    gemm_kernel<EPI, WPACK, G><<<nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, nwg,
+                                                                          ptiles_n, tile0);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+// Compute units of the current device (cached per device): the round size of a one-workgroup-per-CU launch.
+inline int kr_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
 }
 
 // 0 = automatic; 128 / 256 / 512 (= pipelined 256x256) forced by KARANTA_GEMM_TILE (tests, tuning sweeps)

@@ -25,8 +25,9 @@ def run(name, M, N, K, epi, packed, reps=5):
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
     out = {}
-    for tile in (128, 256, 512):
-        os.environ["KARANTA_GEMM_TILE"] = str(tile)
+    for tile in (128, 256, 512, 513):   # 513: pipelined 256 with the last round cut into 128x128 quarters (the default)
+        os.environ["KARANTA_GEMM_TILE"] = str(min(tile, 512))
+        os.environ["KARANTA_GEMM_TAIL"] = "1" if tile == 513 else "0"
         call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
         call(); torch.cuda.synchronize()
         best = 1e9
@@ -36,7 +37,8 @@ def run(name, M, N, K, epi, packed, reps=5):
         out[tile] = best
     fl = 2.0 * M * N * K
     print(f"{name:16s} M={M:6d} N={N:6d} K={K:5d}: 128-tile {out[128]*1e3:8.1f} us {fl/out[128]/1e9:7.0f} TF/s | "
-          f"256-tile {out[256]*1e3:8.1f} us {fl/out[256]/1e9:7.0f} TF/s | pipelined 256 {out[512]*1e3:8.1f} us {fl/out[512]/1e9:7.0f} TF/s", flush=True)
+          f"256-tile {out[256]*1e3:8.1f} us {fl/out[256]/1e9:7.0f} TF/s | pipelined 256 {out[512]*1e3:8.1f} us {fl/out[512]/1e9:7.0f} TF/s | "
+          f"+ tail split {out[513]*1e3:8.1f} us {fl/out[513]/1e9:7.0f} TF/s  ({-(-M // 256) * (N // 256)} tiles)", flush=True)
 
 
 if __name__ == "__main__":

@@ -251,6 +251,40 @@ def test_gemm_256_tile_silu_mul8(L, tile256, packed):
                       what="256-tile silu8")
 
 
+@pytest.mark.parametrize("M,N,K,epi,packed", [(10800, 1536, 64, EPI_NONE, False),        # 258 tiles: 2 in the tail, partial M tile
+                                               (11152, 1536, 1536, EPI_GELU_ERF, True),     # prefill o_proj shape: 264 tiles, tail 8
+                                               (11152, 1536, 1536, EPI_SILU_MUL8, True),    # the interleaved gate/up epilogue
+                                               (9800, 5120, 1536, EPI_QUICK_GELU, False)])  # 780 tiles = 3 rounds + 12
+def test_gemm_tail_round_as_quarter_tiles(L, M, N, K, epi, packed):
+    """A pipelined-256 launch whose last round of workgroups would be at most half full runs those tiles as 128x128
+    quarters in a second launch (launch_gemm_pipe): exact on integers, and the one-launch form's values."""
+    import os
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = -(-M // 256) * (N // 256)
+    assert tiles > cus and 0 < tiles % cus <= cus // 2, "shape no longer exercises the tail on this device"
+    rng = np.random.default_rng(M + N + K)
+    os.environ["KARANTA_GEMM_TILE"] = "512"
+    try:
+        if epi == EPI_NONE:
+            A, W = ints(rng, M, K), ints(rng, N, K)
+            np.testing.assert_array_equal(run_gemm(L, A, W), ref_linear(A, W))
+        A, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+        bias = None if epi == EPI_SILU_MUL8 else rnd(rng, N, scale=0.1)
+        res = None if epi == EPI_SILU_MUL8 else rnd(rng, M, N)
+        got = run_gemm(L, A, W, bias, res, epi, packed=packed)
+        os.environ["KARANTA_GEMM_TAIL"] = "0"
+        one = run_gemm(L, A, W, bias, res, epi, packed=packed)
+        # the same k order and the same epilogue arithmetic; the two instantiations are compiled separately, so an
+        # element sitting on a bf16 rounding boundary may land on either side: (almost) all bits equal, none far off
+        assert (got != one).mean() < 1e-5, f"{(got != one).sum()} elements differ between the one- and two-launch forms"
+        assert_close_bf16(got, one, what="tail split vs one launch")
+        rows = np.r_[0:300, M - 600:M]          # the head and the tail tiles' rows against the host reference
+        assert_close_bf16(got[rows], ref_linear(A[rows], W, bias, None if res is None else res[rows], epi), what="tail split")
+    finally:
+        os.environ.pop("KARANTA_GEMM_TILE", None)
+        os.environ.pop("KARANTA_GEMM_TAIL", None)
+
+
 def test_gemm_asymmetric_operands_catch_transposes(L):
     M, N, K = 128, 128, 64
     A = np.zeros((M, K), np.float32); A[np.arange(64), np.arange(64)] = 1  # rows 0..63 = identity on K
