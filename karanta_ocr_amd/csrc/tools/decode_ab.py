@@ -65,7 +65,7 @@ def main():
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         eng = Engine(cfg, max_batch=B, s_max=s_max, max_patches=64, max_prompt_tokens=64,
-                     decode_splits=int(over.pop("n_split", 8)), weight_dtype=a.weights)
+                     decode_splits=int(over.pop("n_split", 16)), weight_dtype=a.weights)
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
