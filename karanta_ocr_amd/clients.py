@@ -129,7 +129,7 @@ class VLLMClient:
             status, extra = self._endpoint.request("/health", timeout=5)
             if status == 200:
                 info.update(extra)
-        except Exception:
+        except (OSError, ValueError, RuntimeError):
             pass
         self._info = info
         return info
@@ -138,7 +138,7 @@ class VLLMClient:
     def generate(self, messages: List[Dict[str, str]], model: Optional[str] = None, max_tokens: int = 100,
                  temperature: float = 0.7, response_format: Optional[Dict[str, Any]] = None, **kwargs) -> Dict[str, Any]:
         if self.health_check() is False:
-            raise VLLMClientError(f"VLLM server at {self.base_url} is not healthy")
+            raise VLLMClientError(f"{self.base_url}: the VLLM server is not healthy (GET {self.health_url} did not answer 200)")
         if not model:
             served = self.get_server_info().get("models")
             if not served:
@@ -202,7 +202,7 @@ class VLLMClientManager:
 
     def __init__(self, server_config: Dict[int, str] = None):
         self.server_config: Dict[int, str] = dict(server_config or {})
-        self.clients: Dict[int, VLLMClient] = {}
+        self.clients = {}   # port -> VLLMClient
 
     def get_client(self, port: int, **client_kwargs) -> VLLMClient:
         client = self.clients.get(port)
@@ -215,7 +215,7 @@ class VLLMClientManager:
         for port in sorted(self.clients):
             try:
                 report[port] = bool(self.clients[port].health_check(force=True))
-            except Exception:      # a probe must not take the whole report down
+            except (VLLMClientError, OSError, ValueError):      # a probe must not take the whole report down
                 report[port] = False
         return report
 
@@ -233,7 +233,8 @@ client_manager = VLLMClientManager()
 
 
 def get_vllm_client_for_worker(worker_name: str, **kwargs) -> VLLMClient:
-    return client_manager.get_client_from_worker_name(worker_name, **kwargs)
+    manager = client_manager
+    return manager.get_client_from_worker_name(worker_name, **kwargs)
 
 
 # ----------------------------------------------------------------------------- llm_clients surface
