@@ -199,12 +199,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NT][MT], const kr_bf1
     }
 }
 
+// Tile id -> (m tile, n tile) of the 256x256 tile list.  group_m <= 1: m-major rows.  group_m = g: the list walks DOWN g
+// m tiles before it moves to the next n tile (groups of g x tiles_n tiles), so the ~32 workgroups that run side by side on
+// one XCD (a contiguous run of ids, xcd_remap) cover g x 32/g tiles and share g A blocks + 32/g W blocks in that XCD's L2
+// instead of 1 + 32 (prefill gate/up, 70 n tiles: every m row re-streamed all of W through the 4 MB L2).
+__device__ __forceinline__ void tile_coords(unsigned id, unsigned tiles_m, unsigned tiles_n, unsigned group_m, unsigned& tm,
+                                            unsigned& tn) {
+    if (group_m <= 1) {
+        tm = id / tiles_n;
+        tn = id - tm * tiles_n;
+        return;
+    }
+    const unsigned per_group = group_m * tiles_n;
+    const unsigned g = id / per_group, first = g * group_m;
+    const unsigned gsz = min(tiles_m - first, group_m);
+    const unsigned r = id - g * per_group;
+    tn = r / gsz;
+    tm = first + (r - tn * gsz);
+}
+
 template <int EPI, bool WPACK, typename G>
 __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
                                                    const kr_bf16* __restrict__ W, const kr_bf16* __restrict__ bias,
                                                    const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C,
                                                    int64_t ldc, int64_t M, int N, int K, int tiles_n, unsigned nwg,
-                                                   int ptiles_n, unsigned qbase) {
+                                                   int ptiles_n, unsigned qbase, int group_m) {
     constexpr int BM = G::BM, BN = G::BN, NTHR = G::WM * G::WN * 64;
     constexpr int WTM = BM / G::WM, WTN = BN / G::WN;  // wave tile
     constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -222,8 +241,10 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
         // TAIL of a 256x256-tile launch (launch_gemm_pipe): this grid is the quarters (128x128) of the 256x256 tiles
         // qbase, qbase + 1, ... of that launch's m-major tile list — the tiles of its last, mostly empty round
         const unsigned parent = qbase + (wg >> 2), sub = wg & 3u;
-        m0 = (int64_t)(parent / (unsigned)ptiles_n) * 256 + (sub >> 1) * 128;
-        n0 = (int)(parent % (unsigned)ptiles_n) * 256 + (int)(sub & 1u) * 128;
+        unsigned tm, tn;
+        tile_coords(parent, (unsigned)((M + 255) >> 8), (unsigned)ptiles_n, (unsigned)group_m, tm, tn);
+        m0 = (int64_t)tm * 256 + (sub >> 1) * 128;
+        n0 = (int)tn * 256 + (int)(sub & 1u) * 128;
         if (m0 >= M) return;  // the parent straddled the end of M (whole workgroup: before any barrier)
     }
 
@@ -341,7 +362,7 @@ template <int EPI, bool WPACK, bool W8>
 __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restrict__ A, int64_t lda, const kr_bf16* __restrict__ W,
                                                         const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R,
                                                         int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                                                        int tiles_n, unsigned nwg, const float* __restrict__ w_scale) {
+                                                        int tiles_n, unsigned nwg, const float* __restrict__ w_scale, int group_m) {
     constexpr int NT = 4, MT = 8, A_BYTES = 256 * PK * 2;
     const uint8_t* W8p = reinterpret_cast<const uint8_t*>(W);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (a second one makes hipcc drain the DMA)
@@ -350,8 +371,10 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const unsigned wg = xcd_remap(blockIdx.x, nwg);
-    const int64_t m0 = (int64_t)(wg / tiles_n) * 256;
-    const int n0 = (int)(wg % tiles_n) * 256;
+    unsigned tm, tn;
+    tile_coords(wg, (unsigned)((M + 255) >> 8), (unsigned)tiles_n, (unsigned)group_m, tm, tn);
+    const int64_t m0 = (int64_t)tm * 256;
+    const int n0 = (int)tn * 256;
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -461,7 +484,8 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
 
 template <int EPI, bool WPACK>
 int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
-                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, kr_stream s);
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, int group_m,
+                     kr_stream s);
 inline int kr_cu_count();
 
 // One 512-thread workgroup per CU at a time: a launch of T tiles takes ceil(T / CUs) ROUNDS, and the page-sized GEMMs
@@ -496,11 +520,17 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
+    // measured (tools/gemm_microbench.py, r2): groups of 8 m tiles against m-major rows — ViT qkv (15 n tiles) 373 -> 350 us,
+    // fc1 (20) 518 -> 496, prefill gate/up (70) 581 -> 562, 8192^3 856 -> 1390 TFLOP/s; with 5-6 n tiles an m-major run of
+    // 32 ids is already a compact patch and groups are neutral (proj, down_proj) or worse (ViT fc2, K = 5120: 467 -> 495)
+    const char* genv = getenv("KARANTA_GEMM_GROUP_M");
+    const int group_m = genv ? atoi(genv) : (tiles_n >= 8 ? 8 : 1);
     gemm_pipe_kernel<EPI, WPACK, W8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
-                                                                            (unsigned)nwg, w_scale);
+                                                                            (unsigned)nwg, w_scale, group_m);
     KR_CHECK_LAUNCH();
     if constexpr (!W8) {
-        if (tail) return launch_gemm_tail<EPI, WPACK>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg, tail, s);
+        if (tail)
+            return launch_gemm_tail<EPI, WPACK>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg, tail, group_m, s);
     }
     return KR_OK;
 }
@@ -519,7 +549,7 @@ int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     gemm_kernel<EPI, WPACK, G><<<(unsigned)nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
-                                                                                      tiles_n, (unsigned)nwg, 0, 0u);
+                                                                                      tiles_n, (unsigned)nwg, 0, 0u, 0);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
@@ -527,7 +557,8 @@ int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
 // The quarters of the 256x256 tiles [tile0, tile0 + n_tiles) of a launch_gemm_pipe tile list, as 128x128 workgroups.
 template <int EPI, bool WPACK>
 int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
-                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, kr_stream s) {
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, int group_m,
+                     kr_stream s) {
     using G = G128;
     constexpr int LDS = 2 * (G::BM + G::BN) * BK * 2;
     static KrPerDeviceOnce attr_set;
@@ -537,7 +568,7 @@ int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     }
     const unsigned nwg = 4 * n_tiles;
     gemm_kernel<EPI, WPACK, G><<<nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, nwg,
-                                                                          ptiles_n, tile0);
+                                                                          ptiles_n, tile0, group_m);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

@@ -25,20 +25,30 @@ def run(name, M, N, K, epi, packed, reps=5):
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
     out = {}
-    for tile in (128, 256, 512, 513):   # 513: pipelined 256 with the last round cut into 128x128 quarters (the default)
-        os.environ["KARANTA_GEMM_TILE"] = str(min(tile, 512))
-        os.environ["KARANTA_GEMM_TAIL"] = "1" if tile == 513 else "0"
-        call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
+    # (label, KARANTA_GEMM_TILE, KARANTA_GEMM_TAIL, KARANTA_GEMM_GROUP_M); the last one is the default configuration
+    variants = [("128-tile", 128, 0, 0), ("256-tile", 256, 0, 0), ("pipelined 256 m-major", 512, 0, 0),
+                ("+ groups of 4", 512, 0, 4), ("+ groups of 8", 512, 0, 8), ("+ groups of 16", 512, 0, 16),
+                ("default (groups where >= 8 n tiles, tail split)", 512, 1, None)]
+    call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
+    for label, tile, tail, gm in variants:
+        os.environ["KARANTA_GEMM_TILE"] = str(tile)
+        os.environ["KARANTA_GEMM_TAIL"] = str(tail)
+        if gm is None:
+            os.environ.pop("KARANTA_GEMM_GROUP_M", None)
+        else:
+            os.environ["KARANTA_GEMM_GROUP_M"] = str(gm)
         call(); torch.cuda.synchronize()
         best = 1e9
         for _ in range(reps):
-            L.kr_event_record(e0, S); call(); L.kr_event_record(e1, S); L.kr_event_synchronize(e1)
-            ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms)); best = min(best, ms.value)
-        out[tile] = best
+            L.kr_event_record(e0, S)
+            for _ in range(3):
+                call()
+            L.kr_event_record(e1, S); L.kr_event_synchronize(e1)
+            ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms)); best = min(best, ms.value / 3)
+        out[label] = best
     fl = 2.0 * M * N * K
-    print(f"{name:16s} M={M:6d} N={N:6d} K={K:5d}: 128-tile {out[128]*1e3:8.1f} us {fl/out[128]/1e9:7.0f} TF/s | "
-          f"256-tile {out[256]*1e3:8.1f} us {fl/out[256]/1e9:7.0f} TF/s | pipelined 256 {out[512]*1e3:8.1f} us {fl/out[512]/1e9:7.0f} TF/s | "
-          f"+ tail split {out[513]*1e3:8.1f} us {fl/out[513]/1e9:7.0f} TF/s  ({-(-M // 256) * (N // 256)} tiles)", flush=True)
+    print(f"{name:16s} M={M:6d} N={N:6d} K={K:5d} ({-(-M // 256) * (N // 256)} tiles of 256x256): "
+          + " | ".join(f"{lb} {t*1e3:7.1f} us {fl/t/1e9:5.0f} TF/s" for lb, t in out.items()), flush=True)
 
 
 if __name__ == "__main__":

@@ -230,6 +230,23 @@ def test_gemm_256_tile_exact_on_integers(L, tile256, M, N, K):
     np.testing.assert_array_equal(run_gemm(L, A, W, packed=True), ref_linear(A, W))
 
 
+@pytest.mark.parametrize("M,N,K,group", [(700, 2304, 64, 2), (1793, 768, 128, 3), (2049, 2304, 64, 8), (513, 1280, 192, 5)])
+def test_gemm_grouped_tile_order_exact_on_integers(L, M, N, K, group):
+    """The pipelined kernel walks its tile list in groups of `group` m tiles (L2 reuse per XCD; chosen automatically
+    from 8 n tiles up): every tile still computed exactly once, including ragged last groups and the partial M tile."""
+    import os
+    rng = np.random.default_rng(M + N + K + group)
+    A, W = ints(rng, M, K), ints(rng, N, K)
+    os.environ["KARANTA_GEMM_TILE"] = "512"
+    os.environ["KARANTA_GEMM_GROUP_M"] = str(group)
+    try:
+        np.testing.assert_array_equal(run_gemm(L, A, W), ref_linear(A, W))
+        np.testing.assert_array_equal(run_gemm(L, A, W, packed=True), ref_linear(A, W))
+    finally:
+        os.environ.pop("KARANTA_GEMM_TILE", None)
+        os.environ.pop("KARANTA_GEMM_GROUP_M", None)
+
+
 @pytest.mark.parametrize("epi", [EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF])
 def test_gemm_256_tile_epilogues(L, tile256, epi):
     rng = np.random.default_rng(77 + epi)
