@@ -1864,7 +1864,9 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
     // records with 16-byte sc1 loads (never a plain load of these bytes), all requested at once.  Nobody waits:
     // the other workgroups just leave.  Correct for any placement of the splits on XCDs / CUs.
     // (Measured r2: 1.2200 ms per step against 1.2033 with the separate merge launch — the hand-off costs what the
-    // launch costs; kept for the ABI and as the tested example of the protocol.)
+    // launch costs; kept for the ABI and as the tested example of the protocol.  CAUTION before reusing it: the same form
+    // with 64 KB payloads per workgroup — a split-K GEMM fix-up, profiles/r02_decode_experiments.txt — let the last arriver
+    // read a few 16-byte pieces too early in 1 of ~10^6; nothing on the default path depends on an in-launch hand-off.)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, ws_bytes, 0x00020000);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
