@@ -13,6 +13,9 @@
 //  gemv_kernel      : same contract for M <= 16 (decode).  Weights go HBM -> VGPR exactly once with
 //                     non-temporal 16-byte loads, 8+ loads in flight per wave; x (<= 16 rows) is staged
 //                     (optionally RMS-normalised) in LDS.  HBM-bound; roofline = 8 TB/s.
+#include <algorithm>
+#include <mutex>
+
 #include "kr_common.h"
 
 // =====================================================================================
@@ -218,12 +221,18 @@ __device__ __forceinline__ void tile_coords(unsigned id, unsigned tiles_m, unsig
     tm = first + (r - tn * gsz);
 }
 
-template <int EPI, bool WPACK, typename G>
+// STAGES = 2: the tile of K step k+1 is requested at the top of step k and drained (vmcnt(0)) at its end — fine with
+// several workgroups per CU covering for each other.  STAGES = 4 (launches of at most one workgroup per CU: the tail
+// quarters of a 256-tile launch, small GEMMs of a one-page admission): three K steps in flight behind a COUNTED wait and
+// raw barriers, because a lone 4-wave workgroup on a CU has nobody to hide a memory round trip per K step behind (the 8
+// tail tiles of prefill down_proj, K = 8960: 32 workgroups x 140 steps x 1.2 us = 166 us for 3 % of the GEMM's work).
+template <int EPI, bool WPACK, typename G, int STAGES = 2>
 __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16* __restrict__ A, int64_t lda,
                                                    const kr_bf16* __restrict__ W, const kr_bf16* __restrict__ bias,
                                                    const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C,
                                                    int64_t ldc, int64_t M, int N, int K, int tiles_n, unsigned nwg,
-                                                   int ptiles_n, unsigned qbase, int group_m) {
+                                                   int ptiles_n, unsigned qbase, int group_m, int ksplit, int ks_mode,
+                                                   float* __restrict__ ws) {
     constexpr int BM = G::BM, BN = G::BN, NTHR = G::WM * G::WN * 64;
     constexpr int WTM = BM / G::WM, WTN = BN / G::WN;  // wave tile
     constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -234,12 +243,27 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / G::WN, wc = wave % G::WN;
 
-    const unsigned wg = xcd_remap(blockIdx.x, nwg);
+    unsigned wg = xcd_remap(blockIdx.x, nwg);
     int64_t m0 = (int64_t)(wg / tiles_n) * BM;
     int n0 = (int)(wg % tiles_n) * BN;
+    // Tail with a K split (ks_mode): TWO launches, the kernel boundary between them is the hand-off.
+    //   ks_mode 1: grid = quarters x ksplit; this workgroup walks its share of the K steps and leaves its f32 accumulators in
+    //              the workspace, image [quarter][split][thread][NT * MT] f32x4 (thread-private: same fragment map everywhere);
+    //   ks_mode 2: grid = quarters; sums the ksplit partials in split order and runs the epilogue.  No K loop.
+    // A lone 128x128 workgroup streams its 32 KB per K step at the ~45 GB/s ONE CU pulls from HBM (measured: 0.82 us per
+    // step with three steps in flight), so a long-K tail wants its bytes on many CUs, not a deeper ring.
+    unsigned qid = 0, sidx = 0;
     if (ptiles_n > 0) {
         // TAIL of a 256x256-tile launch (launch_gemm_pipe): this grid is the quarters (128x128) of the 256x256 tiles
-        // qbase, qbase + 1, ... of that launch's m-major tile list — the tiles of its last, mostly empty round
+        // qbase, qbase + 1, ... of that launch's tile list — the tiles of its last, mostly empty round
+        if (ks_mode == 1) {
+            wg = blockIdx.x;
+            qid = wg / (unsigned)ksplit;
+            sidx = wg - qid * (unsigned)ksplit;
+            wg = qid;
+        } else {
+            qid = wg;
+        }
         const unsigned parent = qbase + (wg >> 2), sub = wg & 3u;
         unsigned tm, tn;
         tile_coords(parent, (unsigned)((M + 255) >> 8), (unsigned)ptiles_n, (unsigned)group_m, tm, tn);
@@ -254,19 +278,63 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
-    stage_tile<false, BM, NTHR>(A, lda, m0, M, 0, smem, tid, wave);
-    stage_tile<WPACK, BN, NTHR>(W, K, n0, N, 0, smem + A_BYTES, tid, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    int kt0 = 0, nk = K / BK;
+    if (ks_mode == 1) {  // this workgroup's K steps: an even share, the remainder to the first splits
+        const int q = nk / ksplit, r = nk - q * ksplit;
+        kt0 = (int)sidx * q + min((int)sidx, r);
+        nk = kt0 + q + ((int)sidx < r ? 1 : 0);
+    }
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE;
-        if (kt + 1 < nk) {
-            char* nxt = smem + ((kt + 1) & 1) * STAGE;
-            stage_tile<false, BM, NTHR>(A, lda, m0, M, (kt + 1) * BK, nxt, tid, wave);
-            stage_tile<WPACK, BN, NTHR>(W, K, n0, N, (kt + 1) * BK, nxt + A_BYTES, tid, wave);
+    constexpr int FRAGS = NT * MT;
+    if (ks_mode == 2) {
+        for (int sp = 0; sp < ksplit; ++sp) {
+            const f32x4* part = reinterpret_cast<const f32x4*>(ws) + (((size_t)qid * ksplit + sp) * NTHR + tid) * FRAGS;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const f32x4 pv = part[i * MT + j];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][c] += pv[c];
+                }
+        }
+        nk = 0;   // straight to the epilogue
+    }
+    constexpr int LPT = (BM + BN) * 8 / NTHR;   // LDS-DMA instructions per thread and K step
+    auto stage = [&](int kt, int buf) {
+        stage_tile<false, BM, NTHR>(A, lda, m0, M, kt * BK, smem + buf * STAGE, tid, wave);
+        stage_tile<WPACK, BN, NTHR>(W, K, n0, N, kt * BK, smem + buf * STAGE + A_BYTES, tid, wave);
+    };
+    if constexpr (STAGES == 2) {
+        if (kt0 < nk) {
+            stage(kt0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    } else {
+        static_assert(STAGES == 4, "ring depth");
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (kt0 + p < nk) stage(kt0 + p, p);
+    }
+
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int ki = kt - kt0;
+        char* cur = smem + (ki % STAGES) * STAGE;
+        if constexpr (STAGES == 2) {
+            if (kt + 1 < nk) stage(kt + 1, (ki + 1) & 1);
+        } else {
+            // buffer (ki + 3) % 4 = (ki - 1) % 4 was read in step ki - 1, which every wave left at its trailing barrier
+            if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, (ki + STAGES - 1) % STAGES);
+            // K step kt has landed once at most the steps requested after it are outstanding (loads retire in order)
+            const int later = min(STAGES - 1, nk - 1 - kt);
+            if (later == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // raw: a __syncthreads() would drain the staging
+            asm volatile("" ::: "memory");
         }
         const char* At = cur;
         const char* Wt = cur + A_BYTES;
@@ -285,10 +353,24 @@ __global__ void __launch_bounds__(G::WM * G::WN * 64) gemm_kernel(const kr_bf16*
                 for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][mt], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // every wave has read this step's buffer: the next step may restage its ring slot
+            asm volatile("" ::: "memory");
+        }
     }
 
+    if (ks_mode == 1) {
+        f32x4* part = reinterpret_cast<f32x4*>(ws) + (((size_t)qid * ksplit + sidx) * NTHR + tid) * FRAGS;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) part[i * MT + j] = acc[i][j];
+        return;
+    }
     gemm_epilogue<EPI, NT, MT, G::BM == 256>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * WTM, n0 + wc * WTN, fr, fg,
                                              smem + wave * (WTM * 128));
 }
@@ -535,42 +617,97 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     return KR_OK;
 }
 
-template <int EPI, bool WPACK, typename G>
-int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
-                 kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
-    constexpr int LDS = 2 * (G::BM + G::BN) * BK * 2;
-    const int64_t tiles_m = (M + G::BM - 1) / G::BM;
-    const int tiles_n = (N + G::BN - 1) / G::BN;
-    const int64_t nwg = tiles_m * tiles_n;
-    KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
+inline int kr_cu_count();
+
+template <int EPI, bool WPACK, typename G, int STAGES>
+int launch_gemm_kernel(unsigned nwg, const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R,
+                       int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int tiles_n, int ptiles_n, unsigned qbase,
+                       int group_m, kr_stream s, int ksplit = 1, int ks_mode = 0, float* ws = nullptr) {
+    constexpr int LDS = STAGES * (G::BM + G::BN) * BK * 2;
     static KrPerDeviceOnce attr_set;
     if (attr_set.need()) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK, G>),
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK, G, STAGES>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
-    gemm_kernel<EPI, WPACK, G><<<(unsigned)nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K,
-                                                                                      tiles_n, (unsigned)nwg, 0, 0u, 0);
+    gemm_kernel<EPI, WPACK, G, STAGES><<<nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
+                                                                                  nwg, ptiles_n, qbase, group_m, ksplit, ks_mode, ws);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
 
-// The quarters of the 256x256 tiles [tile0, tile0 + n_tiles) of a launch_gemm_pipe tile list, as 128x128 workgroups.
+// 128x128 launches of at most one workgroup per CU take the 4-deep ring (see gemm_kernel); KARANTA_GEMM_STAGES=2 forces
+// the two-buffer form (A/B, tests).
+inline bool gemm_deep_ring(int64_t nwg) {
+    const char* env = getenv("KARANTA_GEMM_STAGES");
+    if (env) return atoi(env) == 4;
+    return nwg <= kr_cu_count();
+}
+
+template <int EPI, bool WPACK, typename G>
+int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
+                 kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s) {
+    const int64_t tiles_m = (M + G::BM - 1) / G::BM;
+    const int tiles_n = (N + G::BN - 1) / G::BN;
+    const int64_t nwg = tiles_m * tiles_n;
+    KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_bf16: grid too large");
+    if constexpr (G::BM == 128) {
+        if (gemm_deep_ring(nwg))
+            return launch_gemm_kernel<EPI, WPACK, G, 4>((unsigned)nwg, A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, 0, 0u, 0, s);
+    }
+    return launch_gemm_kernel<EPI, WPACK, G, 2>((unsigned)nwg, A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, 0, 0u, 0, s);
+}
+
+// Split-K workspace of the tail launches: per (device, stream), allocated on first use (never while the stream is
+// capturing).  nullptr -> the caller runs the tail unsplit.
+constexpr int TAIL_MAX_WGS = 512, TAIL_WG_BYTES = 256 * 16 * 16;   // 128x128 f32 per workgroup
+inline float* gemm_tail_workspace(kr_stream s) {
+    struct Slot { int dev; hipStream_t st; bool used; float* ws; };
+    static Slot slots[32] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& sl : slots)
+        if (sl.used && sl.dev == dev && sl.st == kr_hs(s)) return sl.ws;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(kr_hs(s), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    for (auto& sl : slots) {
+        if (sl.used) continue;
+        void* a = nullptr;
+        if (hipMalloc(&a, (size_t)TAIL_MAX_WGS * TAIL_WG_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        sl.used = true; sl.dev = dev; sl.st = kr_hs(s); sl.ws = (float*)a;
+        return sl.ws;
+    }
+    return nullptr;
+}
+
+// The quarters of the 256x256 tiles [tile0, tile0 + n_tiles) of a launch_gemm_pipe tile list, as 128x128 workgroups; with a
+// long K (>= 4096) and few tail tiles each quarter is cut into K ranges (partials launch + reduce-and-epilogue launch, see
+// gemm_kernel) so that the tail's bytes are pulled by ~256-512 workgroups instead of 4 per tail tile.
 template <int EPI, bool WPACK>
 int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
                      kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, int group_m,
                      kr_stream s) {
-    using G = G128;
-    constexpr int LDS = 2 * (G::BM + G::BN) * BK * 2;
-    static KrPerDeviceOnce attr_set;
-    if (attr_set.need()) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, WPACK, G>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    const unsigned nq = 4 * n_tiles;
+    const char* env = getenv("KARANTA_GEMM_TAIL_KSPLIT");   // 0 / 1: never split (A/B, tests); n: at most n ranges
+    const int cap = env ? atoi(env) : 16;
+    int ksplit = 1;
+    // one round of workgroups (4-deep ring: one per CU), at least 8 K steps each
+    if (cap > 1 && K >= 4096) ksplit = std::max(1, std::min(std::min(cap, (K / BK) / 8), (int)(kr_cu_count() / nq)));
+    float* ws = ksplit > 1 ? gemm_tail_workspace(s) : nullptr;
+    if (ws) {
+        int rc = launch_gemm_kernel<EPI, WPACK, G128, 4>(nq * ksplit, A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, ptiles_n, tile0,
+                                                         group_m, s, ksplit, 1, ws);
+        if (rc != KR_OK) return rc;
+        return launch_gemm_kernel<EPI, WPACK, G128, 2>(nq, A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, ptiles_n, tile0, group_m, s,
+                                                       ksplit, 2, ws);
     }
-    const unsigned nwg = 4 * n_tiles;
-    gemm_kernel<EPI, WPACK, G><<<nwg, G::WM * G::WN * 64, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, nwg,
-                                                                          ptiles_n, tile0, group_m);
-    KR_CHECK_LAUNCH();
-    return KR_OK;
+    if (gemm_deep_ring(nq))
+        return launch_gemm_kernel<EPI, WPACK, G128, 4>(nq, A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, ptiles_n, tile0, group_m, s);
+    return launch_gemm_kernel<EPI, WPACK, G128, 2>(nq, A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, ptiles_n, tile0, group_m, s);
 }
 
 // Compute units of the current device (cached per device): the round size of a one-workgroup-per-CU launch.

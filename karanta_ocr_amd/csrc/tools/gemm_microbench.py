@@ -28,10 +28,19 @@ def run(name, M, N, K, epi, packed, reps=5):
     # (label, KARANTA_GEMM_TILE, KARANTA_GEMM_TAIL, KARANTA_GEMM_GROUP_M); the last one is the default configuration
     variants = [("128-tile", 128, 0, 0), ("256-tile", 256, 0, 0), ("pipelined 256 m-major", 512, 0, 0),
                 ("+ groups of 4", 512, 0, 4), ("+ groups of 8", 512, 0, 8), ("+ groups of 16", 512, 0, 16),
-                ("default (groups where >= 8 n tiles, tail split)", 512, 1, None)]
+                ("groups + tail, 2-buffer 128 kernel", 512, 1, None, 2), ("groups + unsplit deep-ring tail", 512, 1, None, 4, 1), ("default (groups where >= 8 n tiles, tail split, deep ring)", 512, 1, None),
+                ("automatic tile, 2-buffer", 0, 1, None, 2), ("automatic tile (default)", 0, 1, None)]
     call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
-    for label, tile, tail, gm in variants:
-        os.environ["KARANTA_GEMM_TILE"] = str(tile)
+    for label, tile, tail, gm, *st in variants:
+        if tile:
+            os.environ["KARANTA_GEMM_TILE"] = str(tile)
+        else:
+            os.environ.pop("KARANTA_GEMM_TILE", None)
+        if st and st[0] != 4:
+            os.environ["KARANTA_GEMM_STAGES"] = str(st[0])
+        else:
+            os.environ.pop("KARANTA_GEMM_STAGES", None)
+        os.environ["KARANTA_GEMM_TAIL_KSPLIT"] = str(st[1]) if len(st) > 1 else "16"
         os.environ["KARANTA_GEMM_TAIL"] = str(tail)
         if gm is None:
             os.environ.pop("KARANTA_GEMM_GROUP_M", None)
@@ -56,5 +65,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "square":   # the shapes GEMM kernels are usually quoted on
         SHAPES = [("4096^3", 4096, 4096, 4096, EPI_NONE, 0), ("8192^3", 8192, 8192, 8192, EPI_NONE, 0),
                   ("16384x4096x4096", 16384, 4096, 4096, EPI_NONE, 0)]
+    if len(sys.argv) > 1 and sys.argv[1] == "page":     # one page admitted alone (serving): M = 4900 patches / 1394 tokens
+        SHAPES = [("1p vit qkv", 4900, 3840, 1280, EPI_NONE, 0), ("1p vit proj", 4900, 1280, 1280, EPI_NONE, 0),
+                  ("1p vit fc1", 4900, 5120, 1280, EPI_QUICK_GELU, 0), ("1p vit fc2", 4900, 1280, 5120, EPI_NONE, 0),
+                  ("1p prefill qkv", 1394, 2048, 1536, EPI_NONE, 1), ("1p prefill o", 1394, 1536, 1536, EPI_NONE, 1),
+                  ("1p prefill gate_up", 1394, 17920, 1536, EPI_SILU_MUL8, 1), ("1p prefill down", 1394, 1536, 8960, EPI_NONE, 1)]
     for sh in SHAPES:
         run(*sh)
