@@ -152,6 +152,9 @@ extern "C" int kr_attn_debug_read(unsigned long long* out) {
 #else
 #define KR_STAMP(var)
 #endif
+#ifndef KR_ATTN_ROT
+#define KR_ATTN_ROT 0   // measured slower (see ROT in the kernel): build with -DKR_ATTN_ROT=1 to repeat the experiment
+#endif
 #ifndef KR_ATTN_VPRE
 #define KR_ATTN_VPRE(HD) ((HD) == 80 ? 3 : 0)
 #endif
@@ -294,10 +297,49 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
+    // P (bf16) and the V^T fragments of a tile; with ROT they live across the barrier (see below)
+    bf16x8 vf[C::DT][4], pf[2][2];
+    auto load_v = [&](const char* v_s, int dt) {
+        const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int kb = f * 16 + 4 * lh;  // keys kb..kb+3 and kb+8..kb+11
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
+            vf[dt][f] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+        }
+    };
+    // ---- O^T += V^T P^T
+    auto do_pv = [&](const char* v_s) {
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            if (dt + VPRE < C::DT) load_v(v_s, dt + VPRE);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][sub * 2 + ss], pf[sub][ss], o[dt], 0, 0, 0);
+        }
+    };
+    // ROT (8-wave workgroups with every V^T fragment prefetched): the two waves a SIMD holds come from the same workgroup and
+    // march in step — both in QK^T (matrix pipe contended, vector ALU idle), then both in the softmax (the reverse).  The
+    // second half of the waves therefore runs its PV one barrier LATE, from registers: tile t's P and V^T fragments are kept
+    // across the barrier and multiplied at the top of the next iteration, so one wave's PV / QK^T MFMAs sit beside the other's
+    // softmax.  Nothing else changes: PV(t) still completes before tile t + 1's rescale decision, in program order.
+    // MEASURED (r2, same box, bit-identical outputs): 8 x 4900 tokens 1.196-1.200 ms per block against 1.135-1.152 without,
+    // 19 276 tokens 2.21 against 2.11 — the late PV is 12 bare MFMAs that no longer hide this wave's exponentials, and that
+    // costs more than the staggering gains.  OFF by default (KR_ATTN_ROT).
+    constexpr bool ROT = (NW == 8) && (VPRE == C::DT) && KR_ATTN_ROT;
+    const bool rot = ROT && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+    bool pend = false;
     for (int t = 0; t < n_tiles; ++t) {
         KR_STAMP(st0);
         const char* k_s = img_s + (t & 1) * IMG;
         const char* v_s = k_s + K_BYTES;
+        if (ROT && rot && pend) {
+            do_pv(nullptr);
+            pend = false;
+        }
 
         // ---- S^T = K Q^T.  All K fragments of the tile are requested before the first MFMA.
         // (r2: requesting one 32-key half at a time does not lower the register peak, and forcing 3 waves per SIMD
@@ -345,19 +387,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
         // V^T fragments of the first VPRE 32-row tiles of O^T are requested here, behind the QK^T MFMAs: their LDS
         // round trips run under the softmax instead of in front of each PV MFMA (the register file has the room since
         // the accumulators stopped being copied: 186 -> ~230 of the 256 two waves per SIMD allow)
-        bf16x8 vf[C::DT][4];
-        auto load_v = [&](int dt) {
-            const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int kb = f * 16 + 4 * lh;  // keys kb..kb+3 and kb+8..kb+11
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
-                vf[dt][f] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
-            }
-        };
-#pragma unroll
-        for (int dt = 0; dt < VPRE; ++dt) load_v(dt);
+        for (int dt = 0; dt < VPRE; ++dt) load_v(v_s, dt);
         // ---- mask, online softmax (lane = query; rows = keys).  The softmax is the VALU-bound part of this
         // kernel (PMC: vector ALU ~70 % busy, MFMA 22 %), so: masks only on tiles that need one (wave-uniform
         // test), the scale folded into one fma per score, P converted to bf16 pairwise, and a LAZY running max:
@@ -406,7 +437,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
         float psum = 0.f;
-        bf16x8 pf[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -420,16 +450,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
                 pf[sub][h8] = __builtin_convertvector(pv, bf16x8);
             }
         l_run += psum;
-        // ---- O^T += V^T P^T
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) {
-            if (dt + VPRE < C::DT) load_v(dt + VPRE);
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][sub * 2 + ss], pf[sub][ss], o[dt], 0, 0, 0);
-        }
+        if (ROT && rot) pend = true;
+        else do_pv(v_s);
         }
 #ifdef KR_ATTN_STAMPS
 #pragma unroll
@@ -448,6 +470,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
         acc[0] += st1 - st0; acc[1] += st2 - st1; acc[2] += st3 - st2; acc[3] += st4 - st3; acc[4] += st5 - st4; acc[5] += st6 - st5;
 #endif
     }
+    if (ROT && rot && pend) do_pv(nullptr);
 #ifdef KR_ATTN_STAMPS
     if (blockIdx.x == gridDim.x / 2 && lane == 0) {
 #pragma unroll
