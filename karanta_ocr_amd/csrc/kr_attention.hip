@@ -152,6 +152,9 @@ extern "C" int kr_attn_debug_read(unsigned long long* out) {
 #else
 #define KR_STAMP(var)
 #endif
+#ifndef KR_ATTN_PRESCALE
+#define KR_ATTN_PRESCALE 1
+#endif
 #ifndef KR_ATTN_ROT
 #define KR_ATTN_ROT 0   // measured slower (see ROT in the kernel): build with -DKR_ATTN_ROT=1 to repeat the experiment
 #endif
@@ -237,6 +240,21 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
     bf16x8 qf[C::KS];
 #pragma unroll
     for (int s = 0; s < C::KS; ++s) qf[s] = ld8(qp + s * 16);
+    // PRESCALE (hd 80, where the registers allow a second accumulator-sized tuple): Q is multiplied by scale * log2(e) ONCE
+    // and rounded back to bf16, and the QK^T accumulators START at -m_ref (the lazy reference maximum, a per-query constant
+    // held in `cinit`), so that S^T comes out of the matrix pipe as the exp2 argument itself: the 32 v_fma per tile that
+    // applied scale and reference were a fifth of the loop's vector-ALU issue slots.  The extra rounding of Q (relative
+    // 2^-9 per element) is of the size of the bf16 rounding the HF reference applies to the scores themselves.
+    constexpr bool PRESCALE = (HD == 80) && KR_ATTN_PRESCALE;
+    if (PRESCALE) {
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = f2bf(bf2f(qf[s][j]) * scale_log2e);
+    }
+    f32x16 cinit;   // PRESCALE: -m_run in every register of the lane (lane = query)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
     const int qpos = q_pos0 + wave * 32 + lq;
 
     const kr_bf16* kbase = k + (int64_t)kvh * k_head_stride + k_row0 * HD;
@@ -247,7 +265,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
     for (int t = 0; t < C::DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = PRESCALE ? 0.f : -1e30f, l_run = 0.f;
 
     // Every thread takes exactly one chunk in every pass, in the loop ALWAYS (a tile index past the end re-loads the last
     // tile, a list index past the end the last chunk: the same bytes to the same place), and a chunk goes to LDS as two
@@ -375,10 +393,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
         f32x16 s[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            if (PRESCALE) {
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][0], qf[0], cinit, 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][0], qf[0], s[sub], 0, 0, 0);
+            }
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
+            for (int ks = 1; ks < C::KS; ++ks)
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[ks], s[sub], 0, 0, 0);
         }
 #ifdef KR_ATTN_PRIO
@@ -421,20 +444,45 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
             mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
         }
 #endif
-        mx *= scale_log2e;  // scale > 0: max commutes with it
+        if (!PRESCALE) mx *= scale_log2e;  // scale > 0: max commutes with it
 #ifdef KR_ATTN_STAMPS
         asm volatile("" : "+v"(mx));
 #endif
         KR_STAMP(st2);
-        const float m_new = fmaxf(m_run, mx);
-        if (__any(m_new - m_run > 8.0f)) {  // first tile (m_run = -1e30), then rarely
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
+        if (PRESCALE) {
+            // the scores ARE s - m_run already: mx is this tile's maximum relative to the reference.  The first tile moves
+            // the reference onto its own maximum (o and l are still zero: nothing to scale), later tiles move it only
+            // when a query's maximum grew by more than 2^8 — both rare enough to pay 48 extra subtractions there.
+            const bool first = t == 0;
+            if (first || __any(mx > 8.0f)) {
+                const float d = first ? (mx > -INFINITY ? mx : 0.f) : fmaxf(mx, 0.f);
+                m_run += d;
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
+                for (int r = 0; r < 16; ++r) cinit[r] = -m_run;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[sub][r] -= d;
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                }
+            }
+        } else {
+            const float m_new = fmaxf(m_run, mx);
+            if (__any(m_new - m_run > 8.0f)) {  // first tile (m_run = -1e30), then rarely
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
         }
         float psum = 0.f;
 #pragma unroll
@@ -444,7 +492,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
                 f32x8 pv;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    pv[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][h8 * 8 + j], scale_log2e, -m_run));
+                    pv[j] = PRESCALE ? __builtin_amdgcn_exp2f(s[sub][h8 * 8 + j])
+                                     : __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][h8 * 8 + j], scale_log2e, -m_run));
                     if (!ONES) psum += pv[j];
                 }
                 pf[sub][h8] = __builtin_convertvector(pv, bf16x8);

@@ -617,6 +617,10 @@ def test_attention_online_softmax_rescale_branch(L):
     rng = np.random.default_rng(77)
     H, hd, n = 1, 80, 300
     q, k, v = rnd(rng, H, n, hd, scale=0.3), rnd(rng, H, n, hd, scale=0.3), rnd(rng, H, n, hd)
+    # (the model's scale, hd^-0.5: the spikes below are then 12 |q|^2 hd^-0.5 ~ 10 nats = 14 in the kernel's log2 units, well
+    # past the 2^8 rescale threshold, at score magnitudes a trained head can reach.  The hd 80 kernel rounds Q * scale to
+    # bf16 once — an error proportional to |score| — so unit scale with 40-nat scores would test a regime it never sees.)
+    scale = hd ** -0.5
     k[0, 250] = bf16_round(q[0, 17] * 12)  # spike in tile 3 for query 17
     k[0, 3] = bf16_round(q[0, 200] * 12)   # and an early spike for a query of the second q-block
     qd, kd = dev_bf16(q), dev_bf16(k)
@@ -630,8 +634,11 @@ def test_attention_online_softmax_rescale_branch(L):
     qb, ql = t_(plan.qblk), t_(plan.qblk_len)
     vtd = dev_bf16(vt)
     L.kr_attn_varlen(ptr(qd), ptr(kd), ptr(vtd), ptr(o), ptr(qb), ptr(ql), plan.qblk.shape[0], n, H, H, hd,
-                     n * hd, 5 * hd * 64, 1.0, 0, 0)
-    ref = np_attention(q, k, v, 1.0, False)
+                     n * hd, 5 * hd * 64, scale, 0, 0)
+    ref = np_attention(q, k, v, scale, False)
+    s17 = float(q[0, 17] @ k[0, 250]) * scale * 1.4427
+    others = float(np.max(np.delete(q[0, 17] @ k[0].T, 250))) * scale * 1.4427
+    assert s17 - max(others, 0.0) > 8.0, "the spike no longer crosses the kernel's rescale threshold"
     assert_close_bf16(host(o), ref, rel=2 ** -6, abs_=2e-2, what="rescale branch")
 
 
