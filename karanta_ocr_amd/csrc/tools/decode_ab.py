@@ -66,6 +66,7 @@ def main():
         os.environ.update(env)
         eng = Engine(cfg, max_batch=B, s_max=s_max, max_patches=64, max_prompt_tokens=64,
                      decode_splits=int(over.pop("n_split", 16)), weight_dtype=a.weights)
+        over.pop("steps_per_graph", None)     # handled where the graph is captured
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -95,13 +96,26 @@ def main():
 
     if a.chain:
         return chains(a, engines, reset)
-    graphs = {}
+    graphs, per_graph = {}, {}
     for spec, eng in engines:
         reset(eng)
+        k = 1
+        for kv in spec.split(","):
+            if kv.startswith("steps_per_graph="):
+                k = int(kv.split("=")[1])
+        per_graph[spec] = k
         with torch.cuda.stream(eng.stream):
             eng._decode_step_launches(B)          # eager once (function attributes), then captured
             eng.stream.synchronize()
-            graphs[spec] = eng._graph_for(B)
+            if k == 1:
+                graphs[spec] = eng._graph_for(B)
+            else:                                 # k consecutive steps in ONE graph (the state lives on the device)
+                L.kr_graph_begin_capture(eng.s)
+                for _ in range(k):
+                    eng._decode_step_launches(B)
+                g = C.c_void_p()
+                L.kr_graph_end_capture(eng.s, C.byref(g))
+                graphs[spec] = g.value
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
     times = {spec: [] for spec, _ in engines}
@@ -109,7 +123,7 @@ def main():
         for spec, eng in engines:
             reset(eng)
             L.kr_event_record(e0, eng.s)
-            for _ in range(a.steps):
+            for _ in range(a.steps // per_graph[spec]):
                 L.kr_graph_launch(graphs[spec], eng.s)
             L.kr_event_record(e1, eng.s)
             L.kr_event_synchronize(e1)
