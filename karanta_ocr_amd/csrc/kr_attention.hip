@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
                                                        int64_t k_head_stride, kr_bf16* __restrict__ vt_out,
                                                        int64_t vt_head_stride, int q_heads, int n_slots) {
     constexpr int HC = HD / 16;  // 8-element chunks in half a head
-    __shared__ __attribute__((aligned(16))) kr_bf16 vt_s[HD][64 + 8];
+    constexpr int VT_RS = 33;    // dwords per V^T row in LDS: 32 token pairs + 1
+    __shared__ unsigned vt_s[HD * VT_RS];
     const int i = blockIdx.x;
     const int y0 = blockIdx.y * PREP_G, y1 = min(y0 + PREP_G, n_slots);
     const int tok0 = blk_tok0[i], ntok = blk_ntok[i];
@@ -108,21 +109,29 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
             st8(dst + d1, rope8(b, a, c1, s1, 1.f));
         }
     }
-    // ---- V of the block's k-head slots: [64 tok][HD] -> LDS transposed -> V^T block [HD][64], zero padded past ntok
+    // ---- V of the block's k-head slots: [64 tok][HD] -> LDS transposed -> V^T block [HD][64], zero padded past ntok.
+    // A thread takes one 8-channel chunk of a PAIR of tokens and writes 8 whole dwords (two tokens of one channel): rows
+    // of 33 dwords put the 10 / 16 chunks of a pair on distinct banks (r1 / early r2: 2-byte writes, 8-way conflicts).
     for (int y = max(y0, q_heads); y < y1; ++y) {
         const int head = y - q_heads;
-        for (int e = threadIdx.x; e < 64 * (HD / 8); e += 256) {
-            const int j = e / (HD / 8), c = e - j * (HD / 8);
-            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-            if (j < ntok) v = *reinterpret_cast<const u32x4*>(qkv + (int64_t)(tok0 + j) * ld_qkv + v_off + head * HD + c * 8);
+        for (int e = threadIdx.x; e < 32 * (HD / 8); e += 256) {
+            const int jp = e / (HD / 8), c = e - jp * (HD / 8);
+            u32x4 va = (u32x4){0u, 0u, 0u, 0u}, vb = va;
+            const kr_bf16* src = qkv + (int64_t)(tok0 + 2 * jp) * ld_qkv + v_off + head * HD + c * 8;
+            if (2 * jp < ntok) va = *reinterpret_cast<const u32x4*>(src);
+            if (2 * jp + 1 < ntok) vb = *reinterpret_cast<const u32x4*>(src + ld_qkv);
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) vt_s[c * 8 + jj][j] = (kr_bf16)((v[jj >> 1] >> ((jj & 1) * 16)) & 0xffffu);
+            for (int jj = 0; jj < 8; ++jj) {
+                const unsigned lo = (va[jj >> 1] >> ((jj & 1) * 16)) & 0xffffu, hi = (vb[jj >> 1] >> ((jj & 1) * 16)) & 0xffffu;
+                vt_s[(c * 8 + jj) * VT_RS + jp] = lo | (hi << 16);
+            }
         }
         __syncthreads();
         kr_bf16* vt = vt_out + (int64_t)head * vt_head_stride + blk_vt_blk[i] * (int64_t)(HD * 64);
         for (int e = threadIdx.x; e < HD * 8; e += 256) {
             const int d = e >> 3, c = e & 7;
-            *reinterpret_cast<u32x4*>(vt + d * 64 + c * 8) = *reinterpret_cast<const u32x4*>(&vt_s[d][c * 8]);
+            const unsigned* r = vt_s + d * VT_RS + c * 4;
+            *reinterpret_cast<u32x4*>(vt + d * 64 + c * 8) = (u32x4){r[0], r[1], r[2], r[3]};
         }
         __syncthreads();
     }
