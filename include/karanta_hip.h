@@ -326,6 +326,16 @@ int kr_decode_prefetch_next(const void* ptr, size_t bytes, int blocks);
  * per 16-row range).  0 restores the default. */
 int kr_decode_part_rows_next(int rows);
 
+/* One-shot, consumed by the next kr_linear_decode_narrow* launch of this thread (the ONE-slab form of the deferred
+ * split-K between a layer's down_proj and the next layer's qkv prologue; VERDICT r1 lever (iii)):
+ *   atomic_out != 0 : a ksplit == 2 launch ADDS its two K ranges into ONE f32 slab out_f32 [M][ldc] with float atomics
+ *                     instead of writing two slabs.  The slab must hold zeros; two addends onto zero give the same bits in
+ *                     either arrival order, so the path stays reproducible.  The consumer passes it as part_in with
+ *                     n_part_in = 1 and reads half the slab bytes in every workgroup's prologue.
+ *   zero_ptr, zero_bytes : the launch also zeroes that f32 range (multiple of 16 bytes; at most gridsize x 16 bytes):
+ *                     the engine lets layer L's qkv launch zero the slab layer L's down_proj will add into. */
+int kr_decode_slab_next(float* zero_ptr, size_t zero_bytes, int atomic_out);
+
 /* The same two kernels on fp8 (OCP e4m3fn) weights — BASELINE.json config 5: decoder Linears in fp8 with one f32 scale
  * per output row, activations bf16.  w_packed_fp8 = weights.pack_w16x64_fp8 (one 16-row x 64-column block = 1 KiB in
  * lane order: half the bytes per launch), converted to bf16 in registers (exact) and fed to the bf16 MFMA; w_scale

@@ -76,6 +76,7 @@ SIGNATURES = {
     "kr_linear_decode_narrow_x32": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                     i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
     "kr_decode_part_rows_next": [i32],
+    "kr_decode_slab_next": [c_p, C.c_size_t, i32],
     "kr_decode_prefetch_next": [c_p, C.c_size_t, i32],
     "kr_oproj_heads": [c_p, i32, c_p, c_p, c_p, i64, i32, i32, i32, c_p],
     "kr_linear_decode_wide_x32": [i32, c_p, i64, c_p, i64, c_p, c_p, c_p, f32, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],

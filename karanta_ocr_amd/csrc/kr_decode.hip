@@ -68,6 +68,12 @@ struct DecLinArgs {
     // plain loads (the range lands in the memory-side Infinity Cache) on CUs the launch would otherwise leave idle
     const char* pf_ptr; int64_t pf_bytes; int pf_blocks;
     int part_rows;                     // rows per slab of part_in (0: = M)
+    int n_part;                        // slabs in part_in (1 or 2)
+    // ONE-slab mode of the deferred split (kr_decode_slab_next): the PARTIAL epilogue ADDS its K range into slab 0 with
+    // global_atomic_add_f32 (two addends onto zero: the sum does not depend on their order), and a narrow launch may
+    // carry a zeroing job for the accumulator the NEXT down_proj will add into
+    int part_atomic;
+    float* zero_ptr; int zero_n16;
 };
 
 // One 64-wide K chunk of a 16-row weight tile in registers, and where its operands sit.
@@ -1194,6 +1200,11 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
         for (int t = 0; t < NT; ++t) wbuf[u][t].load(wp[t], c);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (a.zero_ptr) {   // zero the other split-K accumulator (behind this launch's own requests: plain 16-byte stores)
+        const int zstep = (int)(gridDim.x * gridDim.y) * (WAVES * 64);
+        for (int zi = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (WAVES * 64) + tid; zi < a.zero_n16; zi += zstep)
+            reinterpret_cast<f32x4*>(a.zero_ptr)[zi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- 3. x (+ deferred partial sums) -> RMSNorm -> LDS
     if constexpr (NORM) {
@@ -1412,7 +1423,13 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
             if (tile[t] >= ntiles) continue;
             const int n = tile[t] * 16 + fg * 4;
             if (EPI == DEPI_PARTIAL) {
-                *reinterpret_cast<f32x4*>(a.out_f32 + ((int64_t)ks * M + b) * a.ldc + n) = sum[t];
+                if (a.part_atomic) {
+                    float* acc = a.out_f32 + (int64_t)b * a.ldc + n;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(acc + j, sum[t][j]);
+                } else {
+                    *reinterpret_cast<f32x4*>(a.out_f32 + ((int64_t)ks * M + b) * a.ldc + n) = sum[t];
+                }
                 continue;
             }
             float v[4];
@@ -1530,6 +1547,13 @@ int launch_narrow_norm_u(DecLinArgs& a, int groups, kr_stream s) {
 template <int NT, int EPI>
 int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
     const int nch = a.K >> 6;
+    if (a.part_in && a.n_part == 1) {
+        if (nch == 24) return launch_narrow_norm_u<NT, EPI, 24, 1>(a, groups, s);
+        if (nch == 32) return launch_narrow_norm_u<NT, EPI, 32, 1>(a, groups, s);
+        if (nch == 56) return launch_narrow_norm_u<NT, EPI, 56, 1>(a, groups, s);
+        kr_set_error("kr_linear_decode_narrow: deferred partial sums need K = 1536, 2048 or 3584 (K=%d)", a.K);
+        return KR_ERR_ARG;
+    }
     if (a.part_in) {
         if (nch == 24) return launch_narrow_norm_u<NT, EPI, 24, 2>(a, groups, s);
         if (nch == 32) return launch_narrow_norm_u<NT, EPI, 32, 2>(a, groups, s);
@@ -2260,6 +2284,22 @@ extern "C" int kr_decode_part_rows_next(int rows) {
     return KR_OK;
 }
 
+// One-shot, consumed by the next narrow launch of this thread.  zero_ptr / zero_bytes: the launch also zeroes that f32
+// range (16-byte granules).  atomic_out: a split-K (ksplit > 1) launch ADDS its partial sums into ONE slab out_f32 [M][ldc]
+// with float atomics instead of writing ksplit slabs — with two K ranges onto a zeroed slab the result is the same bits
+// whichever range arrives first (a + b = b + a), so the consumer's prologue reads one slab, not two.
+static thread_local float* g_zero_ptr = nullptr;
+static thread_local int64_t g_zero_bytes = 0;
+static thread_local int g_atomic_out = 0;
+extern "C" int kr_decode_slab_next(float* zero_ptr, size_t zero_bytes, int atomic_out) {
+    KR_CHECK_ARG((zero_ptr || zero_bytes == 0) && ((uintptr_t)zero_ptr & 15) == 0 && (zero_bytes & 15) == 0 && zero_bytes < (1u << 30),
+                 "kr_decode_slab_next: zero range");
+    g_zero_ptr = zero_bytes ? zero_ptr : nullptr;
+    g_zero_bytes = (int64_t)zero_bytes;
+    g_atomic_out = atomic_out ? 1 : 0;
+    return KR_OK;
+}
+
 static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
                                        kr_bf16* x_out, int64_t ldxo, const void* w_packed, const float* w_scale, const kr_bf16* bias,
                                        const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
@@ -2274,8 +2314,8 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
     KR_CHECK_ARG(waves == 8 || waves == 16, "kr_linear_decode_narrow: waves=%d (8 or 16)", waves);
     KR_CHECK_ARG(ksplit >= 1 && ksplit <= 8 && ksplit <= (K >> 6), "kr_linear_decode_narrow: ksplit=%d", ksplit);
     KR_CHECK_ARG(!norm_w || K <= 4096, "kr_linear_decode_narrow: fused RMSNorm supports K <= 4096");
-    KR_CHECK_ARG(!part_in || (norm_w && n_part_in == 2 && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0),
-                 "kr_linear_decode_narrow: partial sums need the norm prologue, 2 slabs and a separate x_out");
+    KR_CHECK_ARG(!part_in || (norm_w && (n_part_in == 1 || n_part_in == 2) && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0),
+                 "kr_linear_decode_narrow: partial sums need the norm prologue, 1 or 2 slabs and a separate x_out");
     DecLinArgs a{};
     a.x = x; a.ldx = ldx; a.wp = reinterpret_cast<const kr_bf16*>(w_packed); a.w_scale = w_scale; a.bias = bias;
     a.norm_w = norm_w; a.norm_eps = norm_eps;
@@ -2285,6 +2325,10 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
     a.x_out_f32 = x_out_f32; a.ldxf = ldxf;
     a.part_rows = g_part_rows;
     g_part_rows = 0;
+    a.n_part = part_in ? n_part_in : 0;
+    a.zero_ptr = g_zero_ptr; a.zero_n16 = (int)(g_zero_bytes >> 4); a.part_atomic = g_atomic_out;
+    g_zero_ptr = nullptr; g_zero_bytes = 0; g_atomic_out = 0;
+    KR_CHECK_ARG(!a.part_atomic || (ksplit == 2 && mode == DEPI_PLAIN), "kr_decode_slab_next: atomic slabs are for ksplit 2 (order-free sum)");
     KR_CHECK_ARG(a.part_rows == 0 || (part_in && a.part_rows >= M), "kr_linear_decode_narrow: part rows %d < M %d", a.part_rows, M);
     if (ksplit == 1) {   // a pending prefetch request rides on this launch
         a.pf_ptr = g_pf_ptr; a.pf_bytes = g_pf_bytes; a.pf_blocks = g_pf_blocks;

@@ -349,6 +349,10 @@ class Engine:
         self.d_x = z(B, t.hidden_size)
         self.d_x2 = z(B, t.hidden_size)  # the other residual buffer (deferred split-K ping-pong)
         self.d_part = z(2, B, t.hidden_size, dtype=torch.float32)  # down_proj slabs of the deferred split
+        # ONE-slab form of the deferred split (KARANTA_ATOMIC_SLAB, default on): down_proj's two K ranges add into one f32
+        # accumulator with float atomics (a + b onto zero: order-free, reproducible); two accumulators alternate by layer
+        # parity, layer L's qkv launch zeroes the one layer L's down_proj adds into.  d_part doubles as the pair.
+        self.atomic_slab = os.environ.get("KARANTA_ATOMIC_SLAB", "1") == "1"
         self.d_xacc = z(B, t.hidden_size, dtype=torch.float32)     # fast-residual mode: f32 residual accumulator
         self.d_qkv = z(B, t.qkv_dim)
         self.d_q = z(B, t.num_heads, t.head_dim)
@@ -483,7 +487,7 @@ class Engine:
         N, K = W.shape
         o = out if out is not None else out_f32
         ldc = o.stride(-2) if o is not None else 0  # slabs of the deferred split are [ksplit][M][ldc] with the CURRENT M, packed in d_part
-        head = (mode, ptr(x), x.stride(0), ptr(part_in), 2 if part_in is not None else 0, ptr(x_out),
+        head = (mode, ptr(x), x.stride(0), ptr(part_in), int(part_in.shape[0]) if part_in is not None else 0, ptr(x_out),
                 x_out.stride(0) if x_out is not None else 0)
         # row0: the launch covers batch rows row0 .. row0 + M - 1 (every per-sequence array is handed over from that row)
         tail = (ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
@@ -501,9 +505,10 @@ class Engine:
         else:
             self.L.kr_linear_decode_narrow(*head, ptr(W), *tail)
 
-    @staticmethod
-    def _down_waves(B: int) -> int:
-        return 16 if B <= 16 else 8   # two batch column tiles double the x fragments: 8-wave workgroups only
+    down_waves_small = 16         # waves per down_proj workgroup at <= 16 rows (instance attribute for sweeps)
+
+    def _down_waves(self, B: int) -> int:
+        return self.down_waves_small if B <= 16 else 8   # two batch column tiles double the x fragments: 8-wave workgroups only
 
     def _w8kw(self, name: str) -> dict:
         w8, sc = self._w8(name)
@@ -1105,11 +1110,17 @@ class Engine:
                 L.kr_decode_prefetch_next(w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks)
             if self.narrow_mode:
                 ranges = self._row_ranges(B)
+                slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packs them
+                one_slab = self.atomic_slab and self.defer_down
+                if one_slab and i + 1 < nl:
+                    # this layer's down_proj will ADD into accumulator (i + 1) & 1: this launch zeroes it (it was last read
+                    # by layer i - 1's qkv launch, which is complete)
+                    L.kr_decode_slab_next(ptr(slabs[(i + 1) & 1]), B * t.hidden_size * 4, 0)
                 if pending:
-                    slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packed them
                     for r0, m in ranges:
+                        pin = slabs[i & 1:(i & 1) + 1, r0:] if one_slab else slabs[:, r0:]
                         self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
-                                         norm_w=w.view(p + "ln1.w"), part_in=slabs[:, r0:], x_out=x_other[r0:], kc=kc, vc=vc,
+                                         norm_w=w.view(p + "ln1.w"), part_in=pin, x_out=x_other[r0:], kc=kc, vc=vc,
                                          x_out_f32=None if xacc is None else xacc[r0:], part_rows=B if len(ranges) > 1 else 0,
                                          row0=r0, **self._w8kw(p + "qkv.w"))
                     x, x_other = x_other, x
@@ -1168,8 +1179,14 @@ class Engine:
                 L.kr_event_record(e2, s)
             if self.defer_down and i + 1 < nl:
                 # 2 workgroups per tile; the slabs are added to x by the next layer's qkv prologue
-                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=self._down_waves(B), ksplit=2,
-                                 **self._w8kw(p + "down.w"))
+                if self.atomic_slab:
+                    acc = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)[(i + 1) & 1]
+                    L.kr_decode_slab_next(0, 0, 1)
+                    self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=acc, waves=self._down_waves(B), ksplit=2,
+                                     **self._w8kw(p + "down.w"))
+                else:
+                    self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=self._down_waves(B),
+                                     ksplit=2, **self._w8kw(p + "down.w"))
                 pending = True
             elif self.narrow_mode:
                 self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self._down_waves(B),

@@ -1098,8 +1098,9 @@ def test_linear_wide_rejects_bad_shapes(L):
 
 
 def narrow_call(L, mode, x, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_w=0, res=0, ldr=0, waves=8, ksplit=1,
-                part_in=0, x_out=0, cs=0, cs_stride=0, plen=0, ctx=0, q_out=0, kc=0, vc=0, heads=0, kv_heads=0, s_max=64):
-    L.kr_linear_decode_narrow(mode, x, K, part_in, 2 if part_in else 0, x_out, K, W, bias, norm_w, 1e-6, res, ldr, out,
+                part_in=0, x_out=0, cs=0, cs_stride=0, plen=0, ctx=0, q_out=0, kc=0, vc=0, heads=0, kv_heads=0, s_max=64,
+                n_part=2):
+    L.kr_linear_decode_narrow(mode, x, K, part_in, n_part if part_in else 0, x_out, K, W, bias, norm_w, 1e-6, res, ldr, out,
                               out_f32, ldc, M, N, K, waves, ksplit, cs, cs_stride, plen, ctx, q_out, kc, vc, heads,
                               kv_heads, s_max, 0)
 
@@ -1147,6 +1148,60 @@ def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
                                       if k * cpb < K else np.zeros((M, N), np.float32))
     with pytest.raises(KarantaHipError):   # slabs only: no residual / bf16 output in the split form
         narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(xd), ldc=N, waves=waves, ksplit=ksplit)
+
+
+@pytest.mark.parametrize("M,N,K,waves", [(8, 1536, 8960, 16), (32, 1536, 8960, 8), (5, 3584, 18944, 16), (16, 96, 256, 8)])
+def test_linear_narrow_one_slab_atomic_split(L, M, N, K, waves):
+    """kr_decode_slab_next: the two K ranges of a ksplit-2 launch ADD into ONE zeroed f32 slab (float atomics; two addends
+    onto zero: the same bits in either order = slab0 + slab1 of the two-slab form), and a launch can carry the zeroing
+    of another range.  Exact on integers, identical run to run, equal to the sum of the two-slab launch on real data."""
+    rng = np.random.default_rng(M + N + K)
+    x, W = ints(rng, M, K), ints(rng, N, K)
+    xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
+    acc = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    other = torch.full((M * N + 8,), 3.0, dtype=torch.float32, device=DEV)     # the range this launch is asked to zero
+    L.kr_decode_slab_next(ptr(other), M * N * 4, 1)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=waves, ksplit=2)
+    np.testing.assert_array_equal(acc.cpu().numpy(), ref_linear(x, W))
+    oc = other.cpu().numpy()
+    assert not oc[:M * N].any() and (oc[M * N:] == 3.0).all(), "zeroing job: exactly the requested range"
+    # the one-shot is consumed: the next launch writes two slabs again and zeroes nothing
+    slabs = torch.full((2, M, N), 7.0, dtype=torch.float32, device=DEV)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(slabs), ldc=N, waves=waves, ksplit=2)
+    np.testing.assert_array_equal(slabs.cpu().numpy().sum(0), ref_linear(x, W))
+    # real data: a + b does not depend on which range lands first
+    xr, Wr = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    xd, Wd = dev_bf16(xr), dev_bf16(pack_w16x64(Wr))
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(slabs), ldc=N, waves=waves, ksplit=2)
+    two = slabs.cpu().numpy()
+    for _ in range(3):
+        acc.zero_()
+        L.kr_decode_slab_next(0, 0, 1)
+        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=waves, ksplit=2)
+        np.testing.assert_array_equal(acc.cpu().numpy(), two[0] + two[1])
+    with pytest.raises(KarantaHipError):       # three addends would make the sum order-dependent: refused
+        L.kr_decode_slab_next(0, 0, 1)
+        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=8, ksplit=3)
+
+
+@pytest.mark.parametrize("M,K", [(8, 1536), (16, 3584), (32, 1536), (27, 2048)])
+def test_linear_narrow_norm_with_one_partial_slab(L, M, K):
+    """n_part_in = 1: x_new = bf16(x + slab) -> x_out, RMSNorm(x_new) @ W^T + bias (the consumer of the one-slab split)."""
+    rng = np.random.default_rng(900 + M + K)
+    N = 16 * 9
+    x, W, nw = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))
+    bias = rnd(rng, N, scale=0.1)
+    p = (rng.standard_normal((1, M, K)) * 0.5).astype(np.float32)
+    xd, Wd, nd, bd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(nw), dev_bf16(bias)
+    pd = torch.from_numpy(p).to(DEV)
+    xo = torch.full((M, K), 5.0, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(out), ldc=N, norm_w=ptr(nd), bias=ptr(bd), part_in=ptr(pd),
+                x_out=ptr(xo), n_part=1)
+    x_new = bf16_round(x + p[0])
+    np.testing.assert_array_equal(host(xo), x_new)          # one f32 add, one rounding: exact
+    xn = bf16_round(O.rms_norm(x_new, nw, 1e-6, O._Policy("bf16")))
+    assert_close_bf16(host(out), ref_linear(xn, W, bias), what="narrow norm + one partial slab")
 
 
 @pytest.mark.parametrize("M,K,parts", [(8, 1536, True), (8, 1536, False), (16, 3584, True), (3, 256, False), (11, 1536, True),
