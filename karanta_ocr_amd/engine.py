@@ -506,6 +506,7 @@ class Engine:
             self.L.kr_linear_decode_narrow(*head, ptr(W), *tail)
 
     down_waves_small = 16         # waves per down_proj workgroup at <= 16 rows (instance attribute for sweeps)
+    o_waves = 8                   # waves per o_proj workgroup at <= 16 rows
 
     def _down_waves(self, B: int) -> int:
         return self.down_waves_small if B <= 16 else 8   # two batch column tiles double the x fragments: 8-wave workgroups only
@@ -1146,7 +1147,7 @@ class Engine:
                                  ptr(self.d_xacc), self.d_xacc.stride(0), B, t.hidden_size, H, s)
             elif self.attn_fused_merge:
                 if self.narrow_o:
-                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8, **self._w8kw(p + "o.w"))
+                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.o_waves if B <= 16 else 8, **self._w8kw(p + "o.w"))
                 else:
                     self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
             elif self.merge_in_o_proj:
@@ -1155,7 +1156,7 @@ class Engine:
             else:
                 L.kr_attn_decode_merge(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
                 if self.narrow_o:
-                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=8, **self._w8kw(p + "o.w"))
+                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.o_waves if B <= 16 else 8, **self._w8kw(p + "o.w"))
                 else:
                     self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
             if joined is not None:
