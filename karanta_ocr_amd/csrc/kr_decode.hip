@@ -1528,6 +1528,20 @@ inline int narrow_share(const DecLinArgs& a, int waves) {
 template <int EPI, int WAVES>
 int launch_narrow_direct(DecLinArgs& a, int groups, kr_stream s) {
     const int share = narrow_share(a, WAVES);
+    if constexpr (EPI == DEPI_PARTIAL) {
+        // TWO weight tiles per workgroup share one ring of x fragments where there are tiles enough to keep every CU
+        // loading (>= 192: down_proj at 7B widths, 224 tiles -> 112 x 2 workgroups).  A direct-path wave fetches its x
+        // fragment (1-2 KB per K chunk, from L2) with every weight chunk (2 KB): with one tile a third of its loads
+        // move activations, not weights.  Same-process A/B on the 7B decode step: 3.122 -> 2.986 ms (16 waves), 2.950
+        // (8 waves, 5-deep ring) = 62.9 % of the step roofline; at 2B widths (96 tiles -> 48 x 2 workgroups) it starves
+        // the chip: 1.171 -> 1.240 ms.  KARANTA_NARROW_NT2 = 0 / 1 forces either form.
+        const char* e = getenv("KARANTA_NARROW_NT2");
+        const bool nt2 = e ? atoi(e) != 0 : groups >= 192;
+        if (nt2 && (groups & 1) == 0 && a.M <= 16) {
+            if constexpr (WAVES == 16) return launch_narrow_u<2, EPI, WAVES, 0, 0, false, 3>(a, groups / 2, s);
+            else return launch_narrow_u<2, EPI, WAVES, 0, 0, false, 5>(a, groups / 2, s);
+        }
+    }
     if (share <= 3) return launch_narrow_u<1, EPI, WAVES, 0, 0, false, 3>(a, groups, s);
     if constexpr (WAVES == 16) {  // 128-VGPR budget
         return launch_narrow_u<1, EPI, WAVES, 0, 0, false, 5>(a, groups, s);

@@ -353,6 +353,10 @@ class Engine:
         # accumulator with float atomics (a + b onto zero: order-free, reproducible); two accumulators alternate by layer
         # parity, layer L's qkv launch zeroes the one layer L's down_proj adds into.  d_part doubles as the pair.
         self.atomic_slab = os.environ.get("KARANTA_ATOMIC_SLAB", "1") == "1"
+        # down_proj at >= 192 weight tiles (7B widths) runs two tiles per workgroup (kr_decode.hip, launch_narrow_direct):
+        # 8-wave workgroups with a 5-deep ring then beat 16-wave ones (7B step 2.992 -> 2.975 ms)
+        if t.hidden_size // 16 >= 192:
+            self.down_waves_small = 8
         self.d_xacc = z(B, t.hidden_size, dtype=torch.float32)     # fast-residual mode: f32 residual accumulator
         self.d_qkv = z(B, t.qkv_dim)
         self.d_q = z(B, t.num_heads, t.head_dim)

@@ -1132,7 +1132,9 @@ def test_linear_narrow_plain_exact_on_integers(L, M, N, K, waves):
 
 
 @pytest.mark.parametrize("M,N,K,ksplit,waves", [(8, 1536, 8960, 2, 16), (16, 96, 8960, 3, 8), (3, 48, 256, 2, 8),
-                                                (8, 64, 64 * 9, 8, 8), (32, 1536, 8960, 2, 8), (19, 96, 8960, 3, 8)])
+                                                (8, 64, 64 * 9, 8, 8), (32, 1536, 8960, 2, 8), (19, 96, 8960, 3, 8),
+                                                # >= 192 tiles: two tiles per workgroup on one x-fragment ring (7B down_proj)
+                                                (8, 3584, 18944, 2, 8), (13, 3584, 18944, 2, 16), (16, 3072, 1216, 3, 8)])
 def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
     """ksplit > 1 writes f32 slabs [ksplit][M][N]; their sum is the product (exact on integers)."""
     rng = np.random.default_rng(M + N + ksplit)
