@@ -1534,7 +1534,8 @@ int launch_narrow_direct(DecLinArgs& a, int groups, kr_stream s) {
         // fragment (1-2 KB per K chunk, from L2) with every weight chunk (2 KB): with one tile a third of its loads
         // move activations, not weights.  Same-process A/B on the 7B decode step: 3.122 -> 2.986 ms (16 waves), 2.950
         // (8 waves, 5-deep ring) = 62.9 % of the step roofline; at 2B widths (96 tiles -> 48 x 2 workgroups) it starves
-        // the chip: 1.171 -> 1.240 ms.  KARANTA_NARROW_NT2 = 0 / 1 forces either form.
+        // the chip: 1.171 -> 1.240 ms.  KARANTA_NARROW_NT2 = 0 / 1 forces either form.  (o_proj — no K split, so half as
+        // many workgroups — loses with two tiles at both widths: 7B 2.98 -> 3.03 ms, 2B 1.17 -> 1.23.)
         const char* e = getenv("KARANTA_NARROW_NT2");
         const bool nt2 = e ? atoi(e) != 0 : groups >= 192;
         if (nt2 && (groups & 1) == 0 && a.M <= 16) {
