@@ -1538,7 +1538,7 @@ int launch_narrow_direct(DecLinArgs& a, int groups, kr_stream s) {
         // many workgroups — loses with two tiles at both widths: 7B 2.98 -> 3.03 ms, 2B 1.17 -> 1.23.)
         const char* e = getenv("KARANTA_NARROW_NT2");
         const bool nt2 = e ? atoi(e) != 0 : groups >= 192;
-        if (nt2 && (groups & 1) == 0 && a.M <= 16) {
+        if (nt2 && (groups & 1) == 0 && (a.M <= 16 || WAVES == 8)) {   // two batch column tiles: 8-wave workgroups only
             if constexpr (WAVES == 16) return launch_narrow_u<2, EPI, WAVES, 0, 0, false, 3>(a, groups / 2, s);
             else return launch_narrow_u<2, EPI, WAVES, 0, 0, false, 5>(a, groups / 2, s);
         }

@@ -1134,7 +1134,8 @@ def test_linear_narrow_plain_exact_on_integers(L, M, N, K, waves):
 @pytest.mark.parametrize("M,N,K,ksplit,waves", [(8, 1536, 8960, 2, 16), (16, 96, 8960, 3, 8), (3, 48, 256, 2, 8),
                                                 (8, 64, 64 * 9, 8, 8), (32, 1536, 8960, 2, 8), (19, 96, 8960, 3, 8),
                                                 # >= 192 tiles: two tiles per workgroup on one x-fragment ring (7B down_proj)
-                                                (8, 3584, 18944, 2, 8), (13, 3584, 18944, 2, 16), (16, 3072, 1216, 3, 8)])
+                                                (8, 3584, 18944, 2, 8), (13, 3584, 18944, 2, 16), (16, 3072, 1216, 3, 8),
+                                                (27, 3584, 18944, 2, 8), (32, 3072, 640, 2, 8)])   # ... and two batch column tiles
 def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
     """ksplit > 1 writes f32 slabs [ksplit][M][N]; their sum is the product (exact on integers)."""
     rng = np.random.default_rng(M + N + ksplit)
@@ -1152,7 +1153,8 @@ def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
         narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(xd), ldc=N, waves=waves, ksplit=ksplit)
 
 
-@pytest.mark.parametrize("M,N,K,waves", [(8, 1536, 8960, 16), (32, 1536, 8960, 8), (5, 3584, 18944, 16), (16, 96, 256, 8)])
+@pytest.mark.parametrize("M,N,K,waves", [(8, 1536, 8960, 16), (32, 1536, 8960, 8), (5, 3584, 18944, 16), (16, 96, 256, 8),
+                                         (32, 3584, 18944, 8), (8, 3584, 18944, 8)])
 def test_linear_narrow_one_slab_atomic_split(L, M, N, K, waves):
     """kr_decode_slab_next: the two K ranges of a ksplit-2 launch ADD into ONE zeroed f32 slab (float atomics; two addends
     onto zero: the same bits in either order = slab0 + slab1 of the two-slab form), and a launch can carry the zeroing
