@@ -1709,6 +1709,39 @@ def test_graph_capture_and_replay(L):
     L.kr_graph_destroy(g.value)
 
 
+def test_gemm_with_a_long_k_tail_inside_a_stream_capture(L):
+    """The split-K scratch of a GEMM tail is allocated on first use — never while the stream is capturing: on a stream
+    that has no scratch yet the captured launch runs its tail unsplit (no allocation inside the capture), and the replayed
+    graph gives the eager result."""
+    import os
+    stream = torch.cuda.Stream()          # a fresh stream: no scratch for it yet
+    s = stream.cuda_stream
+    M, N, K = 11152, 1536, 4480           # 264 tiles = 1 round + 8; K >= 4096: the eager launch would split the tail along K
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert 0 < (-(-M // 256) * (N // 256)) % cus <= cus // 2
+    rng = np.random.default_rng(11)
+    A, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    Ad, Wd = dev_bf16(A), dev_bf16(W)
+    Cd = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    os.environ["KARANTA_GEMM_TILE"] = "512"
+    try:
+        torch.cuda.synchronize()
+        L.kr_graph_begin_capture(s)
+        L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Cd), N, M, N, K, EPI_NONE, 0, s)
+        g = C.c_void_p()
+        L.kr_graph_end_capture(s, C.byref(g))
+        L.kr_graph_launch(g.value, s)
+        L.kr_stream_synchronize(s)
+        captured = host(Cd)
+        L.kr_graph_destroy(g.value)
+        eager = run_gemm(L, A, W)         # default stream: tail split along K (its own scratch)
+    finally:
+        os.environ.pop("KARANTA_GEMM_TILE", None)
+    assert_close_bf16(captured, eager, what="captured GEMM vs eager")
+    rows = np.r_[0:200, M - 400:M]
+    assert_close_bf16(captured[rows], ref_linear(A[rows], W), what="captured GEMM")
+
+
 def test_events_time_a_kernel(L):
     stream = torch.cuda.Stream()
     s = stream.cuda_stream
