@@ -11,8 +11,14 @@ dev = "cuda:0"
 a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
 w = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
 c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-for tile in (256, 512):
+# launches in this order: 256-tile x3, pipelined m-major x3 (GROUP_M=1), pipelined grouped x3 (default order)
+for tile, group in ((256, None), (512, "1"), (512, None)):
     os.environ["KARANTA_GEMM_TILE"] = str(tile)
+    os.environ["KARANTA_GEMM_TAIL"] = "0"
+    if group is None:
+        os.environ.pop("KARANTA_GEMM_GROUP_M", None)
+    else:
+        os.environ["KARANTA_GEMM_GROUP_M"] = group
     for _ in range(3):
         L.kr_gemm_bf16(ptr(a), K, ptr(w), 0, 0, 0, ptr(c), N, M, N, K, EPI_NONE, 0, 0)
     torch.cuda.synchronize()
