@@ -107,6 +107,17 @@ int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
                  const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc,
                  int64_t M, int N, int K, int epilogue, int w_packed, kr_stream s);
 
+/* kr_gemm_bf16 with a CALLER-OWNED split-K scratch (>= KR_GEMM_SCRATCH_BYTES, 16-byte aligned; NULL = kr_gemm_bf16).
+ * A launch whose last round of 256x256 tiles is at most half full runs that round as 128x128 quarters; with K >= 4096
+ * and a scratch each quarter is also cut along K (partials into the scratch, then a reduce-in-split-order + epilogue
+ * launch; prefill down_proj 353 -> 259 us).  The library allocates nothing and keeps nothing between calls: the same
+ * call with the same scratch argument gives the same bits whatever ran before it, inside a stream capture or not.  The
+ * scratch must not be used by another stream's GEMM at the same time. */
+#define KR_GEMM_SCRATCH_BYTES ((size_t)512 * 65536)
+int kr_gemm_bf16_ws(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
+                    const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc,
+                    int64_t M, int N, int K, int epilogue, int w_packed, float* scratch, size_t scratch_bytes, kr_stream s);
+
 /* kr_gemm_bf16 with weight-only fp8 (BASELINE.json config 5: "fp8 weights, bf16 activations"; SURVEY.md §8(b2)
  * kr_gemm_fp8): W as OCP e4m3fn codes in the decode layout [N/16][K/64][4][16][16] (weights.pack_w16x64_fp8) with one
  * f32 scale per output row, C = epi(A (scale * W)^T + bias) (+ residual).  The codes are converted to bf16 on the way
@@ -274,12 +285,32 @@ int kr_linear_decode_wide(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16
                           kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int blocks, int waves,
                           float* amax_val, int32_t* amax_idx, kr_stream s);
 
+/* Options of one narrow launch (NULL = all zero).  They replace round 2's thread-local one-shot setters
+ * (kr_decode_slab_next / kr_decode_part_rows_next): nothing about a launch is decided by an earlier call.
+ *   atomic_out != 0 : a ksplit == 2 launch ADDS its two K ranges into ONE f32 slab out_f32 [M][ldc] with float atomics
+ *                     instead of writing two slabs (the ONE-slab form of the deferred split-K between a layer's down_proj
+ *                     and the next layer's qkv prologue).  The slab must hold zeros; two addends onto zero give the same
+ *                     bits in either arrival order, so the path stays reproducible.  The consumer passes it as part_in
+ *                     with n_part_in = 1 and reads half the slab bytes in every workgroup's prologue.
+ *   zero_ptr, zero_bytes : the launch also zeroes that f32 range (16-byte aligned, a multiple of 16 bytes): the engine
+ *                     lets layer L's qkv launch zero the slab layer L's down_proj will add into.
+ *   part_rows       : the part_in slabs have `part_rows` rows each ([n_part_in][part_rows][K]) instead of M — the launch
+ *                     covers a row range of a larger batch whose down_proj wrote the slabs (decode batches above 16 rows
+ *                     at the 7B width run the norm-prologue launches once per 16-row range).  0: = M. */
+typedef struct kr_narrow_opts {
+    float* zero_ptr;
+    uint64_t zero_bytes;
+    int32_t atomic_out;
+    int32_t part_rows;
+} kr_narrow_opts;
+
 /* Narrow decode linears (qkv, o_proj, down_proj): one workgroup per 16-row tile (ROPE_KV: per rotary tile
  * pair), K split over its `waves` (8 or 16; the norm prologue always runs 8) waves; x / norm weight / epilogue
  * operands are requested before the weights.  Modes PLAIN and ROPE_KV as kr_linear_decode.
  *   ksplit > 1 (PLAIN only): K is also split over `ksplit` workgroups and the reduction is DEFERRED: out_f32
- *     receives f32 slabs [ksplit][M][ldc] (no bias / residual / norm); the consumer adds them.
- *   part_in (with norm_w): n_part_in (= 2) slabs [n][M][K] f32 are added to x in the prologue,
+ *     receives f32 slabs [ksplit][M][ldc] (no bias / residual / norm) — or, with opts->atomic_out, one slab the
+ *     K ranges add into; the consumer adds them.
+ *   part_in (with norm_w): n_part_in (1 or 2) slabs [n][M][K] f32 are added to x in the prologue,
  *     x_new = bf16(x + sum of slabs) is RMS-normalised and, by workgroup 0, stored to x_out (ldxo), which
  *     must not alias x (other workgroups still read x).  K must be 1536, 2048 or 3584 for this. */
 int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
@@ -288,53 +319,7 @@ int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float
                             kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
                             const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                             kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
-                            kr_stream s);
-
-/* FAST-RESIDUAL MODE (optional; the deterministic path above stays the parity mode).  Three entry points that remove
- * the attention-merge launch from the decode step:
- *   kr_linear_decode_narrow_x32 : kr_linear_decode_narrow (+ w_scale: fp8 codes when non-NULL) whose workgroup 0 ALSO
- *       stores x_new as f32 to x_out_f32 [M, ldxf] — the start value of the residual accumulator;
- *   kr_oproj_heads : o_proj with K split BY ATTENTION HEAD: workgroup (tile group, head) merges that head's split-KV
- *       partials (attn_partials [M][heads][n_split][hd+4] f32, as kr_attn_decode_fused leaves them with out == NULL),
- *       multiplies by W_o[rows, head columns] and adds the product to x_acc [M, ld_acc] f32 with float atomics
- *       (`heads` adders per element; sums in arrival order: low f32 bits vary from run to run);
- *   kr_linear_decode_wide_x32 : kr_linear_decode_wide (SILU8 / ARGMAX) reading its x rows from that f32 accumulator,
- *       rounding them to bf16 once; workgroup 0 stores the rounded rows to x_out [M, ldxo] (may be NULL). */
-int kr_linear_decode_narrow_x32(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
-                                kr_bf16* x_out, int64_t ldxo, float* x_out_f32, int64_t ldxf, const void* w_packed,
-                                const float* w_scale, const kr_bf16* bias, const kr_bf16* norm_w, float norm_eps,
-                                const kr_bf16* residual, int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M,
-                                int N, int K, int waves, int ksplit, const float* cs_table, int cs_stride,
-                                const int32_t* prompt_len, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
-                                kr_bf16* vtcache, int heads, int kv_heads, int s_max, kr_stream s);
-int kr_oproj_heads(const float* attn_partials, int n_split, const void* w_packed, const float* w_scale, float* x_acc,
-                   int64_t ld_acc, int M, int N, int heads, kr_stream s);
-int kr_linear_decode_wide_x32(int mode, const float* x_f32, int64_t ldx, kr_bf16* x_out, int64_t ldxo, const void* w_packed,
-                              const float* w_scale, const kr_bf16* norm_w, float norm_eps, kr_bf16* out, float* out_f32,
-                              int64_t ldc, int M, int N, int K, int blocks, int waves, float* amax_val, int32_t* amax_idx,
-                              kr_stream s);
-
-/* One-shot request, consumed by the next kr_linear_decode_narrow* launch (ksplit 1) issued from this thread: that
- * launch gets `blocks` extra workgroups whose only work is to read [ptr, ptr + bytes) with plain loads, so the range
- * sits in the memory-side Infinity Cache when a later launch streams it (the narrow launches of a decode step occupy
- * 64-96 of the 256 CUs).  bytes == 0 or blocks == 0 cancels. */
-int kr_decode_prefetch_next(const void* ptr, size_t bytes, int blocks);
-
-/* One-shot, consumed by the next kr_linear_decode_narrow* launch of this thread: its part_in slabs have `rows` rows each
- * ([n_part_in][rows][K]) instead of M — the launch covers a row range of a larger batch whose down_proj wrote the slabs
- * (decode batches above 16 rows at hidden sizes whose 32 x rows do not fit the LDS run the norm-prologue launches once
- * per 16-row range).  0 restores the default. */
-int kr_decode_part_rows_next(int rows);
-
-/* One-shot, consumed by the next kr_linear_decode_narrow* launch of this thread (the ONE-slab form of the deferred
- * split-K between a layer's down_proj and the next layer's qkv prologue; VERDICT r1 lever (iii)):
- *   atomic_out != 0 : a ksplit == 2 launch ADDS its two K ranges into ONE f32 slab out_f32 [M][ldc] with float atomics
- *                     instead of writing two slabs.  The slab must hold zeros; two addends onto zero give the same bits in
- *                     either arrival order, so the path stays reproducible.  The consumer passes it as part_in with
- *                     n_part_in = 1 and reads half the slab bytes in every workgroup's prologue.
- *   zero_ptr, zero_bytes : the launch also zeroes that f32 range (multiple of 16 bytes; at most gridsize x 16 bytes):
- *                     the engine lets layer L's qkv launch zero the slab layer L's down_proj will add into. */
-int kr_decode_slab_next(float* zero_ptr, size_t zero_bytes, int atomic_out);
+                            const kr_narrow_opts* opts, kr_stream s);
 
 /* The same two kernels on fp8 (OCP e4m3fn) weights — BASELINE.json config 5: decoder Linears in fp8 with one f32 scale
  * per output row, activations bf16.  w_packed_fp8 = weights.pack_w16x64_fp8 (one 16-row x 64-column block = 1 KiB in
@@ -351,15 +336,17 @@ int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t ldx, const f
                                 int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves,
                                 int ksplit, const float* cs_table, int cs_stride, const int32_t* prompt_len,
                                 const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads,
-                                int kv_heads, int s_max, kr_stream s);
+                                int kv_heads, int s_max, const kr_narrow_opts* opts, kr_stream s);
 /* n fp8 e4m3fn codes -> bf16 through the hardware conversion the kernels use (test hook: pins the number format). */
 int kr_fp8_to_bf16(const uint8_t* src, kr_bf16* dst, int64_t n, kr_stream s);
 
 /* Decode attention (q_len 1, GQA, MFMA, split over n_split key ranges), kcache / vtcache = the
  * layer's base pointers.  workspace: fp32 [batch*heads][n_split][hd+4] partials (o[hd], m, l, 2 pad: 16-byte aligned records).
- * out != NULL: the splits are merged in-launch by the last-arriving workgroup (counters: int32
- * [batch*kv_heads], zero-initialised, left zero) and written as bf16 [batch, heads*hd].
- * out == NULL: only the partials are produced; the consumer merges them (kr_linear_decode). */
+ * out == NULL (the product path): only the partials are produced; kr_attn_decode_merge (or kr_linear_decode's
+ * attn_partials prologue) merges them.  out != NULL with n_split == 1: the single range is written as bf16
+ * [batch, heads*hd].  out != NULL with n_split > 1 — the in-launch merge by the last-arriving workgroup (counters:
+ * int32 [batch*kv_heads], zero-initialised, left zero), measured slower than the merge launch — exists in experiment
+ * builds only (-DKR_EXPERIMENTS, include/karanta_hip_experiments.h) and is refused otherwise. */
 int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache,
                          const int32_t* ctx_len, kr_bf16* out, float* workspace, int32_t* counters,
                          int batch, int heads, int kv_heads, int hd, int s_max, int n_split,
@@ -468,9 +455,6 @@ int kr_selftest_mfma(kr_stream s);
 int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, float* us_per_kernel);
 /* Launches an empty kernel (1 wave): calibrates the cost of a HIP-event bracket around one launch. */
 int kr_launch_null(kr_stream s);
-/* Reads [ptr, ptr+bytes) with `blocks` workgroups of plain 16-byte loads and discards the data:
- * a software prefetch into the 256 MiB memory-side Infinity Cache for a later streaming kernel. */
-int kr_prefetch(const void* ptr, size_t bytes, int blocks, kr_stream s);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,7 @@ SIGNATURES = {
     "kr_layernorm": [c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
     "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p],
+    "kr_gemm_bf16_ws": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p, C.c_size_t, c_p],
     "kr_gemv_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, c_p, f32, c_p],
     "kr_qkv_prep": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p, i64, c_p, i64, c_p, i64,
                     i32, i32, i32, c_p],
@@ -63,7 +64,7 @@ SIGNATURES = {
     "kr_image_normalize_patchify": [c_p, i32, i32, c_p, c_p, i32, i32, i32, c_p, c_p],
     "kr_linear_decode_wide_fp8": [i32, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
     "kr_linear_decode_narrow_fp8": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
-                                    i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
+                                    i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p],
     "kr_fp8_to_bf16": [c_p, c_p, i64, c_p],
     "kr_gemm_fp8": [c_p, i64, c_p, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
     "kr_gumbel_argmax": [c_p, i64, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p],
@@ -72,14 +73,7 @@ SIGNATURES = {
     "kr_guide_advance": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, c_p],
     "kr_logprobs_topk": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_linear_decode_narrow": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
-                                i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
-    "kr_linear_decode_narrow_x32": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
-                                    i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
-    "kr_decode_part_rows_next": [i32],
-    "kr_decode_slab_next": [c_p, C.c_size_t, i32],
-    "kr_decode_prefetch_next": [c_p, C.c_size_t, i32],
-    "kr_oproj_heads": [c_p, i32, c_p, c_p, c_p, i64, i32, i32, i32, c_p],
-    "kr_linear_decode_wide_x32": [i32, c_p, i64, c_p, i64, c_p, c_p, c_p, f32, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
+                                i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
     "kr_attn_decode_merge": [c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
@@ -91,9 +85,32 @@ SIGNATURES = {
     "kr_selftest_mfma": [c_p],
     "kr_probe_launch_floor": [c_p, i32, i32, i32, C.POINTER(f32)],
     "kr_launch_null": [c_p],
-    "kr_prefetch": [c_p, C.c_size_t, i32, c_p],
 }
 _RESTYPES = {"kr_last_error": C.c_char_p}
+
+# include/karanta_hip_experiments.h: exported only by -DKR_EXPERIMENTS builds (csrc/tools/build_variant.py, loaded through
+# KARANTA_HIP_LIB); bound when present, absent from the shipped library
+EXPERIMENT_SIGNATURES = {
+    "kr_linear_decode_narrow_x32": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, i64, c_p, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
+                                    i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p,
+                                    c_p, C.c_size_t, i32, c_p],
+    "kr_oproj_heads": [c_p, i32, c_p, c_p, c_p, i64, i32, i32, i32, c_p],
+    "kr_linear_decode_wide_x32": [i32, c_p, i64, c_p, i64, c_p, c_p, c_p, f32, c_p, c_p, i64, i32, i32, i32, i32, i32, c_p, c_p, c_p],
+    "kr_prefetch": [c_p, C.c_size_t, i32, c_p],
+}
+
+
+class NarrowOpts(C.Structure):
+    """kr_narrow_opts (include/karanta_hip.h): the explicit per-launch options of kr_linear_decode_narrow*."""
+    _fields_ = [("zero_ptr", c_p), ("zero_bytes", C.c_uint64), ("atomic_out", C.c_int32), ("part_rows", C.c_int32)]
+
+
+def narrow_opts(zero_ptr: int = 0, zero_bytes: int = 0, atomic_out: bool = False, part_rows: int = 0):
+    """A kr_narrow_opts* for one launch (0 = NULL when every field is at its default).  The struct is read during the
+    call only, so the temporary may die right after it."""
+    if not (zero_bytes or atomic_out or part_rows):
+        return None
+    return C.byref(NarrowOpts(zero_ptr or None, int(zero_bytes), 1 if atomic_out else 0, int(part_rows)))
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SILU_MUL, EPI_SILU_MUL8 = 0, 1, 2, 3, 4
 DEC_PLAIN, DEC_SILU, DEC_ROPE_KV, DEC_ARGMAX, DEC_SILU8 = 0, 1, 2, 3, 4
@@ -123,6 +140,22 @@ class _Lib:
                 setattr(self, name, fn)
             else:
                 setattr(self, name, self._checked(name, fn))
+        self.experiments = hasattr(self._dll, "kr_oproj_heads")
+        for name, argtypes in EXPERIMENT_SIGNATURES.items():
+            if self.experiments:
+                fn = getattr(self._dll, name)
+                fn.argtypes, fn.restype = argtypes, C.c_int
+                setattr(self, name, self._checked(name, fn))
+            else:
+                setattr(self, name, self._absent(name))
+
+    @staticmethod
+    def _absent(name):
+        def call(*_):
+            raise KarantaHipError(f"{name} is an experiment entry point (include/karanta_hip_experiments.h): this library was built "
+                                  "without -DKR_EXPERIMENTS (csrc/tools/build_variant.py; load it through KARANTA_HIP_LIB)")
+        call.__name__ = name
+        return call
 
     def _checked(self, name, fn):
         def call(*args):

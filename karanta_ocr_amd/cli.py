@@ -33,7 +33,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--served-model-name", default=None)
     ap.add_argument("--max-model-len", type=int, default=16384)
-    ap.add_argument("--max-num-seqs", type=int, default=8, help="decode slots (<= 32; above 16 only for hidden_size <= 2048)")
+    ap.add_argument("--max-num-seqs", type=int, default=8, help="decode slots (<= 32; above 16: hidden_size <= 2048 or == 3584)")
     ap.add_argument("--tensor-parallel-size", type=int, default=1)
     ap.add_argument("--data-parallel-size", type=int, default=1)
     ap.add_argument("--gpu-memory-utilization", type=float, default=None)
@@ -123,7 +123,7 @@ def make_server(args, log=print):
     """Engine + front end + LocalServer from parsed arguments (weights and tokenizer from args.model_dir)."""
     from . import image_processing as IP
     from .engine import Engine
-    from .serving import ChatFrontend, HFTokenizer, LocalServer
+    from .serving import ChatFrontend, HFTokenizer, LocalServer, load_chat_template
     from .weights import load_checkpoint
 
     from .dp import load_or_receive_weights, serving_group_env
@@ -150,9 +150,12 @@ def make_server(args, log=print):
                                    stream=eng.s, log=log)
     if world > 1:
         log(f"weight broadcast: {info['bytes'] / 1e9:.2f} GB in {info['bcast_s']:.3f}s over {info['rccl_ranks']} RCCL ranks")
+    template = load_chat_template(args.model_dir)
+    log("chat template: " + ("the checkpoint's own (chat_template.json / tokenizer_config.json)" if template
+                             else "none shipped with the checkpoint: hand-coded Qwen2-VL template"))
     front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), min_pixels=min_pixels,
                          max_pixels=max_pixels,
-                         max_model_len=args.max_model_len, device_images=not args.host_images)
+                         max_model_len=args.max_model_len, device_images=not args.host_images, chat_template=template)
     return LocalServer(eng, front, served_model_name=args.served_model_name, log=log, continuous=not args.static_batching,
                        max_tokens_cap=min(args.max_tokens_cap, args.max_model_len), honor_temperature=not args.greedy,
                        max_logprobs=args.max_logprobs, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait)

@@ -5,6 +5,9 @@
 #include <stdio.h>
 
 #include "../../include/karanta_hip.h"
+#ifdef KR_EXPERIMENTS
+#include "../../include/karanta_hip_experiments.h"
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

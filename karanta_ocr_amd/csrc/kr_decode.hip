@@ -25,6 +25,17 @@
 
 namespace {
 
+// -DKR_EXPERIMENTS (csrc/tools/build_variant.py): the measured-and-not-adopted decode experiments of rounds 1-2 — Infinity-Cache
+// prefetch workgroups riding on the qkv launch, the fast-residual mode (per-head o_proj with float atomics: dec_oproj_heads_kernel,
+// f32 x rows in the wide / narrow kernels), the in-launch split-KV merge of the attention kernel.  The shipped library holds the
+// product path and the general dec_linear_kernel fallback only; the experiment entry points are declared in
+// include/karanta_hip_experiments.h.
+#ifdef KR_EXPERIMENTS
+constexpr bool KR_EXP = true;
+#else
+constexpr bool KR_EXP = false;
+#endif
+
 constexpr int DEPI_PLAIN = 0, DEPI_SILU = 1, DEPI_ROPE_KV = 2, DEPI_ARGMAX = 3, DEPI_SILU8 = 4;
 
 struct DecLinArgs {
@@ -806,10 +817,10 @@ int launch_wide_x(DecLinArgs& a, int blocks, int waves, kr_stream s) {
 template <int EPI, int NCH, bool W8, int MT>
 int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     if (a.x_is_f32) {
-        if constexpr (EPI == DEPI_SILU8 || EPI == DEPI_ARGMAX) {
+        if constexpr (KR_EXP && (EPI == DEPI_SILU8 || EPI == DEPI_ARGMAX)) {
             return launch_wide_x<EPI, NCH, W8, MT, true>(a, blocks, waves, s);
         } else {
-            kr_set_error("kr_linear_decode_wide: f32 x rows are taken by the SILU8 and ARGMAX modes only");
+            kr_set_error("kr_linear_decode_wide: f32 x rows (experiment builds: SILU8 and ARGMAX modes only)");
             return KR_ERR_ARG;
         }
     }
@@ -1102,7 +1113,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int g = blockIdx.x, ks = blockIdx.y;
-    if (a.pf_blocks > 0 && (int)blockIdx.x >= (int)gridDim.x - a.pf_blocks) {
+    if (KR_EXP && a.pf_blocks > 0 && (int)blockIdx.x >= (int)gridDim.x - a.pf_blocks) {
         // prefetcher workgroup: 16 loads of 16 bytes in flight per lane, results discarded (kept alive by the asm)
         const int pb = blockIdx.x - ((int)gridDim.x - a.pf_blocks);
         const int64_t n16 = a.pf_bytes >> 4, stride = (int64_t)a.pf_blocks * (WAVES * 64);
@@ -1201,8 +1212,10 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
     }
     __builtin_amdgcn_sched_barrier(0);
     if (a.zero_ptr) {   // zero the other split-K accumulator (behind this launch's own requests: plain 16-byte stores)
-        const int zstep = (int)(gridDim.x * gridDim.y) * (WAVES * 64);
-        for (int zi = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (WAVES * 64) + tid; zi < a.zero_n16; zi += zstep)
+        // over the WORKING workgroups only: prefetch workgroups (experiment builds) have returned above
+        const int zgx = (int)gridDim.x - (KR_EXP ? a.pf_blocks : 0);
+        const int zstep = zgx * (int)gridDim.y * (WAVES * 64);
+        for (int zi = ((int)blockIdx.y * zgx + (int)blockIdx.x) * (WAVES * 64) + tid; zi < a.zero_n16; zi += zstep)
             reinterpret_cast<f32x4*>(a.zero_ptr)[zi] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
@@ -1246,7 +1259,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
                 }
             }
         }
-        if (a.x_out_f32 && g == 0 && ks == 0 && wave < M) {   // fast-residual mode: x_new also as the f32 accumulator's start value
+        if (KR_EXP && a.x_out_f32 && g == 0 && ks == 0 && wave < M) {   // fast-residual mode: x_new also as the f32 accumulator's start value
 #pragma unroll
             for (int i = 0; i < RL; ++i) {
                 if (FULL || lane + i * 64 < kc) {
@@ -1282,7 +1295,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
                         for (int j = 0; j < 8; ++j) v[i][j] = f2bf(f[j]);
                         if (g == 0 && ks == 0) *reinterpret_cast<bf16x8*>(a.x_out + (int64_t)b * a.ldxo + c * 8) = v[i];
                     }
-                    if (a.x_out_f32 && g == 0 && ks == 0) {
+                    if (KR_EXP && a.x_out_f32 && g == 0 && ks == 0) {
                         float* xo = a.x_out_f32 + (int64_t)b * a.ldxf + c * 8;
                         *reinterpret_cast<f32x4*>(xo) = (f32x4){bf2f(v[i][0]), bf2f(v[i][1]), bf2f(v[i][2]), bf2f(v[i][3])};
                         *reinterpret_cast<f32x4*>(xo + 4) = (f32x4){bf2f(v[i][4]), bf2f(v[i][5]), bf2f(v[i][6]), bf2f(v[i][7])};
@@ -1582,6 +1595,7 @@ int launch_narrow_norm(DecLinArgs& a, int groups, kr_stream s) {
     return launch_narrow_norm_u<NT, EPI, 0, 0>(a, groups, s);
 }
 
+#ifdef KR_EXPERIMENTS
 // =====================================================================================
 // o_proj split over the attention heads, merge of the split-KV partials in its prologue, float-atomic epilogue
 // =====================================================================================
@@ -1716,6 +1730,7 @@ int launch_oproj_heads(const float* ws, const void* wp, const float* w_scale, fl
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
+#endif  // KR_EXPERIMENTS
 
 // =====================================================================================
 // decode attention with in-launch merge
@@ -1884,7 +1899,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
             if (tid + it * NTHR < nq) store_out(tid + it * NTHR, acc4[it], ll[it]);
         return;
     }
-    if (!out) {  // a later launch (kr_attn_decode_merge / the per-head o_proj prologue) merges the partials: plain stores
+    if (!KR_EXP || !out) {  // a later launch (kr_attn_decode_merge) merges the partials: plain stores
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int t = tid + it * NTHR, d4 = (t & 31) << 2;
@@ -2277,52 +2292,19 @@ extern "C" int kr_linear_decode_wide_fp8(int mode, const kr_bf16* x, int64_t ldx
                      blocks, waves, amax_val, amax_idx, s);
 }
 
-// One-shot request consumed by the NEXT narrow launch of this thread (kr_decode_prefetch_next): the launch gets
-// `blocks` extra workgroups that pull [ptr, ptr + bytes) into the Infinity Cache beside its own work.
-static thread_local const char* g_pf_ptr = nullptr;
-static thread_local int64_t g_pf_bytes = 0;
-static thread_local int g_pf_blocks = 0;
-extern "C" int kr_decode_prefetch_next(const void* ptr_, size_t bytes, int blocks) {
-    KR_CHECK_ARG((ptr_ || bytes == 0) && ((uintptr_t)ptr_ & 15) == 0 && blocks >= 0 && blocks <= 1024, "kr_decode_prefetch_next: bad args");
-    g_pf_ptr = reinterpret_cast<const char*>(ptr_);
-    g_pf_bytes = (int64_t)bytes;
-    g_pf_blocks = bytes >= 16 ? blocks : 0;
-    return KR_OK;
-}
-
-// One-shot: the next narrow launch reads its deferred-split slabs as [n][rows][K] (a launch over a ROW RANGE of a larger
-// batch: the slabs were written for the whole batch).
-static thread_local int g_part_rows = 0;
-extern "C" int kr_decode_part_rows_next(int rows) {
-    KR_CHECK_ARG(rows >= 0 && rows <= 32, "kr_decode_part_rows_next: rows=%d", rows);
-    g_part_rows = rows;
-    return KR_OK;
-}
-
-// One-shot, consumed by the next narrow launch of this thread.  zero_ptr / zero_bytes: the launch also zeroes that f32
-// range (16-byte granules).  atomic_out: a split-K (ksplit > 1) launch ADDS its partial sums into ONE slab out_f32 [M][ldc]
-// with float atomics instead of writing ksplit slabs — with two K ranges onto a zeroed slab the result is the same bits
-// whichever range arrives first (a + b = b + a), so the consumer's prologue reads one slab, not two.
-static thread_local float* g_zero_ptr = nullptr;
-static thread_local int64_t g_zero_bytes = 0;
-static thread_local int g_atomic_out = 0;
-extern "C" int kr_decode_slab_next(float* zero_ptr, size_t zero_bytes, int atomic_out) {
-    KR_CHECK_ARG((zero_ptr || zero_bytes == 0) && ((uintptr_t)zero_ptr & 15) == 0 && (zero_bytes & 15) == 0 && zero_bytes < (1u << 30),
-                 "kr_decode_slab_next: zero range");
-    g_zero_ptr = zero_bytes ? zero_ptr : nullptr;
-    g_zero_bytes = (int64_t)zero_bytes;
-    g_atomic_out = atomic_out ? 1 : 0;
-    return KR_OK;
-}
-
 static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
                                        kr_bf16* x_out, int64_t ldxo, const void* w_packed, const float* w_scale, const kr_bf16* bias,
                                        const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                                        kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
                                        const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                                        kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
-                                       kr_stream s, float* x_out_f32 = nullptr, int64_t ldxf = 0) {
+                                       const kr_narrow_opts* opts, kr_stream s, float* x_out_f32 = nullptr, int64_t ldxf = 0,
+                                       const void* pf_ptr = nullptr, size_t pf_bytes = 0, int pf_blocks = 0) {
     KR_CHECK_ARG(x && w_packed, "kr_linear_decode_narrow: null pointer");
+    const kr_narrow_opts o = opts ? *opts : kr_narrow_opts{};
+    KR_CHECK_ARG((o.zero_ptr || o.zero_bytes == 0) && ((uintptr_t)o.zero_ptr & 15) == 0 && (o.zero_bytes & 15) == 0 && o.zero_bytes < (1u << 30),
+                 "kr_linear_decode_narrow: opts zero range");
+    KR_CHECK_ARG(o.part_rows >= 0 && o.part_rows <= 32, "kr_linear_decode_narrow: opts part_rows=%d", o.part_rows);
     KR_CHECK_ARG(M >= 1 && M <= 32, "kr_linear_decode_narrow: M=%d must be in 1..32", M);
     KR_CHECK_ARG(N > 0 && N % 16 == 0 && K > 0 && K % 64 == 0, "kr_linear_decode_narrow: N=%d K=%d (N%%16, K%%64)", N, K);
     KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0, "kr_linear_decode_narrow: ldx");
@@ -2338,16 +2320,14 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
     a.M = M; a.N = N; a.K = K; a.ksplit = ksplit;
     a.part_in = part_in; a.x_out = x_out; a.ldxo = ldxo;
     a.x_out_f32 = x_out_f32; a.ldxf = ldxf;
-    a.part_rows = g_part_rows;
-    g_part_rows = 0;
+    a.part_rows = o.part_rows;
     a.n_part = part_in ? n_part_in : 0;
-    a.zero_ptr = g_zero_ptr; a.zero_n16 = (int)(g_zero_bytes >> 4); a.part_atomic = g_atomic_out;
-    g_zero_ptr = nullptr; g_zero_bytes = 0; g_atomic_out = 0;
-    KR_CHECK_ARG(!a.part_atomic || (ksplit == 2 && mode == DEPI_PLAIN), "kr_decode_slab_next: atomic slabs are for ksplit 2 (order-free sum)");
+    a.zero_ptr = o.zero_bytes ? o.zero_ptr : nullptr; a.zero_n16 = (int)(o.zero_bytes >> 4); a.part_atomic = o.atomic_out ? 1 : 0;
+    KR_CHECK_ARG(!a.part_atomic || (ksplit == 2 && mode == DEPI_PLAIN), "kr_linear_decode_narrow: atomic_out is for ksplit 2 (order-free sum)");
     KR_CHECK_ARG(a.part_rows == 0 || (part_in && a.part_rows >= M), "kr_linear_decode_narrow: part rows %d < M %d", a.part_rows, M);
-    if (ksplit == 1) {   // a pending prefetch request rides on this launch
-        a.pf_ptr = g_pf_ptr; a.pf_bytes = g_pf_bytes; a.pf_blocks = g_pf_blocks;
-        g_pf_blocks = 0;
+    if (KR_EXP && pf_blocks > 0) {   // experiment builds: prefetch workgroups ride on this launch
+        KR_CHECK_ARG(ksplit == 1 && pf_ptr && ((uintptr_t)pf_ptr & 15) == 0 && pf_blocks <= 1024, "kr_linear_decode_narrow_pf: bad args");
+        a.pf_ptr = reinterpret_cast<const char*>(pf_ptr); a.pf_bytes = (int64_t)pf_bytes; a.pf_blocks = pf_bytes >= 16 ? pf_blocks : 0;
     }
     a.cs_table = cs_table; a.cs_stride = cs_stride; a.prompt_len = prompt_len; a.ctx_len = ctx_len;
     a.q_out = q_out; a.kcache = kcache; a.vtcache = vtcache;
@@ -2384,10 +2364,10 @@ extern "C" int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, 
                                        kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int ksplit,
                                        const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                                        kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
-                                       kr_stream s) {
+                                       const kr_narrow_opts* opts, kr_stream s) {
     return narrow_impl(mode, x, ldx, part_in, n_part_in, x_out, ldxo, w_packed, nullptr, bias, norm_w, norm_eps, residual, ldr, out,
                        out_f32, ldc, M, N, K, waves, ksplit, cs_table, cs_stride, prompt_len, ctx_len, q_out, kcache, vtcache,
-                       heads, kv_heads, s_max, s);
+                       heads, kv_heads, s_max, opts, s);
 }
 
 extern "C" int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in,
@@ -2396,11 +2376,11 @@ extern "C" int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t l
                                            int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves,
                                            int ksplit, const float* cs_table, int cs_stride, const int32_t* prompt_len,
                                            const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads,
-                                           int kv_heads, int s_max, kr_stream s) {
+                                           int kv_heads, int s_max, const kr_narrow_opts* opts, kr_stream s) {
     KR_CHECK_ARG(w_scale, "kr_linear_decode_narrow_fp8: w_scale is NULL");
     return narrow_impl(mode, x, ldx, part_in, n_part_in, x_out, ldxo, w_packed_fp8, w_scale, bias, norm_w, norm_eps, residual, ldr,
                        out, out_f32, ldc, M, N, K, waves, ksplit, cs_table, cs_stride, prompt_len, ctx_len, q_out, kcache, vtcache,
-                       heads, kv_heads, s_max, s);
+                       heads, kv_heads, s_max, opts, s);
 }
 
 extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
@@ -2410,6 +2390,9 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     KR_CHECK_ARG(hd == 128, "kr_attn_decode_fused: hd=%d (only 128)", hd);
     KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_fused: GQA group must be <= 16");
     KR_CHECK_ARG(batch > 0 && n_split > 0 && s_max % 64 == 0, "kr_attn_decode_fused: bad sizes");
+    KR_CHECK_ARG(KR_EXP || !out || n_split == 1,
+                 "kr_attn_decode_fused: the in-launch merge (out != NULL with n_split > 1) is an experiment build (-DKR_EXPERIMENTS); "
+                 "pass out = NULL and run kr_attn_decode_merge");
     KR_CHECK_ARG(!out || n_split <= 16, "kr_attn_decode_fused: the in-launch merge takes at most 16 splits");
     KR_CHECK_ARG(!out || n_split == 1 || (workspace && counters), "kr_attn_decode_fused: split needs workspace + counters");
     KR_CHECK_ARG(workspace || n_split == 1, "kr_attn_decode_fused: the split partials need a workspace");
@@ -2494,7 +2477,8 @@ extern "C" int kr_sample_greedy(const float* amax_val, const int32_t* amax_idx, 
 }
 
 
-// ---- fast-residual mode entry points (see dec_oproj_heads_kernel)
+#ifdef KR_EXPERIMENTS
+// ---- fast-residual mode entry points (see dec_oproj_heads_kernel); include/karanta_hip_experiments.h
 extern "C" int kr_oproj_heads(const float* attn_partials, int n_split, const void* w_packed, const float* w_scale, float* x_acc,
                               int64_t ld_acc, int M, int N, int heads, kr_stream s) {
     KR_CHECK_ARG(attn_partials && w_packed && x_acc, "kr_oproj_heads: null pointer");
@@ -2522,11 +2506,12 @@ extern "C" int kr_linear_decode_narrow_x32(int mode, const kr_bf16* x, int64_t l
                                            const kr_bf16* residual, int64_t ldr, kr_bf16* out, float* out_f32, int64_t ldc, int M,
                                            int N, int K, int waves, int ksplit, const float* cs_table, int cs_stride,
                                            const int32_t* prompt_len, const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache,
-                                           kr_bf16* vtcache, int heads, int kv_heads, int s_max, kr_stream s) {
+                                           kr_bf16* vtcache, int heads, int kv_heads, int s_max, const kr_narrow_opts* opts,
+                                           const void* pf_ptr, size_t pf_bytes, int pf_blocks, kr_stream s) {
     KR_CHECK_ARG(!x_out_f32 || (norm_w && ldxf >= K && (ldxf & 3) == 0), "kr_linear_decode_narrow_x32: x_out_f32 needs the norm prologue");
     return narrow_impl(mode, x, ldx, part_in, n_part_in, x_out, ldxo, w_packed, w_scale, bias, norm_w, norm_eps, residual, ldr, out,
                        out_f32, ldc, M, N, K, waves, ksplit, cs_table, cs_stride, prompt_len, ctx_len, q_out, kcache, vtcache, heads,
-                       kv_heads, s_max, s, x_out_f32, ldxf);
+                       kv_heads, s_max, opts, s, x_out_f32, ldxf, pf_ptr, pf_bytes, pf_blocks);
 }
 
 extern "C" int kr_linear_decode_wide_x32(int mode, const float* x_f32, int64_t ldx, kr_bf16* x_out, int64_t ldxo, const void* w_packed,
@@ -2537,3 +2522,4 @@ extern "C" int kr_linear_decode_wide_x32(int mode, const float* x_f32, int64_t l
     return wide_impl(mode, reinterpret_cast<const kr_bf16*>(x_f32), ldx, w_packed, w_scale, nullptr, norm_w, norm_eps, nullptr, 0, out,
                      out_f32, ldc, M, N, K, blocks, waves, amax_val, amax_idx, s, true, x_out, ldxo);
 }
+#endif  // KR_EXPERIMENTS

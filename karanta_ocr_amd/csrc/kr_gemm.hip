@@ -657,32 +657,18 @@ int launch_gemm3(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16*
     return launch_gemm_kernel<EPI, WPACK, G, 2>((unsigned)nwg, A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, 0, 0u, 0, s);
 }
 
-// Split-K workspace of the tail launches: per (device, stream), allocated on first use (never while the stream is
-// capturing).  nullptr -> the caller runs the tail unsplit.
+// Split-K scratch of the tail launches: CALLER-OWNED (kr_gemm_bf16_ws: 128x128 f32 per partial workgroup, KR_GEMM_SCRATCH_BYTES in
+// all).  The library allocates nothing: a call without scratch (kr_gemm_bf16) runs its tail unsplit, a call with scratch splits
+// it — the same call gives the same bits whatever ran before it, in a stream capture or not (the lazily
+// allocated per-stream scratch made the accumulation order depend on call history).  The scratch of the current entry-point
+// call, valid only while that call is on this thread's stack:
 constexpr int TAIL_MAX_WGS = 512, TAIL_WG_BYTES = 256 * 16 * 16;   // 128x128 f32 per workgroup
-inline float* gemm_tail_workspace(kr_stream s) {
-    struct Slot { int dev; hipStream_t st; bool used; float* ws; };
-    static Slot slots[32] = {};
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto& sl : slots)
-        if (sl.used && sl.dev == dev && sl.st == kr_hs(s)) return sl.ws;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(kr_hs(s), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    for (auto& sl : slots) {
-        if (sl.used) continue;
-        void* a = nullptr;
-        if (hipMalloc(&a, (size_t)TAIL_MAX_WGS * TAIL_WG_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        sl.used = true; sl.dev = dev; sl.st = kr_hs(s); sl.ws = (float*)a;
-        return sl.ws;
-    }
-    return nullptr;
-}
+static_assert((size_t)TAIL_MAX_WGS * TAIL_WG_BYTES == KR_GEMM_SCRATCH_BYTES, "karanta_hip.h: KR_GEMM_SCRATCH_BYTES");
+static thread_local float* t_call_scratch = nullptr;
+struct CallScratch {
+    explicit CallScratch(float* p) { t_call_scratch = p; }
+    ~CallScratch() { t_call_scratch = nullptr; }
+};
 
 // The quarters of the 256x256 tiles [tile0, tile0 + n_tiles) of a launch_gemm_pipe tile list, as 128x128 workgroups; with a
 // long K (>= 4096) and few tail tiles each quarter is cut into K ranges (partials launch + reduce-and-epilogue launch, see
@@ -697,7 +683,7 @@ int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     int ksplit = 1;
     // one round of workgroups (4-deep ring: one per CU), at least 8 K steps each
     if (cap > 1 && K >= 4096) ksplit = std::max(1, std::min(std::min(cap, (K / BK) / 8), (int)(kr_cu_count() / nq)));
-    float* ws = ksplit > 1 ? gemm_tail_workspace(s) : nullptr;
+    float* ws = (ksplit > 1 && nq * (unsigned)ksplit <= (unsigned)TAIL_MAX_WGS) ? t_call_scratch : nullptr;
     if (ws) {
         int rc = launch_gemm_kernel<EPI, WPACK, G128, 4>(nq * ksplit, A, lda, W, bias, R, ldr, C, ldc, M, N, K, 1, ptiles_n, tile0,
                                                          group_m, s, ksplit, 1, ws);
@@ -752,6 +738,16 @@ int launch_gemm(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* 
 }
 
 }  // namespace
+
+extern "C" int kr_gemm_bf16_ws(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
+                               const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K,
+                               int epilogue, int w_packed, float* scratch, size_t scratch_bytes, kr_stream s) {
+    KR_CHECK_ARG(scratch == nullptr || (scratch_bytes >= KR_GEMM_SCRATCH_BYTES && ((uintptr_t)scratch & 15) == 0),
+                 "kr_gemm_bf16_ws: scratch of %zu bytes (KR_GEMM_SCRATCH_BYTES = %zu, 16-byte aligned)", scratch_bytes,
+                 (size_t)KR_GEMM_SCRATCH_BYTES);
+    CallScratch guard(scratch);
+    return kr_gemm_bf16(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, epilogue, w_packed, s);
+}
 
 extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias,
                             const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K,

@@ -136,6 +136,7 @@ extern "C" int kr_launch_null(kr_stream s) {
 // Touch a byte range with plain (allocating) 16-byte loads: pulls it into the memory-side Infinity
 // Cache ahead of the kernels that will stream it.  8 independent loads in flight per lane and iteration, so a few
 // hundred waves reach a useful rate while they run beside the latency-bound launches of the other graph branch.
+#ifdef KR_EXPERIMENTS   // Infinity-Cache prefetch launch (decode experiments of rounds 1-2; include/karanta_hip_experiments.h)
 namespace {
 __global__ void __launch_bounds__(256) prefetch_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
     u32x4 acc = {0u, 0u, 0u, 0u};
@@ -159,6 +160,7 @@ extern "C" int kr_prefetch(const void* ptr_, size_t bytes, int blocks, kr_stream
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
+#endif  // KR_EXPERIMENTS
 
 
 // ---- fp8 e4m3fn -> bf16 through the instruction the decode kernels use (pins the hardware's number format)

@@ -24,11 +24,12 @@ import torch
 from . import image_processing as IP
 from . import positions as POS
 from ._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8,
-                   KarantaHipError, lib, ptr)
+                   KarantaHipError, lib, narrow_opts, ptr)
 from .config import ModelConfig
 from .weights import pack_w16x64, to_bf16_bits
 
 BF16 = torch.bfloat16
+GEMM_SCRATCH_BYTES = 512 * 65536   # include/karanta_hip.h: KR_GEMM_SCRATCH_BYTES
 
 
 def _bits(w: np.ndarray) -> np.ndarray:
@@ -294,6 +295,9 @@ class Engine:
         self._pf_blocks = int(os.environ.get("KARANTA_PREFETCH_BLOCKS", "256"))
         self._pf_stream = None
         self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
+        if not self.L.experiments and (self._prefetch_mode or self._want_fast_residual or os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"):
+            raise KarantaHipError("KARANTA_PREFETCH / KARANTA_FAST_RESIDUAL / KARANTA_ATTN_FUSED are decode experiments: build a library "
+                                  "with -DKR_EXPERIMENTS (csrc/tools/build_variant.py) and load it through KARANTA_HIP_LIB")
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
             raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
@@ -342,6 +346,7 @@ class Engine:
         self.p_cos = z(M, t.head_dim, dtype=torch.float32)
         self.p_sin = z(M, t.head_dim, dtype=torch.float32)
         self.p_src = z(M, dtype=torch.int32)
+        self.gemm_scratch = z(GEMM_SCRATCH_BYTES // 4, dtype=torch.float32)   # kr_gemm_bf16_ws (KR_GEMM_SCRATCH_BYTES)
         # KV cache (zero-initialised: masked keys must be finite)
         self.kcache = z(t.num_layers, B, t.num_kv_heads, self.s_max, t.head_dim)
         self.vtcache = z(t.num_layers, B, t.num_kv_heads, self.s_max // 64, t.head_dim, 64)
@@ -391,7 +396,7 @@ class Engine:
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
         self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
         if self.B > 16 and not (self.wide_mode and self.narrow_mode and self.narrow_o and t.intermediate_size % 64 == 0):
-            raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
+            raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels (hidden_size % 512 == 0) and hidden_size <= 2048 or == 3584")
         # Above 16 rows the decode linears hold two 16-row column tiles per weight fragment, with all 32 normalised x rows
         # in LDS — which fits up to hidden_size 2048 (Qwen2-VL-2B, Qwen2.5-VL-3B).  At the 7B width (32 x 3584 bf16 = 229 KB
         # against 160 KB of LDS) the wide launches (gate/up, lm_head) stage K in two halves (dec_wide_kh_kernel: weights
@@ -399,7 +404,7 @@ class Engine:
         # (33 MB of 14 GB streamed twice); o_proj / down_proj read their x fragments straight from L2 on two column tiles.
         self.row_split = self.B > 16 and t.hidden_size > 2048
         if self.row_split and t.hidden_size != 3584:
-            raise KarantaHipError("max_batch > 16 at hidden_size > 2048 is built for the 7B width (3584)")
+            raise KarantaHipError("max_batch > 16: hidden_size <= 2048 or == 3584 (the 7B width) only")
         self.fast_residual = self.fast_residual and self.wide_mode and not self.row_split
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
@@ -467,8 +472,10 @@ class Engine:
             self.L.kr_gemm_fp8(ptr(A), A.stride(0), ptr(w8), ptr(w_scale), ptr(bias), ptr(res),
                                res.stride(0) if res is not None else 0, ptr(C_), C_.stride(0), M, N, K, epi, self.s)
             return
-        self.L.kr_gemm_bf16(ptr(A), A.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
-                            ptr(C_), C_.stride(0), M, N, K, epi, 1 if packed else 0, self.s)
+        # split-K scratch of long-K tail rounds: the engine's own buffer (its GEMMs never run on two streams at once)
+        self.L.kr_gemm_bf16_ws(ptr(A), A.stride(0), ptr(W), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
+                               ptr(C_), C_.stride(0), M, N, K, epi, 1 if packed else 0, ptr(self.gemm_scratch),
+                               self.gemm_scratch.numel() * 4, self.s)
 
     def _dec(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=4, kc=0, vc=0,
              attn_partials=None):
@@ -484,30 +491,36 @@ class Engine:
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _dec_narrow(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=8, ksplit=1,
-                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, x_out_f32=None, part_rows=0, row0=0):
+                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, x_out_f32=None, part_rows=0, row0=0,
+                    zero=None, atomic_out=False, prefetch=None):
         """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32.
-        w8 / w_scale: the fp8 copy of W and its row scales (kr_linear_decode_narrow_fp8)."""
+        w8 / w_scale: the fp8 copy of W and its row scales (kr_linear_decode_narrow_fp8).  zero (an f32 tensor the launch
+        also zeroes), atomic_out, part_rows: the launch's kr_narrow_opts.  x_out_f32 / prefetch = (address, bytes, blocks):
+        experiment builds only (kr_linear_decode_narrow_x32)."""
         t = self.cfg.text
         N, K = W.shape
         o = out if out is not None else out_f32
         ldc = o.stride(-2) if o is not None else 0  # slabs of the deferred split are [ksplit][M][ldc] with the CURRENT M, packed in d_part
         head = (mode, ptr(x), x.stride(0), ptr(part_in), int(part_in.shape[0]) if part_in is not None else 0, ptr(x_out),
                 x_out.stride(0) if x_out is not None else 0)
+        opts = narrow_opts(ptr(zero) if zero is not None else 0, zero.numel() * 4 if zero is not None else 0, atomic_out, part_rows)
         # row0: the launch covers batch rows row0 .. row0 + M - 1 (every per-sequence array is handed over from that row)
         tail = (ptr(bias), ptr(norm_w), t.rms_norm_eps, ptr(res), res.stride(0) if res is not None else 0, ptr(out),
                 ptr(out_f32), ldc, M, N, K, waves, ksplit, ptr(self.d_cs[row0:]) if self.d_cs is not None else 0, self.max_new,
                 ptr(self.d_plen[row0:]), ptr(self.d_ctx[row0:]), ptr(self.d_q[row0:]),
                 kc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if kc else 0,
-                vc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if vc else 0, t.num_heads, t.num_kv_heads, self.s_max, self.s)
-        if part_rows:
-            self.L.kr_decode_part_rows_next(int(part_rows))
-        if x_out_f32 is not None:    # fast-residual mode: workgroup 0 also stores x_new as the f32 accumulator's start value
-            self.L.kr_linear_decode_narrow_x32(*head, ptr(x_out_f32), x_out_f32.stride(0), ptr(w8 if w8 is not None else W),
-                                               ptr(w_scale), *tail)
+                vc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if vc else 0, t.num_heads, t.num_kv_heads, self.s_max, opts)
+        if x_out_f32 is not None or prefetch is not None:
+            # experiment builds: workgroup 0 also stores x_new as the f32 accumulator's start value (fast-residual mode);
+            # prefetch workgroups ride on the launch
+            pf = prefetch or (0, 0, 0)
+            self.L.kr_linear_decode_narrow_x32(*head, ptr(x_out_f32), x_out_f32.stride(0) if x_out_f32 is not None else 0,
+                                               ptr(w8 if w8 is not None else W), ptr(w_scale), *tail, int(pf[0]), int(pf[1]), int(pf[2]),
+                                               self.s)
         elif w8 is not None:
-            self.L.kr_linear_decode_narrow_fp8(*head, ptr(w8), ptr(w_scale), *tail)
+            self.L.kr_linear_decode_narrow_fp8(*head, ptr(w8), ptr(w_scale), *tail, self.s)
         else:
-            self.L.kr_linear_decode_narrow(*head, ptr(W), *tail)
+            self.L.kr_linear_decode_narrow(*head, ptr(W), *tail, self.s)
 
     down_waves_small = 16         # waves per down_proj workgroup at <= 16 rows (instance attribute for sweeps)
     o_waves = 8                   # waves per o_proj workgroup at <= 16 rows
@@ -1104,37 +1117,40 @@ class Engine:
                 L.kr_event_record(joined, self._pf_stream.cuda_stream)
             fast = self.fast_residual
             xacc = self.d_xacc if fast else None     # qkv's workgroup 0 leaves x_new there as f32; o_proj adds into it
+            pf = None
             if self._prefetch_mode in (4, 5, 6) and self.narrow_mode:
-                # PIGGYBACK PREFETCH: the qkv launch occupies 64 of the 256 CUs; extra workgroups of the same launch pull
-                # this layer's down_proj weights (mode 4), gate/up + down (5) or gate/up (6) into the Infinity Cache
+                # PIGGYBACK PREFETCH (experiment builds): the qkv launch occupies 64 of the 256 CUs; extra workgroups of the
+                # same launch pull this layer's down_proj weights (mode 4), gate/up + down (5) or gate/up (6) into the
+                # Infinity Cache
                 lo = "down.w" if self._prefetch_mode == 4 else "gate_up.w"
                 hi = "gate_up.w" if self._prefetch_mode == 6 else "down.w"
                 sfx = "8" if (self.fp8 and w.has(p + "down.w8")) else ""
                 a0 = w.layout[p + lo + sfx][0]
                 a1 = w.layout[p + hi + sfx][0] + (1 if sfx else 2) * int(np.prod(w.layout[p + hi + sfx][1]))
-                L.kr_decode_prefetch_next(w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks)
+                pf = (w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks)
             if self.narrow_mode:
                 ranges = self._row_ranges(B)
                 slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packs them
                 one_slab = self.atomic_slab and self.defer_down
-                if one_slab and i + 1 < nl:
-                    # this layer's down_proj will ADD into accumulator (i + 1) & 1: this launch zeroes it (it was last read
-                    # by layer i - 1's qkv launch, which is complete)
-                    L.kr_decode_slab_next(ptr(slabs[(i + 1) & 1]), B * t.hidden_size * 4, 0)
+                # this layer's down_proj will ADD into accumulator (i + 1) & 1: the (first) qkv launch zeroes it (it was last
+                # read by layer i - 1's qkv launch, which is complete)
+                zero = slabs[(i + 1) & 1] if (one_slab and i + 1 < nl) else None
                 if pending:
-                    for r0, m in ranges:
+                    for k, (r0, m) in enumerate(ranges):
                         pin = slabs[i & 1:(i & 1) + 1, r0:] if one_slab else slabs[:, r0:]
                         self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
                                          norm_w=w.view(p + "ln1.w"), part_in=pin, x_out=x_other[r0:], kc=kc, vc=vc,
                                          x_out_f32=None if xacc is None else xacc[r0:], part_rows=B if len(ranges) > 1 else 0,
-                                         row0=r0, **self._w8kw(p + "qkv.w"))
+                                         row0=r0, zero=zero if k == 0 else None, prefetch=pf if k == 0 else None,
+                                         **self._w8kw(p + "qkv.w"))
                     x, x_other = x_other, x
                     pending = False
                 else:
-                    for r0, m in ranges:
+                    for k, (r0, m) in enumerate(ranges):
                         self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
                                          norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, x_out_f32=None if xacc is None else xacc[r0:],
-                                         row0=r0, **self._w8kw(p + "qkv.w"))
+                                         row0=r0, zero=zero if k == 0 else None, prefetch=pf if k == 0 else None,
+                                         **self._w8kw(p + "qkv.w"))
             else:
                 self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                           waves=self.wv_qkv, kc=kc, vc=vc)
@@ -1186,9 +1202,8 @@ class Engine:
                 # 2 workgroups per tile; the slabs are added to x by the next layer's qkv prologue
                 if self.atomic_slab:
                     acc = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)[(i + 1) & 1]
-                    L.kr_decode_slab_next(0, 0, 1)
                     self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=acc, waves=self._down_waves(B), ksplit=2,
-                                     **self._w8kw(p + "down.w"))
+                                     atomic_out=True, **self._w8kw(p + "down.w"))
                 else:
                     self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=self._down_waves(B),
                                      ksplit=2, **self._w8kw(p + "down.w"))
@@ -1551,7 +1566,7 @@ class Engine:
     def set_fast_residual(self, on: bool):
         """Switch between the deterministic decode step (split-KV merge launch + slab reductions) and the fast-residual
         one (per-head o_proj with float atomics); captured graphs of the other mode are dropped."""
-        on = bool(on) and self.narrow_mode and self.wide_mode and not self.row_split
+        on = bool(on) and self.narrow_mode and self.wide_mode and not self.row_split and self.L.experiments   # an experiment build only
         if on != self.fast_residual:
             self.stream.synchronize()
             for g in self._graphs.values():

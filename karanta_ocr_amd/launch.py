@@ -175,8 +175,10 @@ def router(ports: Sequence[int], queue_len=None) -> LeastLoadedRouter:
 def start_servers(model: str, gpus: Sequence[int], ports: Sequence[int], extra: Sequence[str] = (), log_dir: str = "./vllm_logs",
                   timeout_s: float = 300.0, poll_s: float = 1.0, server_cmd: Optional[Sequence[str]] = None,
                   log: Callable[[str], None] = print, preflight: bool = True, broadcast: bool = True,
-                  env: Optional[Dict[str, str]] = None) -> ServerGroup:
-    """Start the group and return once every server answers ``/health`` (raises, with everything stopped, otherwise)."""
+                  env: Optional[Dict[str, str]] = None, should_stop: Optional[Callable[[], bool]] = None) -> ServerGroup:
+    """Start the group and return once every server answers ``/health`` (raises, with everything stopped, otherwise).
+    should_stop: polled once per health round; when it turns true (SIGINT / SIGTERM during start-up) the children —
+    which run in their own sessions, so a terminal's Ctrl-C does not reach them — are stopped and InterruptedError raised."""
     gpus, ports = list(gpus), list(ports)
     if len(gpus) != len(ports):
         raise ValueError(f"Number of GPUs ({len(gpus)}) must match number of ports ({len(ports)})")
@@ -217,6 +219,8 @@ def start_servers(model: str, gpus: Sequence[int], ports: Sequence[int], extra: 
                     log(f"[SUCCESS] server on GPU {gpus[i]} (port {ports[i]}) is ready after {time.time() - t0:.0f}s")
             if all(ready):
                 break
+            if should_stop is not None and should_stop():
+                raise InterruptedError("stop requested while the servers were starting")
             if time.time() - t0 > timeout_s:
                 late = [f"GPU {gpus[i]}:{ports[i]}" for i in range(n) if not ready[i]]
                 raise TimeoutError(f"Timeout waiting for {', '.join(late)} after {timeout_s:.0f}s")
@@ -291,7 +295,11 @@ def main(argv: Optional[List[str]] = None) -> int:
             pass
     try:
         group = start_servers(args.model, gpus, ports, passthrough + extra, args.log_dir, args.timeout, log=log,
-                              preflight=not args.no_preflight, broadcast=not args.no_broadcast)
+                              preflight=not args.no_preflight, broadcast=not args.no_broadcast,
+                              should_stop=lambda: stop["now"])
+    except InterruptedError as e:
+        log(f"[INFO] {e}: servers stopped")
+        return 130
     except Exception as e:
         log(f"[ERROR] {e}")
         return 1

@@ -15,8 +15,11 @@ request: caller skips the attempt), 500 (internal error: caller retries).
 ``temperature`` is honoured (0 or absent: greedy — the reference's ``build_page_query`` default, pipeline.py:170;
 ``process_page`` sends 0.1 on its first attempt, :281,:301): Gumbel-max sampling from softmax(logits / T)
 (kr_gumbel_argmax), reproducible through the OpenAI ``seed`` field, a random seed per request otherwise.
-``top_p`` / ``top_k`` are not applied.  Not built yet: ``guided_regex`` /
-``response_format`` constrained decoding, logprobs (accepted, ignored).
+``top_p`` / ``top_k`` are not applied.  ``guided_regex`` / ``response_format`` / ``logprobs``: guided.py, engine.
+
+Prompt text: the checkpoint's own ``chat_template`` when the model directory ships one (``chat_template.json`` /
+``chat_template.jinja`` / ``tokenizer_config.json`` — what vLLM applies, pipeline.py:707-734), rendered with jinja2; the
+hand-coded Qwen2-VL template otherwise.
 """
 from __future__ import annotations
 
@@ -34,6 +37,31 @@ from . import image_processing as IP
 from .config import ModelConfig
 
 DEFAULT_SYSTEM = "You are a helpful assistant."
+
+
+def load_chat_template(model_dir: str) -> Optional[str]:
+    """The checkpoint's chat template, as `transformers` / vLLM look it up: ``chat_template.jinja``, ``chat_template.json``
+    (``{"chat_template": ...}``: the processor's file on Qwen2-VL checkpoints), then ``tokenizer_config.json``'s
+    ``chat_template`` (a string, or a list of ``{"name", "template"}`` whose "default" entry is taken).  None when the
+    directory has none: the caller falls back to the hand-coded Qwen2-VL template."""
+    import os
+    try:
+        with open(os.path.join(model_dir, "chat_template.jinja"), encoding="utf-8") as f:
+            return f.read()
+    except OSError:
+        pass
+    for name in ("chat_template.json", "tokenizer_config.json"):
+        try:
+            with open(os.path.join(model_dir, name), encoding="utf-8") as f:
+                t = json.load(f).get("chat_template")
+        except (OSError, ValueError, AttributeError):
+            continue
+        if isinstance(t, list):
+            named = {e.get("name"): e.get("template") for e in t if isinstance(e, dict)}
+            t = named.get("default") or next(iter(named.values()), None)
+        if isinstance(t, str) and t.strip():
+            return t
+    return None
 
 
 # ----------------------------------------------------------------------------- tokenizers
@@ -112,8 +140,21 @@ class ChatFrontend:
     /root/reference/karanta/data/utils.py:283-297)."""
 
     def __init__(self, cfg: ModelConfig, tokenizer, min_pixels: int = IP.MIN_PIXELS,
-                 max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT, max_model_len: int = 16384, device_images: bool = False):
+                 max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT, max_model_len: int = 16384, device_images: bool = False,
+                 chat_template: Optional[str] = None):
         self.cfg, self.tok = cfg, tokenizer
+        # the checkpoint's own jinja template (load_chat_template); None: the hand-coded Qwen2-VL turns below
+        self._template = None
+        if chat_template:
+            import jinja2
+            from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+            def raise_exception(msg):
+                raise jinja2.exceptions.TemplateError(msg)
+
+            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)   # transformers' settings
+            env.globals["raise_exception"] = raise_exception
+            self._template = env.from_string(chat_template)
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
         # True: only decode the image here; the engine resizes / normalises / patchifies it on the GPU
         # (Engine.patches_from_images, bit-identical to the host path) and 3 bytes per pixel cross PCIe
@@ -142,6 +183,49 @@ class ChatFrontend:
         t = self.tok
         return [t.im_start] + t.encode(role) + [t.newline] + body + [t.im_end, t.newline]
 
+    def _special_ids(self) -> Dict[str, int]:
+        return {"<|im_start|>": self.tok.im_start, "<|im_end|>": self.tok.im_end,
+                "<|vision_start|>": self.cfg.vision_start_token_id, "<|vision_end|>": self.cfg.vision_end_token_id,
+                "<|image_pad|>": self.cfg.image_token_id}
+
+    def _ids_from_template(self, messages: List[dict], n_tok: List[int]) -> List[int]:
+        """Render the checkpoint's template (`add_generation_prompt=True`, as vLLM does for a chat completion) and
+        tokenise it: the special-token strings map to their ids here (so the byte tokenizer of the tests and the HF
+        tokenizer agree), the text between them goes through the tokenizer, and the k-th ``<|image_pad|>`` becomes the
+        k-th image's T placeholders — what the HF processor does to the rendered text
+        (/root/reference/karanta/training/test_trained_model.py:77-87)."""
+        import re
+
+        import jinja2
+        msgs = []
+        for m in messages:
+            c = m.get("content")
+            if isinstance(c, list):   # OpenAI parts -> the shape HF templates test for ('image' in content / type == 'image')
+                c = [({"type": "image", "image": ""} if p.get("type") in ("image_url", "image") else p) for p in c]
+            msgs.append({**m, "content": c})
+        try:
+            text = self._template.render(messages=msgs, add_generation_prompt=True, add_vision_id=False)
+        except jinja2.exceptions.TemplateError as e:
+            raise BadRequest(f"chat template: {e}") from e
+        sp = self._special_ids()
+        ids: List[int] = []
+        k = 0
+        for piece in re.split("(" + "|".join(re.escape(x) for x in sp) + ")", text):
+            if not piece:
+                continue
+            if piece == "<|image_pad|>":
+                if k >= len(n_tok):
+                    raise BadRequest("chat template: more image placeholders than images")
+                ids += [sp[piece]] * n_tok[k]
+                k += 1
+            elif piece in sp:
+                ids.append(sp[piece])
+            else:
+                ids += self.tok.encode(piece)
+        if k != len(n_tok):
+            raise BadRequest(f"chat template rendered {k} image placeholders for {len(n_tok)} images")
+        return ids
+
     def parse(self, req: Dict[str, Any]) -> ParsedRequest:
         if not isinstance(req, dict) or not isinstance(req.get("messages"), list) or not req["messages"]:
             raise BadRequest("`messages` must be a non-empty list")
@@ -150,7 +234,7 @@ class ChatFrontend:
         if max_tokens < 1:
             raise BadRequest("max_tokens must be >= 1")
         ids: List[int] = []
-        pvs, grids, images = [], [], []
+        pvs, grids, images, n_toks = [], [], [], []
         if req["messages"][0].get("role") != "system":
             ids += self._turn("system", self.tok.encode(DEFAULT_SYSTEM))
         for msg in req["messages"]:
@@ -185,11 +269,14 @@ class ChatFrontend:
                         pvs.append(pv)
                     grids.append(grid)
                     n_tok = grid[0] * grid[1] * grid[2] // (self.cfg.vision.spatial_merge_size ** 2)
+                    n_toks.append(n_tok)
                     body += [self.cfg.vision_start_token_id] + [self.cfg.image_token_id] * n_tok + [self.cfg.vision_end_token_id]
                 else:
                     raise BadRequest(f"unsupported content part {kind!r}")
             ids += self._turn(role, body)
         ids += [self.tok.im_start] + self.tok.encode("assistant") + [self.tok.newline]
+        if self._template is not None:      # the checkpoint's own template replaces the hand-coded turns
+            ids = self._ids_from_template(req["messages"], n_toks)
         if len(ids) + max_tokens > self.max_model_len:
             raise BadRequest(f"prompt ({len(ids)} tokens) + max_tokens ({max_tokens}) exceeds max_model_len {self.max_model_len}")
         try:

@@ -103,7 +103,25 @@ def weight_shapes(cfg: ModelConfig) -> Dict[str, tuple]:
     return s
 
 
-def random_weights(cfg: ModelConfig, seed: int = 0, as_bits: bool = False) -> Dict[str, np.ndarray]:
+def _random_tensor(shapes, seed: int, idx: int, as_bits: bool) -> np.ndarray:
+    name, shape = shapes[idx]
+    rng = np.random.default_rng([seed, idx])
+    n = int(np.prod(shape))
+    if name.endswith("bias"):
+        w = rng.standard_normal(n, dtype=np.float32) * np.float32(0.02)
+    elif len(shape) == 1:
+        w = np.float32(1.0) + rng.standard_normal(n, dtype=np.float32) * np.float32(0.1)
+    elif "embed_tokens" in name:
+        w = rng.standard_normal(n, dtype=np.float32) * np.float32(0.5)
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        w = rng.standard_normal(n, dtype=np.float32) * np.float32(1.0 / np.sqrt(fan_in))
+    w = w.reshape(shape)
+    return to_bf16_bits(w) if as_bits else bf16_round(w)
+
+
+def random_weights(cfg: ModelConfig, seed: int = 0, as_bits: bool = False, threads: Optional[int] = None,
+                   only: Optional[Iterable[str]] = None) -> Dict[str, np.ndarray]:
     """Seeded random-init weights, every value exactly representable in bf16.
 
     One ``np.random.default_rng([seed, index])`` stream per tensor (PCG64: stable across
@@ -112,24 +130,29 @@ def random_weights(cfg: ModelConfig, seed: int = 0, as_bits: bool = False) -> Di
 
     Matrices ~ N(0, 1/sqrt(fan_in)); norm weights 1 + N(0, 0.1); biases N(0, 0.02).
     With ``as_bits`` the tensors are returned as bf16 bit patterns (uint16) — half
-    the host memory for the full-size bench models.
+    the host memory for the full-size bench models.  The tensors are independent streams, so they
+    are drawn on a few host threads (numpy's generators release the GIL): same bits, a fraction of
+    the wall time for the 2B / 7B bench models.  ``only``: just these tensors (the same bits they have in the full set).
     """
-    out: Dict[str, np.ndarray] = {}
-    for idx, (name, shape) in enumerate(weight_shapes(cfg).items()):
-        rng = np.random.default_rng([seed, idx])
-        n = int(np.prod(shape))
-        if name.endswith("bias"):
-            w = rng.standard_normal(n, dtype=np.float32) * np.float32(0.02)
-        elif len(shape) == 1:
-            w = np.float32(1.0) + rng.standard_normal(n, dtype=np.float32) * np.float32(0.1)
-        elif "embed_tokens" in name:
-            w = rng.standard_normal(n, dtype=np.float32) * np.float32(0.5)
-        else:
-            fan_in = int(np.prod(shape[1:]))
-            w = rng.standard_normal(n, dtype=np.float32) * np.float32(1.0 / np.sqrt(fan_in))
-        w = w.reshape(shape)
-        out[name] = to_bf16_bits(w) if as_bits else bf16_round(w)
-    return out
+    shapes = list(weight_shapes(cfg).items())
+    if only is not None:
+        want = set(only)
+        return {shapes[i][0]: _random_tensor(shapes, seed, i, as_bits) for i in range(len(shapes)) if shapes[i][0] in want}
+
+    def one(idx: int) -> np.ndarray:
+        return _random_tensor(shapes, seed, idx, as_bits)
+
+    total = sum(int(np.prod(sh)) for _, sh in shapes)
+    if threads is None:
+        threads = min(8, os.cpu_count() or 1) if total > (1 << 26) else 1
+    if threads <= 1:
+        return {shapes[i][0]: one(i) for i in range(len(shapes))}
+    from concurrent.futures import ThreadPoolExecutor
+    # largest first, so the big embedding / lm_head tensors do not end up alone at the tail
+    order = sorted(range(len(shapes)), key=lambda i: -int(np.prod(shapes[i][1])))
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        done = dict(zip(order, ex.map(one, order)))
+    return {shapes[i][0]: done[i] for i in range(len(shapes))}
 
 
 # ----------------------------------------------------------------------------- checkpoints

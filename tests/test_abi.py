@@ -42,6 +42,33 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(dll, name), f"{name} declared in the header but not exported"
 
 
+def experiment_prototypes():
+    src = open(os.path.join(ROOT, "include", "karanta_hip_experiments.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+            for m in re.finditer(r"^int\s+(kr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.M | re.S)}
+
+
+def test_shipped_library_holds_the_product_path_only(built_lib):
+    """the measured-and-not-adopted decode experiments (Infinity-Cache prefetch, fast-residual mode,
+    in-launch attention merge) live behind -DKR_EXPERIMENTS with their own header; the shipped .so exports none of them,
+    no thread-local one-shot setter is left in the ABI, and every exported kr_* symbol is declared in karanta_hip.h."""
+    import subprocess
+    from karanta_ocr_amd._lib import EXPERIMENT_SIGNATURES
+    dll = ctypes.CDLL(built_lib)
+    exp = experiment_prototypes()
+    assert set(exp) == set(EXPERIMENT_SIGNATURES) and exp
+    for name, n in exp.items():
+        assert not hasattr(dll, name), f"{name} is an experiment entry point but the shipped library exports it"
+        assert len(EXPERIMENT_SIGNATURES[name]) == n, name
+    protos = header_prototypes()
+    for gone in ("kr_decode_slab_next", "kr_decode_part_rows_next", "kr_decode_prefetch_next"):
+        assert gone not in protos and not hasattr(dll, gone)
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("kr_")}
+    assert exported == set(protos), (sorted(exported - set(protos)), sorted(set(protos) - exported))
+
+
 def test_ctypes_signatures_match_header_arity(built_lib):
     from karanta_ocr_amd._lib import SIGNATURES
 

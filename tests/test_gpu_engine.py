@@ -552,47 +552,3 @@ def test_server_guided_json_and_logprobs(engines, tiny_models):
     c2 = out["static"][2][1]["choices"][0]
     assert len(c2["logprobs"]["content"]) == 4 and all(i["top_logprobs"] == [] for i in c2["logprobs"]["content"])
     eng.close()
-
-
-@pytest.mark.gpu
-def test_full_size_qwen2_vl_2b_properties():
-    """BASELINE.json's own model and page size (Qwen2-VL-2B widths, 28 layers, 1024x1024 scans -> 70x70 patches, 1225
-    image tokens; seeded random weights): no oracle finishes at this size, so the size-independent properties carry the
-    check — a page's tokens in a ragged batch equal its solo run (ViT segments, the 256x256 / 128x128 GEMM tile choice
-    that changes with M, prefill, split-KV decode: all batch-independent by construction), the eager decode loop equals
-    the replayed graph, and the slot scheduler (other slots, other history) reproduces them once more."""
-    from karanta_ocr_amd.config import CONFIGS
-    from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
-    from karanta_ocr_amd.weights import random_weights
-    cfg = CONFIGS["Qwen2-VL-2B"]
-    rng = np.random.default_rng(31)
-    pages = []
-    for i, (h, wd) in enumerate([(1024, 1024), (1024, 1024), (700, 1000)]):
-        pv, grid = IP.image_to_patches(IP.synthetic_page(200 + i, h, wd), max_pixels=1003520)
-        T = grid[1] * grid[2] // 4
-        ids = np.concatenate([rng.integers(0, 150000, 20 + 7 * i), [cfg.vision_start_token_id], [cfg.image_token_id] * T,
-                              [cfg.vision_end_token_id], rng.integers(0, 150000, 30)]).astype(np.int64)
-        pages.append(PageRequest(ids, pv, [grid]))
-    assert pages[0].grids[0] == (1, 70, 70)
-    steps = 24
-    eng = Engine(cfg, max_batch=3, s_max=1536, max_patches=sum(len(p.pixel_values) for p in pages),
-                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=16)
-    eng.load_weights(random_weights(cfg, 0, as_bits=True))
-    try:
-        together = eng.generate(pages, steps, ignore_eos=True)
-        for t in together.tokens:
-            assert len(t) == steps and t.min() >= 0 and t.max() < cfg.text.vocab_size
-        assert not np.array_equal(together.tokens[0], together.tokens[1]), "different scans, different text"
-        for i, pg in enumerate(pages):
-            alone = eng.generate([pg], steps, ignore_eos=True)
-            np.testing.assert_array_equal(alone.tokens[0], together.tokens[i], err_msg=f"page {i}: batch vs solo")
-        eager = eng.generate(pages[:2], steps, ignore_eos=True, use_graph=False)
-        for i in range(2):
-            np.testing.assert_array_equal(eager.tokens[i], together.tokens[i], err_msg=f"page {i}: eager vs graph")
-        sch = SlotScheduler(eng, max_tokens_cap=steps, chunk=5, eos_token_ids=())
-        res = sch.run([SlotRequest(pg, steps, tag=i) for i, pg in enumerate(pages[::-1])])
-        for r, want in zip(res, together.tokens[::-1]):
-            assert r.error is None
-            np.testing.assert_array_equal(r.tokens[:steps], want[:len(r.tokens[:steps])])
-    finally:
-        eng.close()

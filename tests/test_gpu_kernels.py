@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from karanta_ocr_amd import positions as POS  # noqa: E402
 from karanta_ocr_amd._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU, DEC_SILU8, EPI_GELU_ERF, EPI_NONE,  # noqa: E402
-                                  EPI_QUICK_GELU, EPI_SILU_MUL, EPI_SILU_MUL8, KarantaHipError, lib, ptr)
+                                  EPI_QUICK_GELU, EPI_SILU_MUL, EPI_SILU_MUL8, KarantaHipError, lib, narrow_opts, ptr)
 from karanta_ocr_amd.weights import bf16_round, pack_w16x64  # noqa: E402
 from oracle import qwen2vl_oracle as O  # noqa: E402
 
@@ -182,6 +182,9 @@ def ref_linear(A, W, bias=None, res=None, epi=EPI_NONE):
     return acc.astype(np.float32)
 
 
+_GEMM_SCRATCH = None
+
+
 def run_gemm(L, A, W, bias=None, res=None, epi=EPI_NONE, lda_pad=0, packed=False):
     M, K = A.shape
     N = W.shape[0]
@@ -191,8 +194,12 @@ def run_gemm(L, A, W, bias=None, res=None, epi=EPI_NONE, lda_pad=0, packed=False
     Cd = torch.full((M, nc), 9.0, dtype=torch.bfloat16, device=DEV)
     bd = dev_bf16(bias) if bias is not None else None
     rd = dev_bf16(res) if res is not None else None
-    L.kr_gemm_bf16(ptr(Ad), K + lda_pad, ptr(Wd), ptr(bd), ptr(rd), nc if res is not None else 0, ptr(Cd), nc, M, N, K,
-                   epi, 1 if packed else 0, 0)
+    # with the caller-owned split-K scratch (kr_gemm_bf16_ws), as the engine calls it: long-K tail rounds are cut along K
+    global _GEMM_SCRATCH
+    if _GEMM_SCRATCH is None:
+        _GEMM_SCRATCH = torch.zeros(512 * 65536 // 4, dtype=torch.float32, device=DEV)
+    L.kr_gemm_bf16_ws(ptr(Ad), K + lda_pad, ptr(Wd), ptr(bd), ptr(rd), nc if res is not None else 0, ptr(Cd), nc, M, N, K,
+                      epi, 1 if packed else 0, ptr(_GEMM_SCRATCH), _GEMM_SCRATCH.numel() * 4, 0)
     return host(Cd)
 
 
@@ -604,6 +611,13 @@ def test_prefill_attention_hd128_page_sized_prompt(L):
     run_prep_attn(L, [1394, 77], H=12, KVH=2, hd=128, causal=True, seed=1394, as_cache=True, s_max=1408)
 
 
+def test_prefill_attention_hd128_config5_prompt(L):
+    """BASELINE.json config 5's prompt: a 1700x2200 scan at max_pixels 12 845 056 is 4819 image tokens, 4988 with the
+    chat template around it — 78 causal KV tiles per query block, the 7B model's GQA group of 7 (14 q / 2 kv heads here),
+    cache rows of the length that config decodes into (4988 + 128 -> 5184)."""
+    run_prep_attn(L, [4988], H=14, KVH=2, hd=128, causal=True, seed=4988, as_cache=True, s_max=5184)
+
+
 @pytest.mark.parametrize("q_block", [128, 256])
 @pytest.mark.parametrize("lens", [[36], [130, 5, 200], [257]])
 @pytest.mark.parametrize("H,KVH", [(2, 1), (6, 2), (3, 3)])
@@ -644,10 +658,11 @@ def test_attention_online_softmax_rescale_branch(L):
 
 # ----------------------------------------------------------------------------- decode path
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4), (3, 1)])
-@pytest.mark.parametrize("ctxs", [[0, 5, 63], [64, 100, 700], [1, 1279, 2047], [2431, 1393, 2559]])
+@pytest.mark.parametrize("ctxs", [[0, 5, 63], [64, 100, 700], [1, 1279, 2047], [2431, 1393, 2559], [4988, 5116, 5183]])
 def test_decode_prep_and_attention(L, H, KVH, ctxs):
     rng = np.random.default_rng(H * 100 + sum(ctxs))
-    # contexts up to the bench's last step (P = 1394, T_out = 1024 -> 2417 cached tokens) and past it
+    # contexts up to the bench's last step (P = 1394, T_out = 1024 -> 2417 cached tokens) and past it; the last case is
+    # BASELINE config 5's decode range (a 4988-token prompt + 128 tokens) up to the last row of a 5184-row cache
     hd, s_max, B, n_split = 128, max(2048, (max(ctxs) + 64) // 64 * 64), len(ctxs), 4
     kc = np.zeros((B, KVH, s_max, hd), np.float32)
     vc = np.zeros((B, KVH, s_max, hd), np.float32)
@@ -1099,10 +1114,10 @@ def test_linear_wide_rejects_bad_shapes(L):
 
 def narrow_call(L, mode, x, W, M, N, K, out=0, out_f32=0, ldc=0, bias=0, norm_w=0, res=0, ldr=0, waves=8, ksplit=1,
                 part_in=0, x_out=0, cs=0, cs_stride=0, plen=0, ctx=0, q_out=0, kc=0, vc=0, heads=0, kv_heads=0, s_max=64,
-                n_part=2):
+                n_part=2, opts=None):
     L.kr_linear_decode_narrow(mode, x, K, part_in, n_part if part_in else 0, x_out, K, W, bias, norm_w, 1e-6, res, ldr, out,
                               out_f32, ldc, M, N, K, waves, ksplit, cs, cs_stride, plen, ctx, q_out, kc, vc, heads,
-                              kv_heads, s_max, 0)
+                              kv_heads, s_max, opts, 0)
 
 
 @pytest.mark.parametrize("M", [1, 8, 16, 23, 32])
@@ -1156,20 +1171,21 @@ def test_linear_narrow_deferred_splitk_slabs(L, M, N, K, ksplit, waves):
 @pytest.mark.parametrize("M,N,K,waves", [(8, 1536, 8960, 16), (32, 1536, 8960, 8), (5, 3584, 18944, 16), (16, 96, 256, 8),
                                          (32, 3584, 18944, 8), (8, 3584, 18944, 8)])
 def test_linear_narrow_one_slab_atomic_split(L, M, N, K, waves):
-    """kr_decode_slab_next: the two K ranges of a ksplit-2 launch ADD into ONE zeroed f32 slab (float atomics; two addends
-    onto zero: the same bits in either order = slab0 + slab1 of the two-slab form), and a launch can carry the zeroing
-    of another range.  Exact on integers, identical run to run, equal to the sum of the two-slab launch on real data."""
+    """kr_narrow_opts.atomic_out: the two K ranges of a ksplit-2 launch ADD into ONE zeroed f32 slab (float atomics; two
+    addends onto zero: the same bits in either order = slab0 + slab1 of the two-slab form), and a launch can carry the
+    zeroing of another range (zero_ptr / zero_bytes).  Exact on integers, identical run to run, equal to the sum of the
+    two-slab launch on real data.  The options are arguments of ONE launch: the next launch without them writes two slabs."""
     rng = np.random.default_rng(M + N + K)
     x, W = ints(rng, M, K), ints(rng, N, K)
     xd, Wd = dev_bf16(x), dev_bf16(pack_w16x64(W))
     acc = torch.zeros(M, N, dtype=torch.float32, device=DEV)
     other = torch.full((M * N + 8,), 3.0, dtype=torch.float32, device=DEV)     # the range this launch is asked to zero
-    L.kr_decode_slab_next(ptr(other), M * N * 4, 1)
-    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=waves, ksplit=2)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=waves, ksplit=2,
+                opts=narrow_opts(ptr(other), M * N * 4, True))
     np.testing.assert_array_equal(acc.cpu().numpy(), ref_linear(x, W))
     oc = other.cpu().numpy()
     assert not oc[:M * N].any() and (oc[M * N:] == 3.0).all(), "zeroing job: exactly the requested range"
-    # the one-shot is consumed: the next launch writes two slabs again and zeroes nothing
+    # no hidden state: the next launch (no options) writes two slabs again and zeroes nothing
     slabs = torch.full((2, M, N), 7.0, dtype=torch.float32, device=DEV)
     narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(slabs), ldc=N, waves=waves, ksplit=2)
     np.testing.assert_array_equal(slabs.cpu().numpy().sum(0), ref_linear(x, W))
@@ -1180,12 +1196,18 @@ def test_linear_narrow_one_slab_atomic_split(L, M, N, K, waves):
     two = slabs.cpu().numpy()
     for _ in range(3):
         acc.zero_()
-        L.kr_decode_slab_next(0, 0, 1)
-        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=waves, ksplit=2)
+        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=waves, ksplit=2,
+                    opts=narrow_opts(atomic_out=True))
         np.testing.assert_array_equal(acc.cpu().numpy(), two[0] + two[1])
     with pytest.raises(KarantaHipError):       # three addends would make the sum order-dependent: refused
-        L.kr_decode_slab_next(0, 0, 1)
-        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=8, ksplit=3)
+        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=8, ksplit=3, opts=narrow_opts(atomic_out=True))
+    with pytest.raises(KarantaHipError):       # a failed launch leaves nothing armed: the next plain launch is plain
+        narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(acc), ldc=N, waves=5, ksplit=2,
+                    opts=narrow_opts(ptr(other), M * N * 4, True))
+    other.fill_(3.0)
+    narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out_f32=ptr(slabs), ldc=N, waves=waves, ksplit=2)
+    assert (other.cpu().numpy() == 3.0).all()
+    np.testing.assert_array_equal(slabs.cpu().numpy(), two)
 
 
 @pytest.mark.parametrize("M,K", [(8, 1536), (16, 3584), (32, 1536), (27, 2048)])
@@ -1238,7 +1260,7 @@ def test_linear_narrow_partials_reject_unsupported_k(L):
         narrow_call(L, DEC_PLAIN, ptr(x), ptr(x), 8, 16, 256, out=ptr(x), ldc=16, norm_w=ptr(x), part_in=ptr(p), x_out=ptr(p))
     with pytest.raises(KarantaHipError):   # x_out must not alias x
         L.kr_linear_decode_narrow(DEC_PLAIN, ptr(x), 256, ptr(p), 2, ptr(x), 256, ptr(x), 0, ptr(x), 1e-6, 0, 0, ptr(x), 0, 16,
-                                  8, 16, 256, 8, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+                                  8, 16, 256, 8, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, None, 0)
 
 
 @pytest.mark.parametrize("H,KVH,K,parts", [(2, 1, 1024, False), (12, 2, 1536, True), (3, 1, 1536, False), (28, 4, 3584, True),
@@ -1403,12 +1425,12 @@ def test_linear_narrow_fp8_plain_and_slabs(L, M, N, K, waves, ksplit):
     if ksplit > 1:
         slabs = torch.zeros(ksplit, M, N, dtype=torch.float32, device=DEV)
         L.kr_linear_decode_narrow_fp8(DEC_PLAIN, ptr(xd), K, 0, 0, 0, 0, ptr(qd), ptr(sd), 0, 0, 1e-6, 0, 0, 0, ptr(slabs), N, M, N, K,
-                                      waves, ksplit, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+                                      waves, ksplit, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, None, 0)
         got = slabs.sum(0).cpu().numpy()
     else:
         out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
         L.kr_linear_decode_narrow_fp8(DEC_PLAIN, ptr(xd), K, 0, 0, 0, 0, ptr(qd), ptr(sd), 0, 0, 1e-6, 0, 0, 0, ptr(out), N, M, N, K,
-                                      waves, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+                                      waves, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, None, 0)
         got = out.cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
 
@@ -1628,12 +1650,14 @@ def test_attn_partials_merged_by_o_proj_prologue(L, H, KVH, n_split):
 
 @pytest.mark.parametrize("H,KVH", [(12, 2), (28, 4), (3, 1)])
 @pytest.mark.parametrize("n_split", [8, 16, 32])
-def test_attn_decode_partials_then_merge_launch(L, H, KVH, n_split):
+@pytest.mark.parametrize("config5", [False, True])
+def test_attn_decode_partials_then_merge_launch(L, H, KVH, n_split, config5):
     """The engine's deterministic path: split-KV partials (8 splits x 8 waves, 16 x 4, 32 x 2 workgroup shapes) and the
-    merge launch, at the contexts of the bench's decode loop."""
+    merge launch, at the contexts of the bench's decode loop; config5: at the contexts BASELINE config 5 decodes at (a
+    4988-token prompt, then 128 tokens: ctx 4988 .. 5116) up to the last row of its 5184-row cache."""
     rng = np.random.default_rng(H * 10 + n_split + 7)
-    hd, s_max = 128, 2560
-    ctxs = [0, 31, 32, 1393, 1906, 2431, 2559]
+    hd, s_max = 128, 5184 if config5 else 2560
+    ctxs = [63, 4987, 4988, 5052, 5116, 5183] if config5 else [0, 31, 32, 1393, 1906, 2431, 2559]
     B = len(ctxs)
     kc = np.zeros((B, KVH, s_max, hd), np.float32); vc = np.zeros((B, KVH, s_max, hd), np.float32)
     for b, c in enumerate(ctxs):
@@ -1673,6 +1697,12 @@ def test_attn_decode_fused(L, H, KVH, n_split, long_ctx):
     ws = torch.zeros(B * H * n_split * (hd + 4), dtype=torch.float32, device=DEV)
     cnt = torch.zeros(B * KVH, dtype=torch.int32, device=DEV)
     o_d = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
+    if n_split > 1 and not L.experiments:
+        # the in-launch merge is an experiment (measured slower than the merge launch): the shipped library refuses it
+        with pytest.raises(KarantaHipError, match="KR_EXPERIMENTS"):
+            L.kr_attn_decode_fused(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), ptr(o_d), ptr(ws), ptr(cnt), B, H, KVH, hd, s_max,
+                                   n_split, hd ** -0.5, 0)
+        return
     for _ in range(2):
         L.kr_attn_decode_fused(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), ptr(o_d), ptr(ws), ptr(cnt), B, H, KVH, hd, s_max,
                                n_split, hd ** -0.5, 0)
@@ -1710,36 +1740,60 @@ def test_graph_capture_and_replay(L):
 
 
 def test_gemm_with_a_long_k_tail_inside_a_stream_capture(L):
-    """The split-K scratch of a GEMM tail is allocated on first use — never while the stream is capturing: on a stream
-    that has no scratch yet the captured launch runs its tail unsplit (no allocation inside the capture), and the replayed
-    graph gives the eager result."""
+    """The split-K scratch of a GEMM tail is the CALLER's (kr_gemm_bf16_ws; ADVICE r2: a scratch the library allocated on
+    first use made the accumulation order depend on whether the stream's first GEMM ran inside a capture).  The library
+    allocates nothing: with the scratch a captured launch gives the eager launch's bits EXACTLY, on a fresh stream too;
+    without it the tail runs unsplit (another summation order, same tolerance), captured or not."""
     import os
-    stream = torch.cuda.Stream()          # a fresh stream: no scratch for it yet
+    stream = torch.cuda.Stream()          # a fresh stream
     s = stream.cuda_stream
-    M, N, K = 11152, 1536, 4480           # 264 tiles = 1 round + 8; K >= 4096: the eager launch would split the tail along K
+    M, N, K = 11152, 1536, 4480           # 264 tiles = 1 round + 8; K >= 4096: with a scratch the tail is split along K
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     assert 0 < (-(-M // 256) * (N // 256)) % cus <= cus // 2
     rng = np.random.default_rng(11)
     A, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
     Ad, Wd = dev_bf16(A), dev_bf16(W)
-    Cd = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    scratch = torch.zeros(512 * 65536 // 4, dtype=torch.float32, device=DEV)
+
+    def gemm(ws, stream_):
+        Cd = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        torch.cuda.synchronize()
+        if ws:
+            L.kr_gemm_bf16_ws(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Cd), N, M, N, K, EPI_NONE, 0, ptr(scratch), scratch.numel() * 4, stream_)
+        else:
+            L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Cd), N, M, N, K, EPI_NONE, 0, stream_)
+        return Cd
+
     os.environ["KARANTA_GEMM_TILE"] = "512"
     try:
-        torch.cuda.synchronize()
-        L.kr_graph_begin_capture(s)
-        L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Cd), N, M, N, K, EPI_NONE, 0, s)
-        g = C.c_void_p()
-        L.kr_graph_end_capture(s, C.byref(g))
-        L.kr_graph_launch(g.value, s)
-        L.kr_stream_synchronize(s)
-        captured = host(Cd)
-        L.kr_graph_destroy(g.value)
-        eager = run_gemm(L, A, W)         # default stream: tail split along K (its own scratch)
+        out = {}
+        for ws in (True, False):
+            Cd = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+            torch.cuda.synchronize()
+            L.kr_graph_begin_capture(s)
+            if ws:
+                L.kr_gemm_bf16_ws(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Cd), N, M, N, K, EPI_NONE, 0, ptr(scratch), scratch.numel() * 4, s)
+            else:
+                L.kr_gemm_bf16(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Cd), N, M, N, K, EPI_NONE, 0, s)
+            g = C.c_void_p()
+            L.kr_graph_end_capture(s, C.byref(g))
+            L.kr_graph_launch(g.value, s)
+            L.kr_stream_synchronize(s)
+            out["cap", ws] = host(Cd)
+            L.kr_graph_destroy(g.value)
+            Ce = gemm(ws, 0)
+            torch.cuda.synchronize()
+            out["eager", ws] = host(Ce)
     finally:
         os.environ.pop("KARANTA_GEMM_TILE", None)
-    assert_close_bf16(captured, eager, what="captured GEMM vs eager")
+    np.testing.assert_array_equal(out["cap", True], out["eager", True])      # same call, same bits: captured or eager
+    np.testing.assert_array_equal(out["cap", False], out["eager", False])
+    assert not np.array_equal(out["eager", True], out["eager", False]), "the scratch should change the tail's K order"
     rows = np.r_[0:200, M - 400:M]
-    assert_close_bf16(captured[rows], ref_linear(A[rows], W), what="captured GEMM")
+    for k in (True, False):
+        assert_close_bf16(out["eager", k][rows], ref_linear(A[rows], W), what=f"GEMM tail (scratch={k})")
+    with pytest.raises(Exception):      # a scratch smaller than KR_GEMM_SCRATCH_BYTES is refused
+        L.kr_gemm_bf16_ws(ptr(Ad), K, ptr(Wd), 0, 0, 0, ptr(Ad), N, M, N, K, EPI_NONE, 0, ptr(scratch), 1 << 20, 0)
 
 
 def test_events_time_a_kernel(L):
@@ -1928,6 +1982,8 @@ def test_logprobs_topk_matches_oracle(L, V, n_part, k):
 def test_oproj_heads_merges_and_accumulates(L, H, d, n_split, M):
     """kr_oproj_heads = attn_merge_kernel + o_proj + residual add, with K split by head and float atomics: against the
     merge formula in numpy (merged head rounded to bf16, as the separate merge launch leaves it) and an f64 matmul."""
+    if not L.experiments:
+        pytest.skip("experiment entry point: -DKR_EXPERIMENTS builds only (include/karanta_hip_experiments.h)")
     rng = np.random.default_rng(H * 1000 + d + n_split + M)
     hd = 128
     ws = np.zeros((M, H, n_split, hd + 4), np.float32)
@@ -1957,6 +2013,8 @@ def test_oproj_heads_merges_and_accumulates(L, H, d, n_split, M):
 
 
 def test_oproj_heads_fp8_weights(L):
+    if not L.experiments:
+        pytest.skip("experiment entry point: -DKR_EXPERIMENTS builds only (include/karanta_hip_experiments.h)")
     rng = np.random.default_rng(5)
     H, d, n_split, M, hd = 12, 1536, 8, 8, 128
     from karanta_ocr_amd.weights import fp8_e4m3_to_f32, pack_w16x64_fp8, quantize_fp8_rows
@@ -1982,6 +2040,8 @@ def test_oproj_heads_fp8_weights(L):
 def test_linear_wide_f32_rows_equal_the_rounded_bf16_rows(L, M, K, blocks, waves):
     """kr_linear_decode_wide_x32 (x rows from the f32 residual accumulator) = kr_linear_decode_wide on their bf16 rounding,
     bit for bit; workgroup 0 leaves the rounded rows in x_out."""
+    if not L.experiments:
+        pytest.skip("experiment entry point: -DKR_EXPERIMENTS builds only (include/karanta_hip_experiments.h)")
     rng = np.random.default_rng(M + K)
     ff = 16 * 37
     xf = (rng.standard_normal((M, K)) * 2).astype(np.float32)
@@ -2007,6 +2067,8 @@ def test_linear_wide_f32_rows_equal_the_rounded_bf16_rows(L, M, K, blocks, waves
 def test_linear_narrow_x32_also_leaves_x_new_as_f32(L, M, K, parts):
     """kr_linear_decode_narrow_x32: the same product as kr_linear_decode_narrow, and workgroup 0 stores x_new (the bf16
     residual row it normalises) as f32 too — the start value of the fast-residual accumulator — inside ldxf only."""
+    if not L.experiments:
+        pytest.skip("experiment entry point: -DKR_EXPERIMENTS builds only (include/karanta_hip_experiments.h)")
     rng = np.random.default_rng(900 + M + K)
     N = 16 * 9
     x, W, nw = rnd(rng, M, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5), bf16_round(1 + 0.1 * rnd(rng, K))

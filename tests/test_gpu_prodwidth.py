@@ -10,7 +10,10 @@ the depth truncated to what the oracle finishes in seconds (tests/prodwidth.py),
   (a) Qwen2-VL-2B widths, one 1024x1024 scan (70x70 patches, 1225 image tokens): ViT merged output, last-position
       prefill logits, 12 greedy tokens with a MINIMUM number of decisive comparisons, eager = graph, batch of 3 = solo;
   (b) Qwen2-VL-7B widths, batch of 4 (BASELINE config 3's per-GPU share), bf16 and fp8 weights (config 5's dtype);
-  (c) config 5 geometry: a 1700x2200 scan at max_pixels = 12 845 056 (158x122 = 19 276 patches) through the ViT;
+  (a') the bench model itself — Qwen2-VL-2B at FULL depth (32 + 28, tied head) — against the oracle, teacher-forced for 16
+      decode steps, and config 2's batch of 8 pages: batch = solo, eager = graph, slot scheduler;
+  (c) config 5 end to end: a 1700x2200 scan at max_pixels = 12 845 056 (158x122 = 19 276 patches) through the ViT, its
+      4988-token prompt through the fp8 engine's prefill and 9 decode steps at contexts ~5000;
   (d) config 1 geometry: a 1056x1422 JPEG through VLLMClient.generate -> LocalServer -> engine (grid 82x60, 1230 image
       tokens), ids equal to a direct Engine.generate;
   (e) config 4 shape: 64 requests from 8 VLLMClient worker threads through the continuous server
@@ -118,22 +121,23 @@ def test_2b_width_vit_prefill_and_greedy_tokens_match_oracle(m2b):
     assert walked >= 4 and decisive >= 3, f"free run: only {decisive} decisive / {walked} walked steps of {steps}"
     # ---- the FAST-RESIDUAL decode step (per-head o_proj + float atomics, no merge launch): same tolerance, same decisive
     # tokens against the oracle; not bit-identical to the deterministic step by construction (sum order)
-    assert eng.set_fast_residual(True)
-    try:
-        fast = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
-        fast_decisive = PW.compare_teacher_forced(fast.tokens[0], fast.logits[0], o_tok[0], o_log[0], tol, "2B widths (fast residual)")
-        dev = float(np.abs(fast.logits[0] - forced.logits[0]).max())
-        fast_graph = eng.generate([page], steps, ignore_eos=True)
-        m = PW.margins(o_log[0])
-        for i in range(steps):           # the replayed graph of the fast step follows the oracle wherever it is decisive
-            if m[i] <= 2 * tol:
-                break
-            assert int(fast_graph.tokens[0][i]) == int(o_tok[0, i]), f"fast graph step {i}"
-        _record("2b_w_v4_l4_fast_residual", decisive=fast_decisive, max_logit_dev_vs_deterministic=dev, tol=tol)
-        # (dev is sum-order noise of the float atomics: 0.3-0.5 tol from run to run; the oracle check above is the bound)
-        assert fast_decisive == f_decisive and dev < tol
-    finally:
-        eng.set_fast_residual(False)
+    assert eng.set_fast_residual(True) == eng.L.experiments     # the shipped library does not hold this mode
+    if eng.L.experiments:      # an experiment build (-DKR_EXPERIMENTS, loaded through KARANTA_HIP_LIB)
+        try:
+            fast = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
+            fast_decisive = PW.compare_teacher_forced(fast.tokens[0], fast.logits[0], o_tok[0], o_log[0], tol, "2B widths (fast residual)")
+            dev = float(np.abs(fast.logits[0] - forced.logits[0]).max())
+            fast_graph = eng.generate([page], steps, ignore_eos=True)
+            m = PW.margins(o_log[0])
+            for i in range(steps):           # the replayed graph of the fast step follows the oracle wherever it is decisive
+                if m[i] <= 2 * tol:
+                    break
+                assert int(fast_graph.tokens[0][i]) == int(o_tok[0, i]), f"fast graph step {i}"
+            _record("2b_w_v4_l4_fast_residual", decisive=fast_decisive, max_logit_dev_vs_deterministic=dev, tol=tol)
+            # (dev is sum-order noise of the float atomics: 0.3-0.5 tol from run to run; the oracle check above is the bound)
+            assert fast_decisive == f_decisive and dev < tol
+        finally:
+            eng.set_fast_residual(False)
     # ---- the replayed graph gives the eager tokens; a ragged batch of 3 gives page 0 its solo tokens
     graph = eng.generate([page], steps, ignore_eos=True)
     np.testing.assert_array_equal(graph.tokens[0], res.tokens[0])
@@ -145,6 +149,125 @@ def test_2b_width_vit_prefill_and_greedy_tokens_match_oracle(m2b):
 def _pg(cfg, index, h, w, n_pre, max_pixels=MAXPIX_A):
     ids, pv, grid = PW.page_inputs(cfg, index, h, w, max_pixels, n_pre, 5, 1000 + index)
     return ids, pv, [grid]
+
+
+# ------------------------------------------------------------------------------------------------------------ (a')
+@pytest.fixture(scope="module")
+def m2b_full():
+    """BASELINE.json's bench model as shipped: Qwen2-VL-2B at FULL depth (32 ViT blocks, 28 decoder layers, tied head),
+    seeded random weights, an engine with the bench's 8 decode slots."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from karanta_ocr_amd.config import CONFIGS
+    cfg = CONFIGS["Qwen2-VL-2B"]
+    w = random_weights(cfg, 0, as_bits=True)
+    eng = Engine(cfg, max_batch=8, s_max=1536, max_patches=8 * 4960, max_prompt_tokens=8 * 1400, decode_splits=16)
+    eng.load_weights(w)
+    assert eng.wide_mode and eng.narrow_mode and eng.defer_down
+    yield cfg, w, eng
+    eng.close()
+
+
+def test_full_depth_2b_matches_oracle_teacher_forced(m2b_full):
+    """VERDICT r2 Missing #2: the bench model at FULL depth against the oracle — bf16 rounding accumulated through 32 ViT
+    blocks and 28 decoder layers is what the 4 + 4 truncation cannot show.  One 1024x1024 scan (the bench's page
+    geometry: 70x70 patches, 1225 image tokens), call sequence of
+    /root/reference/karanta/training/test_trained_model.py:76-99; the oracle at the engine's dtype policy (bf16 storage,
+    fp32 accumulate) costs ~40 s of ViT + ~6 s of prefill + ~50 ms per token on the GPU box's host cores.  Two heads on
+    the same 28-layer stack:
+      * the model AS SHIPPED (tied head).  A random tied head echoes its last input token with a margin of half the logit
+        range (logit_i = h . E_i with h ~ E_token), so its 17 steps are all decisive and all equal — what this run pins
+        is the logit ERROR at full depth: measured 1.3 - 1.5 % of the range (ViT merged output 1.6 %), against 0.5 - 0.6 %
+        at 4 layers;
+      * the same stack with an UNTIED random head (the variant every other prodwidth test runs: logits that depend on the
+        whole computation, top-2 margins of a few per cent of the range): 33 teacher-forced steps, >= 8 of them decisive.
+    Stated tolerance at full depth (measured errors with headroom): ViT merged output within 2.5 % of its range, logits
+    within TOL = 2 % of the logit range at every step, argmax equal wherever the oracle's top-2 margin exceeds 2 x TOL."""
+    cfg, w, eng = m2b_full
+    ids, pv, grid = PW.page_inputs(cfg, 300, 1024, 1024, MAXPIX_A, 20, 30, 31)
+    assert grid == (1, 70, 70) and cfg.vision.depth == 32 and cfg.text.num_layers == 28 and cfg.text.tie_word_embeddings
+    got_img = eng.vit_forward(pv, [grid])
+    eng.stream.synchronize()
+    got_img = got_img.float().cpu().numpy()
+    ref_img = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+    scale = float(np.abs(ref_img).max())
+    vit_err = float(np.abs(got_img - ref_img).max())
+    assert vit_err < 0.025 * scale, f"ViT merged output off by {vit_err} (range {scale})"
+    # the decoder's parameters as resident fp32 arrays (left as bf16 bit patterns, every oracle call re-expands them)
+    wl = {k: (O._w(w, k) if not k.startswith("model.visual.") else v) for k, v in w.items()}
+    page = PageRequest(ids, pv, [grid])
+    TOL_FULL = 0.02
+
+    def run(engine, mcfg, weights, steps, key, min_decisive):
+        o_tok, o_log = O.generate_greedy(mcfg, weights, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True,
+                                         return_logits=True, image_embeds=ref_img)
+        forced = engine.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
+        rng_ = float(np.abs(o_log[0, 0]).max())
+        tol = TOL_FULL * rng_
+        errs = [float(np.abs(forced.logits[0, i] - o_log[0, i]).max()) for i in range(steps)]
+        m = PW.margins(o_log[0])
+        decisive = [i for i in range(steps) if m[i] > 2 * tol]
+        agree = sum(1 for i in range(steps) if int(forced.tokens[0][i]) == int(o_tok[0, i]))
+        _record(key, vit_err=vit_err, vit_range=scale, logit_range=rng_, tol=tol, forced_logit_err=errs, margins=m.tolist(),
+                decisive=len(decisive), argmax_equal=agree, steps=steps, tokens=[int(t) for t in forced.tokens[0]],
+                oracle_tokens=[int(t) for t in o_tok[0]])
+        assert max(errs) < tol, f"{key}: logits off by {max(errs)} (tol {tol}, range {rng_}); per step {errs}"
+        for i in decisive:
+            assert int(forced.tokens[0][i]) == int(o_tok[0, i]), \
+                f"{key} step {i}: engine {int(forced.tokens[0][i])} vs oracle {int(o_tok[0, i])} at margin {m[i]:.3f}"
+        assert len(decisive) >= min_decisive, f"{key}: only {len(decisive)} of {steps} steps were decisive (margins {m.tolist()})"
+        free = engine.generate([page], steps, ignore_eos=True)     # the replayed graph follows the oracle up to the first near-tie
+        for i in range(steps):
+            if m[i] <= 2 * tol:
+                break
+            assert int(free.tokens[0][i]) == int(o_tok[0, i]), f"{key}: graph step {i}"
+
+    run(eng, cfg, wl, 17, "2b_full_depth_v32_l28_tied", 8)
+    # the same stack under an untied random head
+    ucfg = PW.truncated_config("Qwen2-VL-2B", 32, 28, untie=True)
+    head = random_weights(ucfg, 0, as_bits=True, only=["lm_head.weight"])
+    assert ucfg.text.num_layers == 28 and ucfg.vision.depth == 32 and not ucfg.text.tie_word_embeddings and len(head) == 1
+    ueng = Engine(ucfg, max_batch=1, s_max=1536, max_patches=4960, max_prompt_tokens=1400, decode_splits=16)
+    try:
+        ueng.load_weights({**w, **head})
+        run(ueng, ucfg, {**wl, "lm_head.weight": O._w(head, "lm_head.weight")}, 33, "2b_full_depth_v32_l28_untied", 8)
+    finally:
+        ueng.close()
+
+
+def test_full_size_qwen2_vl_2b_batch_of_8_properties(m2b_full):
+    """BASELINE.json config 2 exactly — Qwen2-VL-2B, full depth, a batch of EIGHT pages (six 1024x1024 scans -> 70x70
+    patches, two of other sizes so the batch is ragged): every page's tokens in the batch equal its solo run (ViT
+    segments, the GEMM tile choice that changes with M, prefill, split-KV decode: all batch-independent by construction),
+    the eager decode loop equals the replayed graph, and the slot scheduler (other slots, other history) reproduces them
+    once more.  The oracle comparison at this depth is the test above."""
+    from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
+    cfg, w, eng = m2b_full
+    rng = np.random.default_rng(31)
+    pages = []
+    for i, (h, wd) in enumerate([(1024, 1024)] * 3 + [(700, 1000)] + [(1024, 1024)] * 3 + [(448, 616)]):
+        pv, grid = IP.image_to_patches(IP.synthetic_page(200 + i, h, wd), max_pixels=MAXPIX_A)
+        T = grid[1] * grid[2] // 4
+        ids = np.concatenate([rng.integers(0, 150000, 20 + 7 * (i % 3)), [cfg.vision_start_token_id], [cfg.image_token_id] * T,
+                              [cfg.vision_end_token_id], rng.integers(0, 150000, 30)]).astype(np.int64)
+        pages.append(PageRequest(ids, pv, [grid]))
+    assert pages[0].grids[0] == (1, 70, 70) and len(pages) == 8
+    steps = 24
+    together = eng.generate(pages, steps, ignore_eos=True)
+    for t in together.tokens:
+        assert len(t) == steps and t.min() >= 0 and t.max() < cfg.text.vocab_size
+    assert not np.array_equal(together.tokens[0], together.tokens[1]), "different scans, different text"
+    for i, pg in enumerate(pages):
+        alone = eng.generate([pg], steps, ignore_eos=True)
+        np.testing.assert_array_equal(alone.tokens[0], together.tokens[i], err_msg=f"page {i}: batch vs solo")
+    eager = eng.generate(pages, steps, ignore_eos=True, use_graph=False)
+    for i in range(8):
+        np.testing.assert_array_equal(eager.tokens[i], together.tokens[i], err_msg=f"page {i}: eager vs graph")
+    sch = SlotScheduler(eng, max_tokens_cap=steps, chunk=5, eos_token_ids=())
+    res = sch.run([SlotRequest(pg, steps, tag=i) for i, pg in enumerate(pages[::-1])])
+    for r, want in zip(res, together.tokens[::-1]):
+        assert r.error is None
+        np.testing.assert_array_equal(r.tokens[:steps], want[:len(r.tokens[:steps])])
 
 
 # ------------------------------------------------------------------------------------------------------------ (b)
@@ -191,25 +314,53 @@ def test_7b_width_batch_of_4_matches_oracle(m7b, weight_dtype):
 
 
 # ------------------------------------------------------------------------------------------------------------ (c)
-def test_config5_geometry_1700x2200_vit_matches_oracle(m7b):
-    """One 1700x2200 newspaper scan at the hub preprocessor's max_pixels (12 845 056): 2212x1708 -> 158x122 = 19 276
-    patches, 4819 image tokens, ONE attention segment of 19 276 tokens (302 KV tiles) — through the 7B model's tower."""
+def test_config5_1700x2200_fp8_end_to_end_matches_oracle(m7b):
+    """BASELINE.json config 5 end to end at the 7B widths (2 + 2 depth): one 1700x2200 newspaper scan at the hub
+    preprocessor's max_pixels (12 845 056): 2212x1708 -> 158x122 = 19 276 patches, ONE attention segment of 19 276 tokens
+    (302 KV tiles), 4819 image tokens; the chat template around it makes a 4988-token prompt — prefill with 78 causal KV
+    tiles per query block through the FP8-weight engine (kr_gemm_fp8 on M = 4988), then 23 teacher-forced decode steps at
+    contexts 4988 .. 5010 (16-split decode attention over 5k cached tokens, the fp8 wide / narrow decode kernels), against
+    the oracle on the dequantised state dict.  Tolerances as in (b) (measured: logits off by 0.5 % of their range at every
+    step; the random model's top-2 margins at this prompt are small — 3 of the first 10 steps decisive — hence 24 steps)."""
     cfg, w, _ = m7b
     pv, grid = IP.image_to_patches(IP.synthetic_page(320, 2200, 1700), max_pixels=MAXPIX_B)
     assert grid == (1, 158, 122) and len(pv) == 19276
-    eng = Engine(cfg, max_batch=1, s_max=64, max_patches=19276, max_prompt_tokens=64, decode_splits=1)
+    rng = np.random.default_rng(55)
+    ids = np.concatenate([rng.integers(0, 150000, 110), [cfg.vision_start_token_id], [cfg.image_token_id] * 4819,
+                          [cfg.vision_end_token_id], rng.integers(0, 150000, 57)]).astype(np.int64)
+    assert len(ids) == 4988
+    steps = 24
+    eng = Engine(cfg, max_batch=1, s_max=5184, max_patches=19276, max_prompt_tokens=5056, decode_splits=16, weight_dtype="fp8")
     eng.load_weights(w)
     try:
+        assert eng.wide_mode and eng.narrow_mode and eng.defer_down and eng.fp8_prefill_gemm
         got = eng.vit_forward(pv, [grid])
         eng.stream.synchronize()
         got = got.float().cpu().numpy()
+        ref = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+        assert got.shape == ref.shape == (4819, 3584)
+        scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
+        _record("config5_vit_19276", err=err, range=scale, rel=err / scale)
+        assert err < 0.02 * scale, f"ViT merged output off by {err} (range {scale})"
+        wref = fp8_dequantized_weights(w, cfg)
+        o_tok, o_log = O.generate_greedy(cfg, wref, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True,
+                                         return_logits=True, image_embeds=ref)
+        page = PageRequest(ids, pv, [grid])
+        forced = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
+        tol = TOL_REL * float(np.abs(o_log[0, 0]).max())
+        f_errs = [float(np.abs(forced.logits[0, i] - o_log[0, i]).max()) for i in range(steps)]
+        assert f_errs[0] < tol, f"prefill logits (P = 4988) off by {f_errs[0]} (tol {tol})"
+        f_decisive = PW.compare_teacher_forced(forced.tokens[0], forced.logits[0], o_tok[0], o_log[0], tol, "config 5 fp8 (forced)")
+        _record("config5_fp8_p4988", tol=tol, forced_logit_err=f_errs, margins=PW.margins(o_log[0]).tolist(), forced_decisive=f_decisive)
+        assert f_decisive >= 4, f"only {f_decisive} of {steps} teacher-forced steps were decisive"
+        graph = eng.generate([page], steps, ignore_eos=True)
+        m = PW.margins(o_log[0])
+        for i in range(steps):
+            if m[i] <= 2 * tol:
+                break
+            assert int(graph.tokens[0][i]) == int(o_tok[0, i]), f"graph step {i}"
     finally:
         eng.close()
-    ref = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
-    assert got.shape == ref.shape == (4819, 3584)
-    scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
-    _record("config5_vit_19276", err=err, range=scale, rel=err / scale)
-    assert err < 0.02 * scale, f"ViT merged output off by {err} (range {scale})"
 
 
 # ------------------------------------------------------------------------------------------------------------ (d), (e)
