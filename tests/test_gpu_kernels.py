@@ -1828,6 +1828,46 @@ def test_rccl_single_rank_broadcast(L):
     L.kr_comm_destroy(comm)
 
 
+def test_rccl_single_rank_broadcast_of_an_arena_above_2_gib_on_the_engine_stream(L):
+    """First-contact insurance for the 8-GPU run: the 7B arena is 16.6 GB, so kr_bcast_weights walks
+    1 GiB pieces with 64-bit offsets — here a 2.5 GiB buffer (three pieces, the last one partial) on a NON-default stream,
+    behind a fill that is still executing on that stream (the broadcast must be stream-ordered, as the engine's
+    load -> broadcast -> first launch sequence needs), with a 1-rank communicator; bytes around every piece boundary and the
+    tail are checked."""
+    n = (5 << 29) + 4096 + 13                      # 2.5 GiB + a ragged tail
+    free, _ = torch.cuda.mem_get_info()
+    if free < n + (1 << 30):
+        pytest.skip("not enough free HBM for a 2.5 GiB buffer")
+    stream = torch.cuda.Stream()
+    uid = (C.c_uint8 * 128)()
+    L.kr_comm_unique_id(uid)
+    comm = C.c_void_p()
+    L.kr_comm_init(C.byref(comm), 1, 0, uid)
+    cnt = C.c_int(0)
+    L.kr_comm_count(comm, C.byref(cnt))
+    assert cnt.value == 1
+    buf = torch.empty(n, dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        buf.fill_(7)
+        buf[::4093] = 201                         # (4093 is prime: a pattern that does not line up with any piece size)
+        L.kr_bcast_weights(comm, ptr(buf), n, 0, stream.cuda_stream)
+        probe = []
+        for edge in (0, 1 << 30, 2 << 30, n):
+            lo, hi = max(0, edge - 4096), min(n, edge + 4096)
+            probe.append((lo, buf[lo:hi].clone()))
+        total = int((buf == 201).sum().item())
+    stream.synchronize()
+    assert total == -(-n // 4093)
+    for lo, got in probe:
+        idx = np.arange(lo, lo + got.numel())
+        want = np.where(idx % 4093 == 0, 201, 7).astype(np.uint8)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    L.kr_comm_destroy(comm)
+    del buf
+    torch.cuda.empty_cache()
+
+
 # ----------------------------------------------------------------------------- guided decoding + log-probabilities
 def _random_vocab(rng, V, eos):
     """Token byte strings: all 256 single bytes first (as byte-level BPE has), then random 2..6 byte pieces over a small
