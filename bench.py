@@ -382,6 +382,9 @@ def main():
                     help="split-KV parts of the decode attention (16: 256 workgroups of 4 waves, every CU loads; r2: -4 %% per step vs 8)")
     ap.add_argument("--weights", default="bf16", choices=("bf16", "fp8"),
                     help="fp8: decoder Linears as e4m3fn codes + per-row scales (BASELINE.json config 5); activations stay bf16")
+    ap.add_argument("--fp8-act", type=int, default=None, choices=(0, 1),
+                    help="with --weights fp8: W8A8 prefill (per-token e4m3 activations through the fp8 matrix instruction) on / off; "
+                         "default: the engine's default")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N-rank control plane (self-launch, rendezvous, barriers, max-over-ranks timing, "
                          "rank 0's JSON line, exit codes) with no engine: the line carries \"dry_run\": true and no measurement")
@@ -452,7 +455,8 @@ def main():
 
     s_max = (max(P) + T_out + 63) // 64 * 64
     eng = Engine(cfg, device=dev, max_batch=B, s_max=s_max, max_patches=sum(g[1] * g[2] for g in grids),
-                 max_prompt_tokens=sum(P), decode_splits=args.decode_splits, weight_dtype=args.weights)
+                 max_prompt_tokens=sum(P), decode_splits=args.decode_splits, weight_dtype=args.weights,
+                 fp8_activations=None if args.fp8_act is None else bool(args.fp8_act))
     if args.guided:
         # no tokenizer ships with random-init weights: the byte tokens 0..255 carry their byte, the rest are specials;
         # the pattern allows any text, so the mask / advance kernels do their full per-step work
@@ -555,6 +559,8 @@ def main():
                             f"max_pixels={args.max_pixels} (grid {grids[0][1]}x{grids[0][2]}, {n_img_tok[0]} image tokens), "
                             f"prompt P={P[0]} tokens, T_out={T_out} (ignore_eos), random-init weights",
                 "global_batch": world * B, "parallelism": f"dp{world}", "decode": "hipGraph replay" if not args.no_graph else "eager",
+                **({"prefill": "W8A8 (per-token e4m3 activations, v_mfma_f32_16x16x32_fp8_fp8)" if eng.fp8_act
+                    else "fp8 weights converted to bf16 in registers, bf16 MFMA"} if args.weights == "fp8" else {}),
                 **({"guided": "every page, pattern [\\s\\S]*"} if args.guided else {}),
                 **({"logprobs": args.logprobs} if args.logprobs is not None else {}),
             },

@@ -127,6 +127,20 @@ int kr_gemm_fp8(const kr_bf16* A, int64_t lda, const uint8_t* w_packed_fp8, cons
                 const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
                 kr_stream s);
 
+/* W8A8 prefill on the fp8 matrix instruction (BASELINE.json config 5: "Qwen2-VL-7B fp8 weights (CDNA4 fp8 MFMA)"; the
+ * reference's default OLMO_7B_0725_FP8, /root/reference/karanta/constants.py:23, is served by vLLM with dynamic per-token
+ * activation scales):
+ *   kr_quantize_rows_fp8 : x bf16 [rows, K] (row stride ldx elements) -> q e4m3fn codes [rows, K] (row stride ldq BYTES,
+ *       a multiple of 16) + scale f32 [rows]: scale = max|row| / 448 (1 for an all-zero row), code = e4m3(x / scale), round
+ *       to nearest even (bit-identical to weights.quantize_fp8_rows on the host);
+ *   kr_gemm_fp8a : C = epi((a_scale * A8) (w_scale * W8)^T + bias) (+ residual) with both operands as codes through
+ *       v_mfma_f32_16x16x32_fp8_fp8 (products of two e4m3 values are exact in f32; f32 accumulation), the two scales applied
+ *       to the accumulators.  A8 row-major [M, lda bytes]; weights, epilogues and constraints as kr_gemm_fp8. */
+int kr_quantize_rows_fp8(const kr_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int64_t rows, int K, kr_stream s);
+int kr_gemm_fp8a(const uint8_t* A8, int64_t lda, const float* a_scale, const uint8_t* w_packed_fp8, const float* w_scale,
+                 const kr_bf16* bias, const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K,
+                 int epilogue, kr_stream s);
+
 /* Decode-time Linear for M <= 16 rows (one row per live sequence): the weight matrix is streamed
  * exactly once from HBM (this is the HBM-roofline kernel of the decode loop).
  * Same semantics and epilogues as kr_gemm_bf16.  If out_f32 != NULL the result is written there

@@ -43,6 +43,8 @@ SIGNATURES = {
     "kr_layernorm": [c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
     "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p],
+    "kr_quantize_rows_fp8": [c_p, i64, c_p, i64, c_p, i64, i32, c_p],
+    "kr_gemm_fp8a": [c_p, i64, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
     "kr_gemm_bf16_ws": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p, C.c_size_t, c_p],
     "kr_gemv_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, c_p, i64, i32, i32, i32, i32, c_p, f32, c_p],
     "kr_qkv_prep": [c_p, i64, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p, i64, c_p, i64, c_p, i64,

@@ -426,6 +426,22 @@ __device__ __forceinline__ void stage_w8_rows32(const uint8_t* __restrict__ g, i
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
+// fp8 ACTIVATIONS (W8A8 prefill: kr_quantize_rows_fp8 + kr_gemm_fp8a): row-major e4m3 codes [M][K], so the 32 k of a K-tile are
+// 32 bytes of a row and a 256-row A tile is 8 KiB — ONE LDS-DMA per wave (32 rows x two 16-byte halves).  LDS image: 32-byte
+// rows; the 16-byte half q of row r holds SOURCE half q ^ ((r >> 3) & 1), so that the 32 lanes of a ds_read_b64 group
+// (rows 0..15 x two 8-byte granules) touch 32 distinct 8-byte slots of the 256-byte bank row.
+__device__ __forceinline__ void stage_a8_rows32(const uint8_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_total, int k0,
+                                                char* lds_op, int lane, int wave) {
+    const int r = wave * 32 + (lane >> 1);
+    const int p = (lane & 1) ^ ((r >> 3) & 1);
+    int64_t gr = row0 + r;
+    gr = gr < rows_total ? gr : rows_total - 1;
+    const uint8_t* src = g + gr * ld + k0 + p * 16;
+    char* dst = lds_op + wave * 1024;  // wave-uniform; the hardware adds lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
 // 8 e4m3 codes (two 32-bit words) -> 8 bf16, natural order (cvt_scalef32_pk_bf16_fp8 converts one 16-bit half of a
 // word; its 2 x bf16 result is moved as a 32-bit word: element-wise extraction is mis-lowered by this compiler)
 __device__ __forceinline__ bf16x8 fp8x8_to_bf16(u32x2 q) {
@@ -440,13 +456,19 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(u32x2 q) {
 
 // W8: W is fp8 codes + one f32 scale per output row (applied to the accumulators before the epilogue); activations,
 // accumulation and outputs as in the bf16 kernel.
-template <int EPI, bool WPACK, bool W8>
+// A8 (with W8): the activations are e4m3 codes too (one f32 scale per ROW of A: dynamic per-token quantisation,
+// kr_quantize_rows_fp8) and the products run on the fp8 matrix instruction, v_mfma_f32_16x16x32_fp8_fp8 — no conversion on
+// the way from LDS to the MFMA, half the A bytes through LDS; both scales multiply the f32 accumulators before the epilogue.
+template <int EPI, bool WPACK, bool W8, bool A8 = false>
 __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restrict__ A, int64_t lda, const kr_bf16* __restrict__ W,
                                                         const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R,
                                                         int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                                                        int tiles_n, unsigned nwg, const float* __restrict__ w_scale, int group_m) {
+                                                        int tiles_n, unsigned nwg, const float* __restrict__ w_scale, int group_m,
+                                                        const float* __restrict__ a_scale = nullptr) {
+    static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
     constexpr int NT = 4, MT = 8, A_BYTES = 256 * PK * 2;
     const uint8_t* W8p = reinterpret_cast<const uint8_t*>(W);
+    const uint8_t* A8p = reinterpret_cast<const uint8_t*>(A);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (a second one makes hipcc drain the DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -467,12 +489,17 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     const int nk = K / PK;
     // fragment read offsets inside a buffer (row * 64 + swizzled chunk * 16)
     const int sw = ((fg ^ (((fr >> 3) & 1) << 1)) << 4);
-    const int a_off = (wr * 128 + fr) * 64 + sw;
+    const int a_off = A8 ? (wr * 128 + fr) * 32 + ((((fg >> 1) ^ ((fr >> 3) & 1))) << 4) + ((fg & 1) << 3)   // 8 codes of row fr
+                         : (wr * 128 + fr) * 64 + sw;
     const int w_off = W8 ? A_BYTES + wc * 4 * 512 + (fg >> 1) * 256 + fr * 16 + (fg & 1) * 8   // 8 codes of row fr
                          : A_BYTES + (wc * 64 + fr) * 64 + sw;
     auto stage_w = [&](int k0, char* buf) {
         if constexpr (W8) stage_w8_rows32(W8p, K, n0, N, k0, buf + A_BYTES, lane, wave);
         else stage_rows32<WPACK>(W, K, n0, N, k0, buf + A_BYTES, lane, wave);
+    };
+    auto stage_a = [&](int k0, char* buf) {
+        if constexpr (A8) stage_a8_rows32(A8p, lda, m0, M, k0, buf, lane, wave);
+        else stage_rows32<false>(A, lda, m0, M, k0, buf, lane, wave);
     };
 
     // ---- prologue: K-tiles 0..2 requested, K-tile 0 landed and visible
@@ -481,16 +508,18 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
         if (t < nk) {
             char* buf = smem + t * PBUF;
             stage_w(t * PK, buf);
-            stage_rows32<false>(A, lda, m0, M, t * PK, buf, lane, wave);
+            stage_a(t * PK, buf);
         }
     }
-    // loads per K-tile and wave: 2 (A) + 2 (bf16 W) or 1 (fp8 W); the counted waits leave two / one K-tile in flight
+    // loads per K-tile and wave: 2 (bf16 A) or 1 (fp8 A) + 2 (bf16 W) or 1 (fp8 W); the counted waits leave two / one K-tile in flight
     auto wait_two = [] {
-        if constexpr (W8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (A8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (W8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
     auto wait_one = [] {
-        if constexpr (W8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (A8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (W8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     };
     if (nk >= 3) wait_two();
@@ -500,6 +529,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
 
     bf16x8 wb[NT], xa[4];
+    u32x2 xq[4];   // A8: the A fragments as 8 codes
     for (int k = 0; k < nk; ++k) {
         const char* cur = smem + (k & 3) * PBUF;
         char* nxt = smem + ((k + 3) & 3) * PBUF;
@@ -514,12 +544,17 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
             for (int t = 0; t < NT; ++t) wb[t] = *reinterpret_cast<const bf16x8*>(cur + w_off + t * 16 * 64);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (A8) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + t * 16 * 64);
+            for (int t = 0; t < 4; ++t) xq[t] = *reinterpret_cast<const u32x2*>(cur + a_off + t * 16 * 32);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + t * 16 * 64);
+        }
         if (more) stage_w((k + 3) * PK, nxt);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (W8) {
+        if constexpr (W8 && !A8) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) wb[t] = fp8x8_to_bf16(wq[t]);
         }
@@ -527,14 +562,24 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][mt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (A8)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, wq[nt]), __builtin_bit_cast(long, xq[mt]),
+                                                                             acc[nt][mt], 0, 0, 0);
+                else
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][mt], 0, 0, 0);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- phase 1: A rows 64..127; the counted wait of this K-tile
+        if constexpr (A8) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + (4 + t) * 16 * 64);
-        if (more) stage_rows32<false>(A, lda, m0, M, (k + 3) * PK, nxt, lane, wave);
+            for (int t = 0; t < 4; ++t) xq[t] = *reinterpret_cast<const u32x2*>(cur + a_off + (4 + t) * 16 * 32);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const bf16x8*>(cur + a_off + (4 + t) * 16 * 64);
+        }
+        if (more) stage_a((k + 3) * PK, nxt);
         // K-tile k+1 must have landed (this wave's share); k+2 and k+3 may stay in flight
         if (more) wait_two();
         else if (k + 3 == nk) wait_one();
@@ -545,8 +590,13 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt][4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][4 + mt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (A8)
+                    acc[nt][4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, wq[nt]), __builtin_bit_cast(long, xq[mt]),
+                                                                                 acc[nt][4 + mt], 0, 0, 0);
+                else
+                    acc[nt][4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], xa[mt], acc[nt][4 + mt], 0, 0, 0);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
@@ -559,6 +609,17 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[nt][mt][j] *= sc[j];
+        }
+    }
+    if constexpr (A8) {  // per-token scales of the quantised activations: the lane's batch row is the accumulator's column
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m0 + wr * 128 + mt * 16 + fr;
+            const float as = a_scale[m < M ? m : M - 1];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][mt][j] *= as;
         }
     }
     gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, fr, fg, smem + wave * (128 * 128));
@@ -575,9 +636,10 @@ inline int kr_cu_count();
 // the work), prefill o_proj / down_proj 264 tiles = 1 round + 8.  When the last round would be at most half full its
 // tiles are cut into 128x128 quarters and run as a second launch of the two-barrier kernel (same k order: the same
 // bits), which fills the chip with 4x as many, co-resident, short workgroups.  KARANTA_GEMM_TAIL=0 disables it.
-template <int EPI, bool WPACK, bool W8 = false>
+template <int EPI, bool WPACK, bool W8 = false, bool A8 = false>
 int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
-                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s, const float* w_scale = nullptr) {
+                     kr_bf16* C, int64_t ldc, int64_t M, int N, int K, kr_stream s, const float* w_scale = nullptr,
+                     const float* a_scale = nullptr) {
     constexpr int LDS = PSTAGES * PBUF;
     const int64_t tiles_m = (M + 255) / 256;
     const int tiles_n = (N + 255) / 256;
@@ -599,7 +661,7 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     }
     static KrPerDeviceOnce attr_set;
     if (attr_set.need()) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8>),
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8, A8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     // measured (tools/gemm_microbench.py, r2): groups of 8 m tiles against m-major rows — ViT qkv (15 n tiles) 373 -> 350 us,
@@ -607,8 +669,8 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     // 32 ids is already a compact patch and groups are neutral (proj, down_proj) or worse (ViT fc2, K = 5120: 467 -> 495)
     const char* genv = getenv("KARANTA_GEMM_GROUP_M");
     const int group_m = genv ? atoi(genv) : (tiles_n >= 8 ? 8 : 1);
-    gemm_pipe_kernel<EPI, WPACK, W8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
-                                                                            (unsigned)nwg, w_scale, group_m);
+    gemm_pipe_kernel<EPI, WPACK, W8, A8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
+                                                                                (unsigned)nwg, w_scale, group_m, a_scale);
     KR_CHECK_LAUNCH();
     if constexpr (!W8) {
         if (tail)
@@ -780,6 +842,99 @@ extern "C" int kr_gemm_bf16(const kr_bf16* A, int64_t lda, const kr_bf16* W, con
             return launch_gemm<KR_EPI_SILU_MUL8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, w_packed, s);
         default:
             kr_set_error("kr_gemm_bf16: unknown epilogue %d", epilogue);
+            return KR_ERR_ARG;
+    }
+}
+
+// ---- dynamic per-token fp8 quantisation of activations (the A operand of kr_gemm_fp8a)
+namespace {
+// One 256-thread workgroup per row: the row in registers (K <= 8 * 256 * QMAX), max |x| over the workgroup, scale = max / 448
+// (1 for an all-zero row), codes = e4m3(x / scale) by v_cvt_pk_fp8_f32 (round to nearest even; |x / scale| <= 448 up to one
+// rounding of the division, far below the 464 where e4m3 would round up past its largest finite value).  Restated on the
+// host by weights.quantize_fp8_rows (same f32 division, same rounding): the codes are bit-identical (GPU test).
+template <int QMAX>
+__global__ void __launch_bounds__(256) quantize_rows_fp8_kernel(const kr_bf16* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                                int64_t ldq, float* __restrict__ scale, int K) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kc = K >> 3;
+    const kr_bf16* xr = x + (int64_t)blockIdx.x * ldx;
+    bf16x8 v[QMAX];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i) {
+        const int c = tid + i * 256;
+        if (c < kc) {
+            v[i] = ld8(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf2f(v[i][j])));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) scale[blockIdx.x] = sc;
+    uint8_t* qr = q + (int64_t)blockIdx.x * ldq;
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i) {
+        const int c = tid + i * 256;
+        if (c < kc) {
+            u32x2 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[i][4 * h + 0]) / sc, bf2f(v[i][4 * h + 1]) / sc, w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[i][4 * h + 2]) / sc, bf2f(v[i][4 * h + 3]) / sc, w, true);
+                o[h] = (unsigned)w;
+            }
+            *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int kr_quantize_rows_fp8(const kr_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int64_t rows, int K,
+                                    kr_stream s) {
+    KR_CHECK_ARG(x && q && scale, "kr_quantize_rows_fp8: null pointer");
+    KR_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && K > 0 && K % 8 == 0 && K <= 8 * 256 * 12, "kr_quantize_rows_fp8: rows=%lld K=%d (K %% 8, K <= 24576)",
+                 (long long)rows, K);
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && ldq >= K && (ldq & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 15) == 0,
+                 "kr_quantize_rows_fp8: strides / alignment");
+    if (rows == 0) return KR_OK;
+    const int per = ((K >> 3) + 255) / 256;
+    if (per <= 2) quantize_rows_fp8_kernel<2><<<(unsigned)rows, 256, 0, kr_hs(s)>>>(x, ldx, q, ldq, scale, K);
+    else if (per <= 4) quantize_rows_fp8_kernel<4><<<(unsigned)rows, 256, 0, kr_hs(s)>>>(x, ldx, q, ldq, scale, K);
+    else if (per <= 8) quantize_rows_fp8_kernel<8><<<(unsigned)rows, 256, 0, kr_hs(s)>>>(x, ldx, q, ldq, scale, K);
+    else quantize_rows_fp8_kernel<12><<<(unsigned)rows, 256, 0, kr_hs(s)>>>(x, ldx, q, ldq, scale, K);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+extern "C" int kr_gemm_fp8a(const uint8_t* A8, int64_t lda, const float* a_scale, const uint8_t* w_packed_fp8, const float* w_scale,
+                            const kr_bf16* bias, const kr_bf16* residual, int64_t ldr, kr_bf16* C, int64_t ldc, int64_t M, int N, int K,
+                            int epilogue, kr_stream s) {
+    KR_CHECK_ARG(A8 && a_scale && w_packed_fp8 && w_scale && C, "kr_gemm_fp8a: null pointer");
+    KR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "kr_gemm_fp8a: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+    KR_CHECK_ARG(K % 64 == 0 && N % 16 == 0, "kr_gemm_fp8a: K=%d must be a multiple of 64, N=%d of 16", K, N);
+    KR_CHECK_ARG(lda >= K && (lda & 15) == 0, "kr_gemm_fp8a: lda=%lld (bytes, a multiple of 16)", (long long)lda);
+    KR_CHECK_ARG((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (residual == nullptr || (ldr & 3) == 0),
+                 "kr_gemm_fp8a: C must be 16-byte aligned with ldc %% 8 == 0 (ldr %% 4 == 0)");
+    KR_CHECK_ARG(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)w_packed_fp8 & 15) == 0 && ((uintptr_t)w_scale & 15) == 0,
+                 "kr_gemm_fp8a: pointer alignment");
+    if (M == 0) return KR_OK;
+    const kr_bf16* Ap = reinterpret_cast<const kr_bf16*>(A8);
+    const kr_bf16* Wp = reinterpret_cast<const kr_bf16*>(w_packed_fp8);
+    switch (epilogue) {
+        case KR_EPI_NONE:
+            KR_CHECK_ARG(ldc >= N, "kr_gemm_fp8a: ldc < N");
+            return launch_gemm_pipe<KR_EPI_NONE, true, true, true>(Ap, lda, Wp, bias, residual, ldr, C, ldc, M, N, K, s, w_scale, a_scale);
+        case KR_EPI_SILU_MUL8:
+            KR_CHECK_ARG(ldc >= N / 2 && !residual, "kr_gemm_fp8a: SILU_MUL8 takes no residual");
+            return launch_gemm_pipe<KR_EPI_SILU_MUL8, true, true, true>(Ap, lda, Wp, bias, residual, ldr, C, ldc, M, N, K, s, w_scale, a_scale);
+        default:
+            kr_set_error("kr_gemm_fp8a: epilogue %d (NONE and SILU_MUL8 only: the decoder's prefill linears)", epilogue);
             return KR_ERR_ARG;
     }
 }

@@ -30,6 +30,7 @@ from .weights import pack_w16x64, to_bf16_bits
 
 BF16 = torch.bfloat16
 GEMM_SCRATCH_BYTES = 512 * 65536   # include/karanta_hip.h: KR_GEMM_SCRATCH_BYTES
+FP8_ACT_DEFAULT = False            # fp8 engines: W8A8 prefill on by default? (measured error and speed)
 
 
 def _bits(w: np.ndarray) -> np.ndarray:
@@ -267,7 +268,7 @@ class DeviceGuide:
 class Engine:
     def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
                  max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 16,
-                 weight_dtype: str = "bf16", fast_residual: Optional[bool] = None):
+                 weight_dtype: str = "bf16", fast_residual: Optional[bool] = None, fp8_activations: Optional[bool] = None):
         self._want_fast_residual = (os.environ.get("KARANTA_FAST_RESIDUAL", "0") == "1") if fast_residual is None else bool(fast_residual)
         if not torch.cuda.is_available():
             raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
@@ -305,6 +306,12 @@ class Engine:
         self.fp8 = weight_dtype == "fp8"
         # fp8 engine: prefill GEMMs read the fp8 codes (kr_gemm_fp8); KARANTA_FP8_PREFILL=0: their dequantised bf16 copy
         self.fp8_prefill_gemm = os.environ.get("KARANTA_FP8_PREFILL", "1") == "1"
+        # W8A8 prefill (fp8 engine): the activations entering the decoder's prefill GEMMs are quantised per token to e4m3
+        # (kr_quantize_rows_fp8) and the products run on the fp8 matrix instruction (kr_gemm_fp8a) — what vLLM does for the
+        # reference's OLMO_7B_0725_FP8.  Decode keeps bf16 activations (weight-only fp8).  KARANTA_FP8_ACT=0/1 overrides.
+        env = os.environ.get("KARANTA_FP8_ACT")
+        self.fp8_act = self.fp8 and self.fp8_prefill_gemm and (bool(fp8_activations) if fp8_activations is not None
+                                                              else (env == "1" if env is not None else FP8_ACT_DEFAULT))
         self._graphs: Dict[Tuple[int, bool], int] = {}
         self._prof_on = False
         self._prof_events: List[Tuple[C.c_void_p, C.c_void_p]] = []
@@ -346,6 +353,9 @@ class Engine:
         self.p_cos = z(M, t.head_dim, dtype=torch.float32)
         self.p_sin = z(M, t.head_dim, dtype=torch.float32)
         self.p_src = z(M, dtype=torch.int32)
+        if self.fp8_act:   # W8A8 prefill: the quantised A operand (row stride = the widest K) and its per-token scales
+            self.p_a8 = z(M, (max(t.intermediate_size, t.hidden_size, t.q_dim) + 15) // 16 * 16, dtype=torch.uint8)
+            self.p_as = z(M, dtype=torch.float32)
         self.gemm_scratch = z(GEMM_SCRATCH_BYTES // 4, dtype=torch.float32)   # kr_gemm_bf16_ws (KR_GEMM_SCRATCH_BYTES)
         # KV cache (zero-initialised: masked keys must be finite)
         self.kcache = z(t.num_layers, B, t.num_kv_heads, self.s_max, t.head_dim)
@@ -467,6 +477,13 @@ class Engine:
     # ------------------------------------------------------------------ small launch helpers
     def _gemm(self, A, W, C_, M, bias=None, res=None, epi=EPI_NONE, packed=False, w8=None, w_scale=None):
         N, K = W.shape
+        if w8 is not None and self.fp8_act:
+            # W8A8: per-token e4m3 codes of A (scale = max|row| / 448), both operands through v_mfma_f32_16x16x32_fp8_fp8
+            ldq = self.p_a8.stride(0)
+            self.L.kr_quantize_rows_fp8(ptr(A), A.stride(0), ptr(self.p_a8), ldq, ptr(self.p_as), M, K, self.s)
+            self.L.kr_gemm_fp8a(ptr(self.p_a8), ldq, ptr(self.p_as), ptr(w8), ptr(w_scale), ptr(bias), ptr(res),
+                                res.stride(0) if res is not None else 0, ptr(C_), C_.stride(0), M, N, K, epi, self.s)
+            return
         if w8 is not None and self.fp8_prefill_gemm:
             # fp8 engine: the prefill streams the SAME e4m3 codes + row scales the decode kernels read (kr_gemm_fp8)
             self.L.kr_gemm_fp8(ptr(A), A.stride(0), ptr(w8), ptr(w_scale), ptr(bias), ptr(res),

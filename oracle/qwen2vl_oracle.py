@@ -57,13 +57,40 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 
 class _Policy:
+    """"fp32" | "bf16" | "w8a8".  "w8a8" = "bf16" plus dynamic per-token fp8 (e4m3) quantisation of the activations that
+    enter the decoder's Linears during PREFILL — what the engine's W8A8 prefill computes (kr_quantize_rows_fp8 +
+    kr_gemm_fp8a) and what vLLM does for the reference's default checkpoint OLMO_7B_0725_FP8
+    (/root/reference/karanta/constants.py:23); the weights are whatever the caller passes (the dequantised fp8 state
+    dict); decode steps keep bf16 activations, as the engine's weight-only decode kernels do."""
+
     def __init__(self, name: str):
-        if name not in ("fp32", "bf16"):
+        if name not in ("fp32", "bf16", "w8a8"):
             raise ValueError(name)
-        self.name = name
+        self.act_fp8 = name == "w8a8"
+        self.name = "bf16" if name == "w8a8" else name
 
     def __call__(self, x: np.ndarray) -> np.ndarray:
         return bf16_round(x) if self.name == "bf16" else np.asarray(x, dtype=F32)
+
+
+def fp8_e4m3_round(x: np.ndarray) -> np.ndarray:
+    """Nearest OCP e4m3fn value (ties to the even mantissa), saturating at +-448: 3 mantissa bits above 2^-6, a fixed
+    step of 2^-9 below it (the subnormals).  Restated arithmetically, independently of the engine's integer version."""
+    x = np.asarray(x, dtype=np.float64)
+    mag = np.minimum(np.abs(x), 448.0)
+    _, e = np.frexp(mag)                       # mag = m * 2^e with m in [0.5, 1): the leading bit has weight 2^(e-1)
+    step = np.exp2(np.maximum(e - 1, -6) - 3.0)  # spacing of the e4m3 grid around mag
+    q = np.minimum(np.rint(mag / step) * step, 448.0)   # np.rint rounds half to even: the even multiple = the even mantissa
+    return np.copysign(q, x).astype(F32)
+
+
+def fake_quant_rows_fp8(x: np.ndarray) -> np.ndarray:
+    """Dynamic per-token fp8 quantisation and back: scale = max|row| / 448 in f32 (1 for an all-zero row),
+    value = e4m3(x / scale) * scale — the A operand of the engine's W8A8 GEMM as real numbers."""
+    x = np.asarray(x, dtype=F32)
+    amax = np.abs(x).max(axis=-1, keepdims=True)
+    scale = np.where(amax > 0, amax / F32(448.0), F32(1.0)).astype(F32)
+    return (fp8_e4m3_round((x / scale).astype(F32)) * scale).astype(F32)
 
 
 def _w(weights: Dict[str, np.ndarray], name: str) -> np.ndarray:
@@ -475,8 +502,9 @@ def decoder_layer(x: np.ndarray, li: int, weights, tcfg, cos, sin, cache: KVCach
     p = f"model.language_model.layers.{li}."
     B, S, d = x.shape
     H, KVH, hd = tcfg.num_heads, tcfg.num_kv_heads, tcfg.head_dim
+    aq = fake_quant_rows_fp8 if (pol.act_fp8 and S > 1) else (lambda t: t)   # W8A8 prefill: per-token fp8 activations
     h = rms_norm(x, _w(weights, p + "input_layernorm.weight"), tcfg.rms_norm_eps, pol)
-    h = pol(h)
+    h = aq(pol(h))
     q = pol(linear(h, _w(weights, p + "self_attn.q_proj.weight"), _w(weights, p + "self_attn.q_proj.bias")))
     k = pol(linear(h, _w(weights, p + "self_attn.k_proj.weight"), _w(weights, p + "self_attn.k_proj.bias")))
     v = pol(linear(h, _w(weights, p + "self_attn.v_proj.weight"), _w(weights, p + "self_attn.v_proj.bias")))
@@ -506,8 +534,8 @@ def decoder_layer(x: np.ndarray, li: int, weights, tcfg, cos, sin, cache: KVCach
     pr = pol(softmax_lastdim(sc))
     o = np.matmul(pr, vv_r).astype(F32)
     o = pol(o.transpose(0, 2, 1, 3).reshape(B, S, H * hd))
-    x = pol(x + linear(o, _w(weights, p + "self_attn.o_proj.weight")))
-    h2 = pol(rms_norm(x, _w(weights, p + "post_attention_layernorm.weight"), tcfg.rms_norm_eps, pol))
+    x = pol(x + linear(aq(o), _w(weights, p + "self_attn.o_proj.weight")))
+    h2 = aq(pol(rms_norm(x, _w(weights, p + "post_attention_layernorm.weight"), tcfg.rms_norm_eps, pol)))
     gate = linear(h2, _w(weights, p + "mlp.gate_proj.weight"))
     up = linear(h2, _w(weights, p + "mlp.up_proj.weight"))
     if pol.name == "bf16":
@@ -516,7 +544,7 @@ def decoder_layer(x: np.ndarray, li: int, weights, tcfg, cos, sin, cache: KVCach
         act = pol(silu(gate) * up)
     else:
         act = silu(gate) * up
-    x = pol(x + linear(act, _w(weights, p + "mlp.down_proj.weight")))
+    x = pol(x + linear(aq(act), _w(weights, p + "mlp.down_proj.weight")))
     return x
 
 
@@ -533,7 +561,7 @@ def decoder_forward(inputs_embeds: np.ndarray, position_ids: np.ndarray, weights
     (``[B,V]`` for the last position, or ``[B,S,V]``)."""
     pol = _Policy(policy)
     cos, sin = mrope_cos_sin(position_ids, tcfg.head_dim, tcfg.rope_theta, tcfg.mrope_section)
-    if policy == "bf16":
+    if pol.name == "bf16":
         cos, sin = pol(cos), pol(sin)  # HF casts cos/sin to x.dtype (:169)
     x = pol(inputs_embeds)
     for li in range(tcfg.num_layers):

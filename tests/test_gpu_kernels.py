@@ -1483,6 +1483,99 @@ def test_gemm_fp8_matches_dequantised_reference(L, epi):
         L.kr_gemm_fp8(ptr(Ad), K, ptr(qd), ptr(sd), 0, 0, 0, ptr(C_[:, 4:]), nc, M, N, K, epi, 0)    # C not 16-byte aligned
 
 
+@pytest.mark.parametrize("rows,K", [(1, 64), (37, 1536), (130, 3584), (9, 8960), (5, 18944), (3, 24576)])
+def test_quantize_rows_fp8_is_bit_identical_to_the_host_quantiser(L, rows, K):
+    """kr_quantize_rows_fp8 (dynamic per-token e4m3 codes of the W8A8 prefill): scales and codes equal
+    weights.quantize_fp8_rows bit for bit — rows of very different magnitude, an all-zero row, values on rounding ties
+    and in the subnormal range of the scaled row, row strides wider than K, bytes beyond K untouched."""
+    from karanta_ocr_amd import weights as W
+    rng = np.random.default_rng(rows + K)
+    x = bf16_round(rng.standard_normal((rows, K)).astype(np.float32) * rng.uniform(1e-3, 40, (rows, 1)).astype(np.float32))
+    x[0, :: 7] = bf16_round(x[0, 0] * 2.0 ** -rng.integers(0, 14, size=len(x[0, ::7])).astype(np.float32))   # down to the subnormals
+    if rows > 2:
+        x[1] = 0
+        x[2, :40] = bf16_round(np.linspace(-1, 1, 40).astype(np.float32) * np.abs(x[2]).max())                 # grid points and ties
+    ldx, ldq = K + 8, (K + 15) // 16 * 16 + 16
+    xd = dev_bf16(np.concatenate([x, np.full((rows, 8), 3.0, np.float32)], 1))
+    qd = torch.full((rows, ldq), 0xAB, dtype=torch.uint8, device=DEV)
+    sd = torch.zeros(rows, dtype=torch.float32, device=DEV)
+    L.kr_quantize_rows_fp8(ptr(xd), ldx, ptr(qd), ldq, ptr(sd), rows, K, 0)
+    q_ref, s_ref = W.quantize_fp8_rows(x)
+    got_q, got_s = qd.cpu().numpy(), sd.cpu().numpy()
+    np.testing.assert_array_equal(got_s, s_ref)
+    np.testing.assert_array_equal(got_q[:, :K], q_ref)
+    assert (got_q[:, K:] == 0xAB).all(), "bytes beyond K untouched"
+    with pytest.raises(KarantaHipError):
+        L.kr_quantize_rows_fp8(ptr(xd), ldx, ptr(qd), ldq, ptr(sd), rows, K + 4, 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (255, 256, 64), (257, 272, 192), (700, 528, 320), (2049, 768, 1280), (300, 1536, 8960)])
+def test_gemm_fp8a_exact_on_small_integers(L, M, N, K):
+    """kr_gemm_fp8a (both operands e4m3 codes through v_mfma_f32_16x16x32_fp8_fp8): integer activations and weights that are
+    exact in e4m3, power-of-two scales on both sides -> exact result.  Catches a k-order mismatch between the A and W
+    fragments, a wrong LDS swizzle of the 32-byte A rows, a wrong row / half address of the staging, a missing scale on
+    either side, a miscounted vmcnt (stale LDS tile)."""
+    from karanta_ocr_amd import weights as W
+    rng = np.random.default_rng(M + N + K + 19)
+    A = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    Wi = rng.integers(-8, 9, size=(N, K)).astype(np.float32)
+    if K > 256:
+        Wi[:, 200:] = 0
+        Wi[::5, K - 40:] = rng.integers(-1, 2, size=(len(Wi[::5]), 40))
+        A[::3, 100:180] = 1
+    Wi[:, 0] = 448
+    A[:, 0] = 0
+    A[:, 1] = 448                                                       # every row's max is 448: its scale is exactly its power of two
+    Wi[:, 1] = 0
+    a_pow = (2.0 ** rng.integers(-3, 2, size=M)).astype(np.float32)
+    w_pow = (2.0 ** rng.integers(-2, 3, size=N)).astype(np.float32)
+    Af, Wf = A * a_pow[:, None], Wi * w_pow[:, None]
+    qa, sa = W.quantize_fp8_rows(Af)
+    qw, sw = W.quantize_fp8_rows(Wf)
+    np.testing.assert_array_equal(W.fp8_e4m3_to_f32(qa) * sa[:, None], Af)
+    np.testing.assert_array_equal(W.fp8_e4m3_to_f32(qw) * sw[:, None], Wf)
+    lda = (K + 15) // 16 * 16 + 32
+    qa_pad = np.full((M, lda), 0x7E, np.uint8)                           # (a read beyond K would add 448s)
+    qa_pad[:, :K] = qa
+    ad, sad = torch.from_numpy(qa_pad).to(DEV), torch.from_numpy(sa).to(DEV)
+    qd, sd = torch.from_numpy(W.pack_w16x64_fp8(qw)).to(DEV), torch.from_numpy(sw).to(DEV)
+    ldc = (N + 7) // 8 * 8 + 8
+    C_ = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.kr_gemm_fp8a(ptr(ad), lda, ptr(sad), ptr(qd), ptr(sd), 0, 0, 0, ptr(C_), ldc, M, N, K, EPI_NONE, 0)
+    got = host(C_)
+    np.testing.assert_array_equal(got[:, :N], bf16_round(ref_linear(Af, Wf)))          # exact sums, one rounding
+    assert (got[:, N:] == 7.0).all(), "columns beyond N untouched"
+
+
+@pytest.mark.parametrize("epi", [EPI_NONE, EPI_SILU_MUL8])
+def test_quantize_then_gemm_fp8a_matches_the_fake_quantised_reference(L, epi):
+    """The W8A8 prefill pair as the engine runs it: kr_quantize_rows_fp8 on bf16 activations, kr_gemm_fp8a on the codes —
+    against the oracle's statement of it (fake_quant_rows_fp8 of A, dequantised W, f32 product), bias / residual /
+    SiLU*mul epilogues, a ragged M with a partial last tile."""
+    rng = np.random.default_rng(191 + epi)
+    from karanta_ocr_amd import weights as W
+    M, N, K = 1394, 2048 if epi == EPI_NONE else 1024, 1536
+    A, Wf = rnd(rng, M, K) * rng.uniform(0.2, 5, (M, 1)).astype(np.float32), rnd(rng, N, K, scale=K ** -0.5)
+    A = bf16_round(A)
+    bias = rnd(rng, N, scale=0.1)
+    res = rnd(rng, M, N) if epi == EPI_NONE else None
+    q, sc, ref = fp8_ref(O.fake_quant_rows_fp8(A), Wf, bias, res, epi)
+    Ad, qd, sd, bd = dev_bf16(A), torch.from_numpy(W.pack_w16x64_fp8(q)).to(DEV), torch.from_numpy(sc).to(DEV), dev_bf16(bias)
+    a8 = torch.zeros(M, K, dtype=torch.uint8, device=DEV)
+    a_s = torch.zeros(M, dtype=torch.float32, device=DEV)
+    nc = N // 2 if epi == EPI_SILU_MUL8 else N
+    C_ = torch.zeros(M, nc, dtype=torch.bfloat16, device=DEV)
+    rd = dev_bf16(res) if res is not None else None
+    L.kr_quantize_rows_fp8(ptr(Ad), K, ptr(a8), K, ptr(a_s), M, K, 0)
+    L.kr_gemm_fp8a(ptr(a8), K, ptr(a_s), ptr(qd), ptr(sd), ptr(bd), ptr(rd) if rd is not None else 0, N if rd is not None else 0,
+                   ptr(C_), nc, M, N, K, epi, 0)
+    assert_close_bf16(host(C_), ref, what=f"quantise + gemm fp8a epi {epi}")   # (ref_linear takes A as given: f64 product)
+    with pytest.raises(KarantaHipError):
+        L.kr_gemm_fp8a(ptr(a8), K, ptr(a_s), ptr(qd), ptr(sd), 0, 0, 0, ptr(C_), nc, M, N, K, EPI_QUICK_GELU, 0)
+    with pytest.raises(KarantaHipError):
+        L.kr_gemm_fp8a(ptr(a8), K + 8, ptr(a_s), ptr(qd), ptr(sd), 0, 0, 0, ptr(C_), nc, M, N, K, epi, 0)    # lda not a multiple of 16
+
+
 def test_gumbel_argmax_matches_oracle_noise(L):
     """kr_gumbel_argmax partials against the oracle's sample_scores: same counter-based noise (integer hash bit-exact,
     the two logs within float rounding), T = 0 rows untouched, ties to the lowest index, sampled frequencies follow

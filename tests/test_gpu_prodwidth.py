@@ -274,19 +274,21 @@ def test_full_size_qwen2_vl_2b_batch_of_8_properties(m2b_full):
 @pytest.mark.parametrize("weight_dtype", ["bf16", "fp8"])
 def test_7b_width_batch_of_4_matches_oracle(m7b, weight_dtype):
     """BASELINE.json config 3's per-GPU share (4 pages) at the 7B widths; fp8 = config 5's weight format, checked against
-    the oracle on the dequantised state dict (the same model, so the same tolerance and token rule)."""
+    the oracle on the dequantised state dict (the same model, so the same tolerance and token rule).  (The W8A8 prefill
+    has its own test below: its tolerance is another one.)"""
     cfg, w, cache = m7b
     ids, pv, grid = PW.page_inputs(cfg, 310, 1024, 1024, MAXPIX_A, 12, 25, 77)
     small = [PageRequest(*_pg(cfg, 311 + k, h, wd, 3 + k)) for k, (h, wd) in enumerate([(336, 448), (560, 420), (224, 224)])]
     pages = [small[0], small[1], PageRequest(ids, pv, [grid]), small[2]]
     steps = 10
     eng = Engine(cfg, max_batch=4, s_max=2048, max_patches=sum(len(p.pixel_values) for p in pages),
-                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=16, weight_dtype=weight_dtype)
+                 max_prompt_tokens=sum(len(p.input_ids) for p in pages), decode_splits=16,
+                 weight_dtype=weight_dtype)
     eng.load_weights(w)
     try:
-        assert eng.wide_mode and eng.narrow_mode and eng.defer_down
+        assert eng.wide_mode and eng.narrow_mode and eng.defer_down and not eng.fp8_act
         res = eng.generate(pages, steps, ignore_eos=True, return_logits=True)
-        wref = fp8_dequantized_weights(w, cfg) if weight_dtype == "fp8" else w
+        wref = fp8_dequantized_weights(w, cfg) if weight_dtype != "bf16" else w
         if "img" not in cache:
             cache["img"] = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
         o_tok, o_log = O.generate_greedy(cfg, wref, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True, return_logits=True,
@@ -309,6 +311,54 @@ def test_7b_width_batch_of_4_matches_oracle(m7b, weight_dtype):
         graph = eng.generate(pages, steps, ignore_eos=True)
         for a, b in zip(graph.tokens, res.tokens):
             np.testing.assert_array_equal(a, b)
+    finally:
+        eng.close()
+
+
+def test_7b_width_w8a8_prefill_against_the_w8a8_oracle(m7b):
+    """The W8A8 prefill (Engine(weight_dtype="fp8", fp8_activations=True): per-token e4m3 activations through
+    v_mfma_f32_16x16x32_fp8_fp8, kr_quantize_rows_fp8 + kr_gemm_fp8a; what vLLM runs for the reference's OLMO_7B_0725_FP8,
+    /root/reference/karanta/constants.py:23) at the 7B widths, one 1024x1024 page, against the oracle's "w8a8" policy.
+    The kernels themselves are pinned exactly (codes bit-identical to the host quantiser, integer GEMMs exact:
+    tests/test_gpu_kernels.py).  End to end the comparison cannot be as tight as the bf16-activation one: an e4m3 code has 3
+    mantissa bits, so a 1-ulp bf16 difference between the engine's and the oracle's hidden state flips ~7 % of the codes by
+    a whole 6 % step — noise of the size of the quantisation error itself, uncorrelated between the two runs.  Stated
+    tolerance: the engine is within TWICE the activation-quantisation effect (oracle w8a8 vs oracle with bf16 activations
+    on the same fp8 weights, measured in the same test) and within 10 % of the logit range, at the prefill and at every
+    teacher-forced decode step; the measured figures go to the report and DESIGN.md section 5f.  This is why bf16 activations
+    stay the engine's default for fp8 checkpoints."""
+    cfg, w, cache = m7b
+    ids, pv, grid = PW.page_inputs(cfg, 310, 1024, 1024, MAXPIX_A, 12, 25, 77)
+    page = PageRequest(ids, pv, [grid])
+    steps = 8
+    eng = Engine(cfg, max_batch=1, s_max=2048, max_patches=len(pv), max_prompt_tokens=len(ids), decode_splits=16, weight_dtype="fp8",
+                 fp8_activations=True)
+    eng.load_weights(w)
+    try:
+        assert eng.fp8_act and eng.wide_mode and eng.narrow_mode
+        wref = fp8_dequantized_weights(w, cfg)
+        if "img" not in cache:
+            cache["img"] = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+        oq_tok, oq_log = O.generate_greedy(cfg, wref, ids[None], None, [grid], steps, policy="w8a8", ignore_eos=True, return_logits=True,
+                                           image_embeds=cache["img"])
+        ob_tok, ob_log = O.generate_greedy(cfg, wref, ids[None], None, [grid], 1, policy="bf16", ignore_eos=True, return_logits=True,
+                                           image_embeds=cache["img"])
+        forced = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=oq_tok[:, :steps - 1])
+        rng_ = float(np.abs(oq_log[0, 0]).max())
+        q_eff = float(np.abs(oq_log[0, 0] - ob_log[0, 0]).max())             # what quantising the activations does to the logits
+        errs = [float(np.abs(forced.logits[0, i] - oq_log[0, i]).max()) for i in range(steps)]
+        e_bf = float(np.abs(forced.logits[0, 0] - ob_log[0, 0]).max())       # engine (W8A8) vs the bf16-activation oracle
+        m = PW.margins(oq_log[0])
+        agree = sum(int(forced.tokens[0][i]) == int(oq_tok[0, i]) for i in range(steps))
+        _record("7b_w_v2_l2_w8a8", logit_range=rng_, act_quant_effect=q_eff, engine_vs_w8a8_oracle=errs, engine_vs_bf16act_oracle=e_bf,
+                margins=m.tolist(), argmax_equal=agree, steps=steps)
+        assert max(errs) < 2.0 * q_eff and max(errs) < 0.10 * rng_, f"W8A8 logits off by {max(errs)} (quantisation effect {q_eff}, range {rng_})"
+        for i in range(steps):
+            if m[i] > 2 * max(errs):
+                assert int(forced.tokens[0][i]) == int(oq_tok[0, i]), f"step {i}"
+        graph = eng.generate([page], steps, ignore_eos=True)     # the W8A8 prefill feeds the same decode graph
+        free = eng.generate([page], steps, ignore_eos=True, use_graph=False)
+        np.testing.assert_array_equal(graph.tokens[0], free.tokens[0])
     finally:
         eng.close()
 
