@@ -58,6 +58,12 @@ const char* kr_last_error(void);
 int kr_device_info(int device, char* name64, int* compute_units, size_t* total_mem);
 int kr_set_device(int device);
 int kr_stream_synchronize(kr_stream s);
+/* A stream restricted to `cus_enabled` of the device's compute units (hipExtStreamCreateWithCUMask; the first cus_enabled
+ * bits of the mask: on an 8-XCD part cus_enabled / 8 CUs of every XCD).  The continuous-batching server runs its admissions
+ * (ViT + prefill: MFMA-bound, long-running workgroups) on such a stream beside the decode graph (HBM-bound, short
+ * launches) on the main one — the reference gets the same overlap from vLLM's chunked prefill.  kr_stream_destroy frees it. */
+int kr_stream_create_cu_mask(kr_stream* out, int cus_enabled);
+int kr_stream_destroy(kr_stream s);
 
 /* ------------------------------------------------------------------ profiling events
  * HIP events on the caller's stream, used by bench.py to time kernels on the stream they are
@@ -320,7 +326,8 @@ typedef struct kr_narrow_opts {
 
 /* Narrow decode linears (qkv, o_proj, down_proj): one workgroup per 16-row tile (ROPE_KV: per rotary tile
  * pair), K split over its `waves` (8 or 16; the norm prologue always runs 8) waves; x / norm weight / epilogue
- * operands are requested before the weights.  Modes PLAIN and ROPE_KV as kr_linear_decode.
+ * operands are requested before the weights.  Modes PLAIN and ROPE_KV as kr_linear_decode.  ROPE_KV with norm_w ==
+ * NULL: x is already normalised (kr_decode_resnorm) and its fragments are read straight from L2 (M up to 32, 8 waves).
  *   ksplit > 1 (PLAIN only): K is also split over `ksplit` workgroups and the reduction is DEFERRED: out_f32
  *     receives f32 slabs [ksplit][M][ldc] (no bias / residual / norm) — or, with opts->atomic_out, one slab the
  *     K ranges add into; the consumer adds them.
@@ -334,6 +341,16 @@ int kr_linear_decode_narrow(int mode, const kr_bf16* x, int64_t ldx, const float
                             const float* cs_table, int cs_stride, const int32_t* prompt_len, const int32_t* ctx_len,
                             kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads, int kv_heads, int s_max,
                             const kr_narrow_opts* opts, kr_stream s);
+
+/* Residual sum + RMSNorm ONCE for a decode batch (the form of batches above 16 rows):
+ *   x_new = bf16(x + part_in[0] + part_in[1] + ...)  (n_part_in slabs [n][part_rows][K] f32, in that order; part_rows 0 = M),
+ *   stored to x_out (ldxo; must not alias x; untouched when n_part_in == 0), and
+ *   h = norm_w * bf16(x_new * rsqrt(mean(x_new^2) + eps))  (Qwen2VLRMSNorm, TF:96-110) stored to h [M, ldh].
+ * One wave per row with the narrow NORM kernel's summation structure: the rows are bit-identical to the ones
+ * kr_linear_decode_narrow's fused prologue computes, so kr_linear_decode_narrow(ROPE_KV, x = h, norm_w = NULL) — x fragments
+ * straight from L2, no per-workgroup staging of 32 rows and their slabs — gives the fused launch's q / K / V bits. */
+int kr_decode_resnorm(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
+                      int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, kr_stream s);
 
 /* The same two kernels on fp8 (OCP e4m3fn) weights — BASELINE.json config 5: decoder Linears in fp8 with one f32 scale
  * per output row, activations bf16.  w_packed_fp8 = weights.pack_w16x64_fp8 (one 16-row x 64-column block = 1 KiB in

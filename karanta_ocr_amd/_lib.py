@@ -29,6 +29,8 @@ SIGNATURES = {
     "kr_device_info": [i32, C.c_char_p, C.POINTER(i32), C.POINTER(C.c_size_t)],
     "kr_set_device": [i32],
     "kr_stream_synchronize": [c_p],
+    "kr_stream_create_cu_mask": [C.POINTER(c_p), i32],
+    "kr_stream_destroy": [c_p],
     "kr_event_create": [C.POINTER(c_p)],
     "kr_event_destroy": [c_p],
     "kr_event_record": [c_p, c_p],
@@ -43,6 +45,7 @@ SIGNATURES = {
     "kr_layernorm": [c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
     "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p],
+    "kr_decode_resnorm": [c_p, i64, c_p, i32, i32, c_p, i64, c_p, f32, c_p, i64, i32, i32, c_p],
     "kr_quantize_rows_fp8": [c_p, i64, c_p, i64, c_p, i64, i32, c_p],
     "kr_gemm_fp8a": [c_p, i64, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
     "kr_gemm_bf16_ws": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p, C.c_size_t, c_p],

@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--admit", type=int, default=8, help="pages one admission may prefill together")
     ap.add_argument("--admit-min", type=int, default=4, help="free slots (and waiting requests) an admission waits for while others decode")
     ap.add_argument("--admit-max-wait", type=int, default=4, help="... but never longer than this many scheduler steps")
+    ap.add_argument("--overlap-cus", type=int, default=None,
+                    help="overlap admissions with decoding: ViT + prefill on a stream restricted to this many CUs "
+                         "(kr_stream_create_cu_mask; 0 = an ordinary second stream; unset = admissions interrupt the decode graph)")
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU front end")
     ap.add_argument("--guided", action="store_true", help="every request carries the pipeline's guided_regex")
     args = ap.parse_args()
@@ -61,10 +64,11 @@ def main():
     n_patch = int(np.prod(probe.grids[0]))
     B = args.slots
     eng = Engine(cfg, max_batch=B, s_max=(P + args.t_max + args.chunk + 64 + 63) // 64 * 64,
-                 max_patches=args.admit * n_patch, max_prompt_tokens=args.admit * P)
+                 max_patches=args.admit * n_patch, max_prompt_tokens=args.admit * P, admission_cus=args.overlap_cus or None)
     eng.load_weights(random_weights(cfg, 0, as_bits=True))
     srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=True, max_tokens_cap=args.t_max, chunk=args.chunk,
-                        honor_temperature=False, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait)
+                        honor_temperature=False, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait,
+                        overlap_admissions=args.overlap_cus is not None)
     port = 8791
     S.register_local_server(port, srv)
     guided = (r"---\nprimary_language: (?:[a-z]{2}|null)\nis_rotation_valid: (?:True|False|true|false)\n"
@@ -112,6 +116,7 @@ def main():
                     f"VLLMClient.generate -> LocalServer(continuous), {args.workers} worker threads, {B} decode slots, "
                     f"max_tokens U[{args.t_min},{args.t_max}] (mean {np.mean(limits):.0f}), prompt {P} tokens, "
                     f"admit_min {args.admit_min} (max wait {args.admit_max_wait} x {args.chunk} steps), "
+                    f"{'admissions interrupt the decode graph' if args.overlap_cus is None else 'admissions overlapped on ' + (str(args.overlap_cus) + ' CUs' if args.overlap_cus else 'an unmasked second stream')}, "
                     f"{'host PIL' if args.host_images else 'GPU'} image front end, {'guided_regex' if args.guided else 'greedy'}, "
                     f"random-init weights",
         "pages_per_s": round(args.pages / wall, 3), "tokens_per_s": round(sum(toks) / wall, 1), "wall_s": round(wall, 2),

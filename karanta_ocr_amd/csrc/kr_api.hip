@@ -41,6 +41,33 @@ int kr_stream_synchronize(kr_stream s) {
     return KR_OK;
 }
 
+// A stream whose kernels run on a SUBSET of the compute units (hipExtStreamCreateWithCUMask): the serving path puts the
+// admissions' ViT + prefill launches — long-running 256x256 GEMM / attention workgroups that otherwise fill every CU — on
+// `cus_enabled` of the device's CUs, so that the decode graph's short HBM-bound launches on the main stream always find free
+// CUs instead of queueing behind them (round 1 measured no gain from a second stream without a mask, for that reason).
+// Bit i of the mask = CU i in the runtime's numbering (on a multi-XCD part consecutive bits go round the XCDs, so the first
+// n bits take n / 8 CUs of every XCD).
+int kr_stream_create_cu_mask(kr_stream* out, int cus_enabled) {
+    KR_CHECK_ARG(out && cus_enabled > 0, "kr_stream_create_cu_mask: bad args");
+    int dev = 0, cus = 0;
+    KR_CHECK_HIP(hipGetDevice(&dev));
+    KR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    KR_CHECK_ARG(cus > 0 && cus_enabled <= cus, "kr_stream_create_cu_mask: %d of %d CUs", cus_enabled, cus);
+    const int words = (cus + 31) / 32;
+    uint32_t mask[32] = {0};
+    KR_CHECK_ARG(words <= 32, "kr_stream_create_cu_mask: %d CUs", cus);
+    for (int i = 0; i < cus_enabled; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    KR_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+    *out = reinterpret_cast<kr_stream>(st);
+    return KR_OK;
+}
+int kr_stream_destroy(kr_stream s) {
+    KR_CHECK_ARG(s, "kr_stream_destroy: the default stream");
+    KR_CHECK_HIP(hipStreamDestroy(kr_hs(s)));
+    return KR_OK;
+}
+
 int kr_event_create(void** ev) {
     KR_CHECK_ARG(ev, "kr_event_create: null");
     hipEvent_t e;

@@ -2347,10 +2347,18 @@ static int narrow_impl(int mode, const kr_bf16* x, int64_t ldx, const float* par
             return waves == 16 ? launch_narrow_direct<DEPI_PLAIN, 16>(a, ntiles, s)
                                : launch_narrow_direct<DEPI_PLAIN, 8>(a, ntiles, s);
         case DEPI_ROPE_KV:
-            KR_CHECK_ARG(norm_w && bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
+            KR_CHECK_ARG(bias && cs_table && prompt_len && ctx_len && q_out && kcache && vtcache && cs_stride > 0,
                          "kr_linear_decode_narrow: ROPE_KV pointers");
             KR_CHECK_ARG(N == (heads + 2 * kv_heads) * 128 && s_max % 64 == 0 && ksplit == 1,
                          "kr_linear_decode_narrow: ROPE_KV needs head_dim 128, ksplit 1");
+            if (!norm_w) {
+                // x is ALREADY normalised (kr_decode_resnorm ran the residual sum + RMSNorm once for the batch): the x
+                // fragments come straight from L2, no staging and no norm arithmetic per workgroup — the form of decode
+                // batches above 16 rows, where every one of the 64-144 workgroups used to stage 32 rows of x + slabs
+                KR_CHECK_ARG(!part_in && waves == 8, "kr_linear_decode_narrow: ROPE_KV without a norm takes no partial sums, 8 waves");
+                if (narrow_share(a, 8) <= 3) return launch_narrow_u<2, DEPI_ROPE_KV, 8, 0, 0, false, 3>(a, ntiles / 2, s);
+                return launch_narrow_u<2, DEPI_ROPE_KV, 8, 0, 0, false, 5>(a, ntiles / 2, s);
+            }
             return launch_narrow_norm<2, DEPI_ROPE_KV>(a, ntiles / 2, s);
         default:
             kr_set_error("kr_linear_decode_narrow: mode %d not supported (PLAIN, ROPE_KV)", mode);
@@ -2418,6 +2426,85 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     else
         attn_decode2_kernel<2><<<grid, 128, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
                                                            workspace, counters, (int)ws_bytes);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
+// ---- residual sum + RMSNorm ONCE per batch (decode batches above 16 rows)
+namespace {
+// x_new = bf16(x + slab_0 + slab_1 + ...) (in that order), h = norm_w * bf16(x_new * rsqrt(mean(x_new^2) + eps)).
+// One wave per row, lane l owns the 8-element chunks l, l + 64, ...: exactly the summation structure of the narrow NORM
+// kernel's prologue (dec_narrow_kernel, section 3), so the rows it writes are bit-identical to the ones that kernel
+// stages — a page's tokens stay independent of the batch it decodes in.
+template <int RL>
+__global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ parts,
+                                                          int n_part, int part_rows, kr_bf16* __restrict__ x_out, int64_t ldxo,
+                                                          const kr_bf16* __restrict__ norm_w, float eps, kr_bf16* __restrict__ h,
+                                                          int64_t ldh, int M, int K) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6), kc = K >> 3;
+    if (b >= M) return;
+    bf16x8 xv[RL], nw[RL];
+#pragma unroll
+    for (int i = 0; i < RL; ++i) {
+        const int c = lane + i * 64;
+        if (c < kc) {
+            xv[i] = ld8(x + (int64_t)b * ldx + c * 8);
+            nw[i] = ld8(norm_w + c * 8);
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) {
+        const int c = lane + i * 64;
+        if (c < kc) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bf2f(xv[i][j]);
+            for (int k = 0; k < n_part; ++k) {
+                const float* pp = parts + ((int64_t)k * part_rows + b) * K + c * 8;
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] += p0[j];
+                    v[4 + j] += p1[j];
+                }
+            }
+            if (n_part > 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[i][j] = f2bf(v[j]);
+                *reinterpret_cast<bf16x8*>(x_out + (int64_t)b * ldxo + c * 8) = xv[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += bf2f(xv[i][j]) * bf2f(xv[i][j]);
+        }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < RL; ++i) {
+        const int c = lane + i * 64;
+        if (c < kc) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[i][j]) * bfround(bf2f(xv[i][j]) * rs));
+            *reinterpret_cast<bf16x8*>(h + (int64_t)b * ldh + c * 8) = o;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int kr_decode_resnorm(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
+                                 int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, kr_stream s) {
+    KR_CHECK_ARG(x && norm_w && h, "kr_decode_resnorm: null pointer");
+    KR_CHECK_ARG(M >= 1 && M <= 32 && K > 0 && K % 8 == 0 && K <= 4096, "kr_decode_resnorm: M=%d K=%d (M <= 32, K %% 8, K <= 4096)", M, K);
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && ldh >= K && (ldh & 7) == 0, "kr_decode_resnorm: ldx / ldh");
+    KR_CHECK_ARG(n_part_in >= 0 && n_part_in <= 8 && (n_part_in == 0 || (part_in && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0)),
+                 "kr_decode_resnorm: partial sums need a separate x_out");
+    KR_CHECK_ARG(n_part_in == 0 || part_rows == 0 || part_rows >= M, "kr_decode_resnorm: part_rows %d < M %d", part_rows, M);
+    const int pr = part_rows > 0 ? part_rows : M, blocks = (M + 3) / 4;
+    if (K <= 1536) dec_resnorm_kernel<3><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K);
+    else if (K <= 2048) dec_resnorm_kernel<4><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K);
+    else dec_resnorm_kernel<8><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

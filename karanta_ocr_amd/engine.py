@@ -268,7 +268,8 @@ class DeviceGuide:
 class Engine:
     def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
                  max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 16,
-                 weight_dtype: str = "bf16", fast_residual: Optional[bool] = None, fp8_activations: Optional[bool] = None):
+                 weight_dtype: str = "bf16", fast_residual: Optional[bool] = None, fp8_activations: Optional[bool] = None,
+                 admission_cus: Optional[int] = None):
         self._want_fast_residual = (os.environ.get("KARANTA_FAST_RESIDUAL", "0") == "1") if fast_residual is None else bool(fast_residual)
         if not torch.cuda.is_available():
             raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
@@ -289,6 +290,12 @@ class Engine:
         self._guided = False          # the decode graph masks logits by the slots' DFA states and advances them
         self._logprobs = None         # None or k: the decode graph records log-probabilities (kr_logprobs_topk)
         self._adm_stream = None                          # second stream of the overlapped admission (slot mode)
+        # overlapped admissions run on a stream restricted to this many compute units (kr_stream_create_cu_mask), so the
+        # decode graph on the main stream always finds free CUs beside the admission's long-running workgroups; 0 / None: an
+        # ordinary second stream (round 1: no gain, the streams serialise).  KARANTA_ADMIT_CUS overrides.
+        env_cus = os.environ.get("KARANTA_ADMIT_CUS")
+        self.admission_cus = int(env_cus) if env_cus is not None else (int(admission_cus) if admission_cus else 0)
+        self._adm_stream_handle = None
         self._resample_cache: Dict[tuple, tuple] = {}   # (h, w, rh, rw) -> device tables of the GPU image front end
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
@@ -374,6 +381,7 @@ class Engine:
             self.down_waves_small = 8
         self.d_xacc = z(B, t.hidden_size, dtype=torch.float32)     # fast-residual mode: f32 residual accumulator
         self.d_qkv = z(B, t.qkv_dim)
+        self.d_h = z(B, t.hidden_size)   # batches above 16 rows: the normalised rows of kr_decode_resnorm (the qkv launch's x)
         self.d_q = z(B, t.num_heads, t.head_dim)
         self.d_o = z(B, t.q_dim)
         self.d_act = z(B, t.intermediate_size)
@@ -393,6 +401,7 @@ class Engine:
         # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
         # reduction deferred to the next layer's qkv prologue (K = 1536 / 2048 / 3584 only)
         self.attn_fused_merge = os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"
+        self.resnorm_qkv = os.environ.get("KARANTA_RESNORM_QKV", "1") == "1"   # > 16 rows: kr_decode_resnorm + one direct qkv launch
         self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
         self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
@@ -1152,7 +1161,21 @@ class Engine:
                 # this layer's down_proj will ADD into accumulator (i + 1) & 1: the (first) qkv launch zeroes it (it was last
                 # read by layer i - 1's qkv launch, which is complete)
                 zero = slabs[(i + 1) & 1] if (one_slab and i + 1 < nl) else None
-                if pending:
+                if B > 16 and self.resnorm_qkv and xacc is None and pf is None:
+                    # ABOVE 16 ROWS: the residual sum + RMSNorm run ONCE for the batch (kr_decode_resnorm: bit-identical rows),
+                    # then ONE qkv launch over all rows reads its x fragments straight from L2 — instead of every one of the
+                    # 64-144 workgroups staging 32 rows of x + slab (294 KB at the 2B width) and, at the 7B width, two launches
+                    # over 16-row ranges that stream the weights twice (r3 kernel trace, 7B at 32 rows: 2 x 15.8 us per layer)
+                    pin = (slabs[i & 1:(i & 1) + 1] if one_slab else slabs) if pending else None
+                    L.kr_decode_resnorm(ptr(x), x.stride(0), ptr(pin), int(pin.shape[0]) if pin is not None else 0, B,
+                                        ptr(x_other), x_other.stride(0), ptr(w.view(p + "ln1.w")), t.rms_norm_eps, ptr(self.d_h),
+                                        self.d_h.stride(0), B, t.hidden_size, s)
+                    if pending:
+                        x, x_other = x_other, x
+                        pending = False
+                    self._dec_narrow(DEC_ROPE_KV, self.d_h, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), kc=kc, vc=vc, zero=zero,
+                                     **self._w8kw(p + "qkv.w"))
+                elif pending:
                     for k, (r0, m) in enumerate(ranges):
                         pin = slabs[i & 1:(i & 1) + 1, r0:] if one_slab else slabs[:, r0:]
                         self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
@@ -1508,7 +1531,13 @@ class Engine:
         self._check_budgets(pages, budgets)
         slots = [int(j) for j in slots]
         if self._adm_stream is None:
-            self._adm_stream = torch.cuda.Stream(device=self.device)
+            if self.admission_cus > 0:
+                h = C.c_void_p()
+                self.L.kr_stream_create_cu_mask(C.byref(h), int(self.admission_cus))
+                self._adm_stream_handle = h
+                self._adm_stream = torch.cuda.ExternalStream(h.value, device=self.device)
+            else:
+                self._adm_stream = torch.cuda.Stream(device=self.device)
         park = np.asarray([self.s_max - 1], np.int32)
         with torch.cuda.stream(self.stream):
             for j in slots:
@@ -1596,3 +1625,8 @@ class Engine:
         for g in self._graphs.values():
             self.L.kr_graph_destroy(g)
         self._graphs.clear()
+        if self._adm_stream_handle is not None:
+            torch.cuda.synchronize(self.device)
+            self._adm_stream = None
+            self.L.kr_stream_destroy(self._adm_stream_handle)
+            self._adm_stream_handle = None

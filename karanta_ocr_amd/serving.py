@@ -313,7 +313,7 @@ class LocalServer:
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
                  batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
                  chunk: int = 16, honor_temperature: bool = True, max_logprobs: Optional[int] = None, admit_min: int = 1,
-                 admit_max_wait: int = 4):
+                 admit_max_wait: int = 4, overlap_admissions: bool = False):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
         self.honor_temperature = bool(honor_temperature)   # False: every request is served greedy
         # guided decoding needs the tokenizer's byte strings on the device; engines without set_vocab (test fakes)
@@ -327,6 +327,9 @@ class LocalServer:
         self.batch_wait_s, self.log = batch_wait_s, log
         self.continuous, self.max_tokens_cap, self.chunk = bool(continuous), int(max_tokens_cap), int(chunk)
         self.admit_min, self.admit_max_wait = int(admit_min), int(admit_max_wait)   # SlotScheduler's admission batching
+        # continuous mode: ViT + prefill of an admission on a second (CU-masked: Engine(admission_cus=...)) stream while the
+        # other slots keep decoding (SlotScheduler(overlap=True))
+        self.overlap_admissions = bool(overlap_admissions)
         self._q: "queue.Queue" = queue.Queue()
         self._running = 0
         self._stop = False
@@ -502,7 +505,7 @@ class LocalServer:
         try:
             sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature,
                                 guided=self.guided, logprobs=self.max_logprobs, admit_min=self.admit_min,
-                                admit_max_wait=self.admit_max_wait)
+                                admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions)
         except Exception as e:  # cannot enter slot mode: every request gets a 500
             sch, boot_error = None, f"{type(e).__name__}: {e}"
         last = (-1, -1)
@@ -540,7 +543,7 @@ class LocalServer:
                 try:
                     sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature,
                                         guided=self.guided, logprobs=self.max_logprobs, admit_min=self.admit_min,
-                                        admit_max_wait=self.admit_max_wait)
+                                        admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions)
                 except Exception as e2:
                     sch, boot_error = None, f"{type(e2).__name__}: {e2}"
                 continue

@@ -147,7 +147,7 @@ def test_image_token_mismatch_is_an_error(engines, tiny_models):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [False, True, "cu-mask"])
 @pytest.mark.parametrize("name", MODELS)
 def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name, overlap):
     """Continuous batching: 7 ragged requests through 3 slots (2 of the engine's 4 stay idle throughout) — every
@@ -171,13 +171,15 @@ def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name, overl
     # an EOS set that some of the free-running sequences hit early, some late, some never
     eos = (int(free[0][4]), int(free[3][9]), int(free[5][2]))
     cfg2 = dataclasses.replace(cfg, eos_token_ids=eos)
-    eng = Engine(cfg2, max_batch=3, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2)
+    # "cu-mask": the admission stream is restricted to 192 compute units (kr_stream_create_cu_mask): the serving path's form
+    eng = Engine(cfg2, max_batch=3, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2,
+                 admission_cus=192 if overlap == "cu-mask" else None)
     eng.load_weights(w)
     solo = [eng.generate([pg], mt) for pg, mt in zip(pages, limits)]
     # overlap: ViT + prefill of an admission on a second stream while the other slots keep decoding (target slots
     # parked on the last cache row meanwhile)
-    sch = SlotScheduler(eng, max_tokens_cap=20, chunk=3, overlap=overlap)
-    assert sch.overlap == overlap
+    sch = SlotScheduler(eng, max_tokens_cap=20, chunk=3, overlap=bool(overlap))
+    assert sch.overlap == bool(overlap)
     res = sch.run([SlotRequest(pg, mt, tag=i) for i, (pg, mt) in enumerate(zip(pages, limits))])
     assert [r.tag for r in res] == list(range(len(pages)))
     reasons = set()
@@ -188,6 +190,8 @@ def test_slot_scheduler_equals_solo_generation(engines, tiny_models, name, overl
         reasons.add(r.finish_reason)
     assert reasons == {"stop", "length"}, "the construction should exercise both ways out of a slot"
     assert sch.steps > 0 and sch.slot_steps_busy <= sch.steps * 3
+    if overlap == "cu-mask":
+        assert eng._adm_stream_handle is not None, "the admissions ran on the CU-masked stream"
     # static generate() still works on the same engine afterwards (leaves slot mode)
     again = eng.generate([pages[1]], limits[1])
     np.testing.assert_array_equal(again.tokens[0], solo[1].tokens[0])

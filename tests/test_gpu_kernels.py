@@ -1317,6 +1317,58 @@ def test_linear_narrow_rope_kv(L, H, KVH, K, parts, B):
     np.testing.assert_array_equal(gv, ref_v_all)
 
 
+@pytest.mark.parametrize("H,KVH,K,n_part", [(12, 2, 1536, 1), (28, 4, 3584, 1), (12, 2, 1536, 2), (28, 4, 3584, 0), (16, 2, 2048, 1),
+                                            (2, 1, 256, 0)])
+@pytest.mark.parametrize("B", [8, 21, 32])
+def test_resnorm_then_direct_qkv_gives_the_fused_launch_bits(L, H, KVH, K, n_part, B):
+    """Decode batches above 16 rows: kr_decode_resnorm (residual sum + RMSNorm once for the batch) followed by ONE
+    kr_linear_decode_narrow(ROPE_KV, norm_w = NULL) launch whose x fragments come straight from L2 — against the fused
+    launch (norm prologue, per 16-row range: what batches up to 16 rows run), BIT FOR BIT: x_new, q, the K-cache rows and
+    the V^T-cache columns.  That equality is what keeps a page's tokens independent of the batch size it decodes in.
+    At the 7B width (K = 3584) 32 rows do not fit the fused kernel's LDS: the fused reference runs per 16-row range."""
+    rng = np.random.default_rng(270 + H + B + n_part)
+    hd, s_max, T = 128, 256, 7
+    N = (H + 2 * KVH) * hd
+    plen = np.asarray([0, 3, 60, 64, 198] + list(rng.integers(0, 190, size=B - 5)), np.int32)
+    step = np.asarray([0, 2, 3, 0, 6] + list(rng.integers(0, T, size=B - 5)), np.int32)
+    ctxs = plen + step
+    x, W = rnd(rng, B, K, scale=2.0), rnd(rng, N, K, scale=K ** -0.5)
+    bias, nw = rnd(rng, N, scale=0.1), bf16_round(1 + 0.1 * rnd(rng, K))
+    p = (rng.standard_normal((max(n_part, 1), B, K)) * 0.5).astype(np.float32)
+    ang = rng.uniform(0, 6.28, size=(B, T, 64)).astype(np.float32)
+    cs = np.concatenate([bf16_round(np.cos(ang)), bf16_round(np.sin(ang))], -1).astype(np.float32)
+    kc = rnd(rng, B, KVH, s_max, hd); vt = rnd(rng, B, KVH, s_max // 64, hd, 64)
+    xd, Wd, bd, nd = dev_bf16(x), dev_bf16(pack_w16x64(W)), dev_bf16(bias), dev_bf16(nw)
+    pd = torch.from_numpy(p).to(DEV)
+    cs_d, ctx_d, pl_d = torch.from_numpy(cs).to(DEV), torch.from_numpy(ctxs).to(DEV), torch.from_numpy(plen).to(DEV)
+    out = {}
+    for form in ("fused", "resnorm"):
+        kc_d, vt_d = dev_bf16(kc), dev_bf16(vt)
+        q_d = torch.zeros(B, H, hd, dtype=torch.bfloat16, device=DEV)
+        xo = torch.full((B, K), 5.0, dtype=torch.bfloat16, device=DEV)
+        if form == "fused":
+            ranges = [(0, B)] if (B <= 16 or K <= 2048) else [(0, 16), (16, B - 16)]
+            for r0, m in ranges:
+                L.kr_linear_decode_narrow(DEC_ROPE_KV, ptr(xd[r0:]), K, ptr(pd[:, r0:]) if n_part else 0, n_part, ptr(xo[r0:]) if n_part else 0, K,
+                                          ptr(Wd), ptr(bd), ptr(nd), 1e-6, 0, 0, 0, 0, 0, m, N, K, 8, 1, ptr(cs_d[r0:]), T, ptr(pl_d[r0:]),
+                                          ptr(ctx_d[r0:]), ptr(q_d[r0:]), ptr(kc_d[r0:]), ptr(vt_d[r0:]), H, KVH, s_max,
+                                          narrow_opts(part_rows=B) if (n_part and len(ranges) > 1) else None, 0)
+        else:
+            h = torch.full((B, K + 8), 9.0, dtype=torch.bfloat16, device=DEV)
+            L.kr_decode_resnorm(ptr(xd), K, ptr(pd) if n_part else 0, n_part, B, ptr(xo) if n_part else 0, K, ptr(nd), 1e-6, ptr(h), K + 8, B, K, 0)
+            assert (host(h)[:, K:] == 9.0).all()
+            L.kr_linear_decode_narrow(DEC_ROPE_KV, ptr(h), K + 8, 0, 0, 0, 0, ptr(Wd), ptr(bd), 0, 1e-6, 0, 0, 0, 0, 0, B, N, K, 8, 1, ptr(cs_d), T,
+                                      ptr(pl_d), ptr(ctx_d), ptr(q_d), ptr(kc_d), ptr(vt_d), H, KVH, s_max, None, 0)
+        out[form] = (host(xo), host(q_d), host(kc_d), host(vt_d))
+    for a, b, what in zip(out["fused"], out["resnorm"], ("x_new", "q", "K cache", "V^T cache")):
+        np.testing.assert_array_equal(a, b, err_msg=what)
+    if n_part:      # and the values are right: the residual sum against numpy
+        ref_x = bf16_round(x + p[:n_part].sum(0, dtype=np.float32))
+        assert np.abs(out["resnorm"][0] - ref_x).max() <= np.abs(ref_x).max() * 2 ** -7
+    with pytest.raises(KarantaHipError):       # partial sums need a separate x_out
+        L.kr_decode_resnorm(ptr(xd), K, ptr(pd), 1, B, ptr(xd), K, ptr(nd), 1e-6, ptr(xd), K, B, K, 0)
+
+
 @pytest.mark.parametrize("h,w,rh,rw", [(100, 160, 56, 84), (60, 90, 140, 112), (308, 200, 308, 140), (56, 84, 56, 84),
                                        (17, 400, 28, 420), (1024, 1024, 980, 980)])
 def test_image_front_end_bit_exact_vs_pil_path(L, h, w, rh, rw):
