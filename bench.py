@@ -570,11 +570,12 @@ def main():
             # Linears are STORED as e4m3 codes (+ f32 row scales) and converted to bf16 in registers
             "dtype": "bf16" if args.weights == "bf16" else "fp8-weights/bf16", "data": "synthetic",
             "config": {
-                "workload": f"{cfg.name} {'bf16' if args.weights == 'bf16' else 'fp8-weight / bf16-activation'} greedy, batch={B} synthetic {args.page_width or args.page}x{args.page} pages per GPU, "
+                "workload": f"{cfg.name} {'bf16' if args.weights == 'bf16' else ('fp8-weight, W8A8 prefill / bf16-activation decode' if eng.fp8_act else 'fp8-weight / bf16-activation')} greedy, batch={B} synthetic {args.page_width or args.page}x{args.page} pages per GPU, "
                             f"max_pixels={args.max_pixels} (grid {grids[0][1]}x{grids[0][2]}, {n_img_tok[0]} image tokens), "
                             f"prompt P={P[0]} tokens, T_out={T_out} (ignore_eos), random-init weights",
                 "global_batch": world * B, "parallelism": f"dp{world}", "decode": "hipGraph replay" if not args.no_graph else "eager",
-                **({"prefill": "W8A8 (per-token e4m3 activations, v_mfma_f32_16x16x32_fp8_fp8)" if eng.fp8_act
+                **({"prefill": ("W8A8 (per-token e4m3 activations, " + ("v_mfma_f32_16x16x32_fp8_fp8)" if os.environ.get("KARANTA_FP8_MX") == "0"
+                                                                                  else "block-scaled v_mfma_scale_f32_32x32x64_f8f6f4)")) if eng.fp8_act
                     else "fp8 weights converted to bf16 in registers, bf16 MFMA"} if args.weights == "fp8" else {}),
                 **({"guided": "every page, pattern [\\s\\S]*"} if args.guided else {}),
                 **({"logprobs": args.logprobs} if args.logprobs is not None else {}),

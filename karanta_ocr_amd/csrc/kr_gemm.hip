@@ -464,8 +464,15 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
                                                         const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R,
                                                         int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
                                                         int tiles_n, unsigned nwg, const float* __restrict__ w_scale, int group_m,
-                                                        const float* __restrict__ a_scale = nullptr) {
+                                                        const float* __restrict__ a_scale = nullptr, int stagger = 0) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
+    // STAGGER (KARANTA_GEMM_STAGGER = n, experiment): every second workgroup of the FIRST round (one per CU) starts n x ~3.4 us
+    // late, so that for the rest of the launch half of the CUs are in their main loop while the other half run their
+    // prologue / epilogue bursts (all tiles take the same time: without it every round's 33 MB of C stores and its
+    // pipeline fills hit the memory system together)
+    if (stagger > 0 && blockIdx.x < 256u && ((blockIdx.x >> 3) & 1u)) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     constexpr int NT = 4, MT = 8, A_BYTES = 256 * PK * 2;
     const uint8_t* W8p = reinterpret_cast<const uint8_t*>(W);
     const uint8_t* A8p = reinterpret_cast<const uint8_t*>(A);
@@ -625,6 +632,251 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, fr, fg, smem + wave * (128 * 128));
 }
 
+// -------------------------------------------------------------------------------------
+// gemm_pipe_mx_kernel: W8A8 on the BLOCK-SCALED fp8 matrix instruction, v_mfma_scale_f32_32x32x64_f8f6f4 — the CDNA4 fp8 pipe
+// at twice the bf16 rate (64 cycles for a 32x32x64 product against 32 for 32x32x16 bf16: MI355X_MICROARCH.md, matrix cores).
+// The same pipeline as gemm_pipe_kernel (256x256 tile, 8 waves x (128 x 64), four 32 KiB LDS buffers, two phases per K-tile,
+// counted vmcnt, staggered wave rows), with K-tiles of 64 codes: an e4m3 row of a K-tile is 64 bytes — the bf16 kernel's LDS
+// geometry — and one MFMA consumes the whole K-tile.  Block scales: both operands carry E8M0 127 (= 2^0) for every 32-code
+// block; the REAL scales (one f32 per row of A from kr_quantize_rows_fp8, one per row of W) multiply the f32 accumulators before
+// the epilogue, as in kr_gemm_fp8a.
+//   A image : 64-byte rows, 16-byte chunk c of row r at slot c ^ ((r >> 2) & 3): lane (row r = lane & 31, h = lane >> 5) reads
+//             chunks 2h, 2h+1 with two ds_read_b128, whose 16-lane groups ({0-3,12-15,20-27}, ...) then hit 16 distinct slots;
+//   W image : the decode layout's 1 KiB blocks as they are ([16-row block][k-group][row][16 B]): lane (r, h) reads k-groups 2h, 2h+1
+//             of block r >> 4 — conflict-free as stored.  Lane (., h) holds the same 32 k of both operands (k-groups 2h, 2h+1),
+//             which is all a dot product needs.
+//   C layout: 32x32 accumulators, column (the A row m) on the lane, rows (the W row n) 8 (i >> 2) + 4 h + (i & 3) in register i —
+//             a 16-row group of n keeps its SiLU gate rows (4h + j) and their up rows (8 + 4h + j) in the same lane.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ void stage_a8_rows64(const uint8_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_total, int k0,
+                                                char* lds_op, int lane, int wave) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // the two 128-row halves: each wave fills one 16-row block (1 KiB) of each
+        const int r = h * 128 + wave * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((lane >> 4) & 3);   // = (r >> 2) & 3: the 16-row block base is a multiple of 16
+        int64_t gr = row0 + r;
+        gr = gr < rows_total ? gr : rows_total - 1;
+        const uint8_t* src = g + gr * ld + k0 + c * 16;
+        char* dst = lds_op + (h * 128 + wave * 16) * 64;  // wave-uniform; the hardware adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void stage_w8_rows64(const uint8_t* __restrict__ g, int K, int n0, int N, int k0, char* lds_op, int lane,
+                                                int wave) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // 16 row blocks of 1 KiB: wave w stages blocks 2w, 2w + 1
+        int rb = (n0 >> 4) + 2 * wave + h;
+        rb = min(rb, (N >> 4) - 1);
+        const uint8_t* src = g + ((int64_t)rb * (K >> 6) + (k0 >> 6)) * 1024 + lane * 16;
+        char* dst = lds_op + (2 * wave + h) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm_pipe_mx_kernel(const uint8_t* __restrict__ A8p, int64_t lda, const uint8_t* __restrict__ W8p,
+                                                           const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R, int64_t ldr,
+                                                           kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K, int tiles_n,
+                                                           unsigned nwg, const float* __restrict__ w_scale, int group_m,
+                                                           const float* __restrict__ a_scale) {
+    constexpr int NT = 2, MT = 4, XK = 64, A_BYTES = 256 * XK, XBUF = 2 * A_BYTES;   // 32 KiB per stage, 4 stages
+    constexpr int ONE = 0x7f7f7f7f;   // E8M0 127 in every byte: block scale 2^0
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int cl = lane & 31, h = lane >> 5;
+    const unsigned wg = xcd_remap(blockIdx.x, nwg);
+    unsigned tm, tn;
+    tile_coords(wg, (unsigned)((M + 255) >> 8), (unsigned)tiles_n, (unsigned)group_m, tm, tn);
+    const int64_t m0 = (int64_t)tm * 256;
+    const int n0 = (int)tn * 256;
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = K / XK;
+    // fragment read offsets inside a buffer
+    const int a_off = (wr * 128 + cl) * 64 + ((((2 * h) ^ ((cl >> 2) & 3))) << 4);      // chunk 2h; chunk 2h+1 is the slot ^ 1
+    const int a_off2 = (wr * 128 + cl) * 64 + ((((2 * h + 1) ^ ((cl >> 2) & 3))) << 4);
+    const int w_off = A_BYTES + (wc * 4 + (cl >> 4)) * 1024 + (2 * h) * 256 + (cl & 15) * 16;   // k-group 2h; 2h+1 is + 256
+
+    // ---- prologue: K-tiles 0..2 requested, K-tile 0 landed and visible (4 loads per K-tile and wave)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (t < nk) {
+            char* buf = smem + t * XBUF;
+            stage_w8_rows64(W8p, K, n0, N, t * XK, buf + A_BYTES, lane, wave);
+            stage_a8_rows64(A8p, lda, m0, M, t * XK, buf, lane, wave);
+        }
+    }
+    if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
+
+    for (int k = 0; k < nk; ++k) {
+        const char* cur = smem + (k & 3) * XBUF;
+        char* nxt = smem + ((k + 3) & 3) * XBUF;
+        const bool more = k + 3 < nk;
+        // ---------------- phase 0: W fragments (2 n-tiles of 32) + A m-tiles 0, 1
+        u32x4 wq[NT][2], xq[2][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            wq[t][0] = *reinterpret_cast<const u32x4*>(cur + w_off + t * 2048);
+            wq[t][1] = *reinterpret_cast<const u32x4*>(cur + w_off + t * 2048 + 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xq[t][0] = *reinterpret_cast<const u32x4*>(cur + a_off + t * 32 * 64);
+            xq[t][1] = *reinterpret_cast<const u32x4*>(cur + a_off2 + t * 32 * 64);
+        }
+        if (more) stage_w8_rows64(W8p, K, n0, N, (k + 3) * XK, nxt + A_BYTES, lane, wave);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        i32x8 wf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wf[t][e] = (int)wq[t][0][e];
+                wf[t][4 + e] = (int)wq[t][1][e];
+            }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            i32x8 xf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xf[e] = (int)xq[mt][0][e];
+                xf[4 + e] = (int)xq[mt][1][e];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[nt], xf, acc[nt][mt], 0, 0, 0, ONE, 0, ONE);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 1: A m-tiles 2, 3; the counted wait of this K-tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xq[t][0] = *reinterpret_cast<const u32x4*>(cur + a_off + (2 + t) * 32 * 64);
+            xq[t][1] = *reinterpret_cast<const u32x4*>(cur + a_off2 + (2 + t) * 32 * 64);
+        }
+        if (more) stage_a8_rows64(A8p, lda, m0, M, (k + 3) * XK, nxt, lane, wave);
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // K-tile k+1 landed; k+2 and k+3 may stay in flight
+        else if (k + 3 == nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            i32x8 xf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xf[e] = (int)xq[mt][0][e];
+                xf[4 + e] = (int)xq[mt][1][e];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][2 + mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[nt], xf, acc[nt][2 + mt], 0, 0, 0, ONE, 0, ONE);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier
+
+    // ---- epilogue: scales, bias / residual or SiLU*mul, bf16, through the wave's 16 KiB of LDS, whole-line stores
+    constexpr bool HALF = EPI == KR_EPI_SILU_MUL8;
+    constexpr int ROWB = HALF ? 64 : 128;
+    char* const wlds = smem + wave * (128 * 128);
+    const int64_t m_base = m0 + wr * 128;
+    const int n_base = n0 + wc * 64;
+    auto swz = [](int r) { return HALF ? ((r >> 1) & 3) : (r & 7); };
+    float as[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = m_base + mt * 32 + cl;
+        as[mt] = a_scale[m < M ? m : M - 1];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // register quad q: n = n_base + nt*32 + 8q + 4h + j
+            const int nq = n_base + nt * 32 + 8 * q + 4 * h;
+            const int ncl = min(nq, N - 4);
+            const f32x4 ws4 = *reinterpret_cast<const f32x4*>(w_scale + ncl);
+            const bf16x4 bv = bias ? *reinterpret_cast<const bf16x4*>(bias + ncl) : bf16x4{};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][mt][4 * q + j] = acc[nt][mt][4 * q + j] * ws4[j] * as[mt] + bf2f(bv[j]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = mt * 32 + cl;               // row inside the wave's 128
+        const int64_t m = m_base + r;
+        const int64_t mc = m < M ? m : M - 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (HALF) {
+#pragma unroll
+                for (int k16 = 0; k16 < 2; ++k16) {   // 16-row group: gate rows in quad 2 k16, their up rows in quad 2 k16 + 1
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[nt][mt][8 * k16 + j]) * acc[nt][mt][8 * k16 + 4 + j]);
+                    const int cc = nt * 2 + k16;      // 16-byte chunk (8 outputs) of the 64-byte scratch row; this lane's half: h
+                    *reinterpret_cast<bf16x4*>(wlds + r * ROWB + ((cc ^ swz(r)) << 4) + h * 8) = o;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nq = n_base + nt * 32 + 8 * q + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j];
+                    if (R) {
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + mc * ldr + min(nq, N - 4));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += bf2f(rv[j]);
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+                    const int cc = nt * 4 + q;
+                    *reinterpret_cast<bf16x4*>(wlds + r * ROWB + ((cc ^ swz(r)) << 4) + h * 8) = o;
+                }
+            }
+        }
+    }
+    {   // same wave, in-order LDS: its reads see its writes
+        constexpr int LPR = ROWB / 16, RPI = 64 / LPR;   // lanes per row, rows per instruction
+        const int n_out = HALF ? (n_base >> 1) : n_base, n_lim = HALF ? (N >> 1) : N;
+#pragma unroll
+        for (int it = 0; it < 128 / RPI; ++it) {
+            const int r = it * RPI + lane / LPR, c = lane % LPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + r * ROWB + ((c ^ swz(r)) << 4));
+            const int64_t m = m_base + r;
+            const int n = n_out + c * 8;
+            if (m < M && n < n_lim) *reinterpret_cast<u32x4*>(C + m * ldc + n) = v;
+        }
+    }
+}
+
 template <int EPI, bool WPACK>
 int launch_gemm_tail(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R, int64_t ldr,
                      kr_bf16* C, int64_t ldc, int64_t M, int N, int K, int ptiles_n, unsigned tile0, unsigned n_tiles, int group_m,
@@ -669,8 +921,10 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     // 32 ids is already a compact patch and groups are neutral (proj, down_proj) or worse (ViT fc2, K = 5120: 467 -> 495)
     const char* genv = getenv("KARANTA_GEMM_GROUP_M");
     const int group_m = genv ? atoi(genv) : (tiles_n >= 8 ? 8 : 1);
+    const char* senv = getenv("KARANTA_GEMM_STAGGER");
+    const int stagger = senv ? atoi(senv) : 0;
     gemm_pipe_kernel<EPI, WPACK, W8, A8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
-                                                                                (unsigned)nwg, w_scale, group_m, a_scale);
+                                                                                (unsigned)nwg, w_scale, group_m, a_scale, stagger);
     KR_CHECK_LAUNCH();
     if constexpr (!W8) {
         if (tail)
@@ -680,6 +934,26 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
 }
 
 inline int kr_cu_count();
+
+template <int EPI>
+int launch_gemm_pipe_mx(const uint8_t* A8, int64_t lda, const uint8_t* W8, const kr_bf16* bias, const kr_bf16* R, int64_t ldr, kr_bf16* C,
+                        int64_t ldc, int64_t M, int N, int K, kr_stream s, const float* w_scale, const float* a_scale) {
+    constexpr int LDS = 4 * 32768;
+    const int64_t tiles_m = (M + 255) / 256;
+    const int tiles_n = (N + 255) / 256;
+    const int64_t nwg = tiles_m * tiles_n;
+    KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_fp8a: grid too large");
+    static KrPerDeviceOnce attr_set;
+    if (attr_set.need()) {
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_mx_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
+    const char* genv = getenv("KARANTA_GEMM_GROUP_M");
+    const int group_m = genv ? atoi(genv) : (tiles_n >= 8 ? 8 : 1);
+    gemm_pipe_mx_kernel<EPI><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A8, lda, W8, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg, w_scale,
+                                                                    group_m, a_scale);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
 
 template <int EPI, bool WPACK, typename G, int STAGES>
 int launch_gemm_kernel(unsigned nwg, const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_bf16* bias, const kr_bf16* R,
@@ -926,12 +1200,19 @@ extern "C" int kr_gemm_fp8a(const uint8_t* A8, int64_t lda, const float* a_scale
     if (M == 0) return KR_OK;
     const kr_bf16* Ap = reinterpret_cast<const kr_bf16*>(A8);
     const kr_bf16* Wp = reinterpret_cast<const kr_bf16*>(w_packed_fp8);
+    // KARANTA_FP8_MX (read per call: the tests flip it): 1 (default) = the block-scaled instruction v_mfma_scale_f32_32x32x64_f8f6f4
+    // (twice the bf16 rate); 0 = v_mfma_f32_16x16x32_fp8_fp8 in the bf16 kernel's pipeline (the bf16 rate).  Same products
+    // (exact in f32), another summation order.
+    const char* mxe = getenv("KARANTA_FP8_MX");
+    const bool mx = !(mxe && atoi(mxe) == 0) && N % 32 == 0;
     switch (epilogue) {
         case KR_EPI_NONE:
             KR_CHECK_ARG(ldc >= N, "kr_gemm_fp8a: ldc < N");
+            if (mx) return launch_gemm_pipe_mx<KR_EPI_NONE>(A8, lda, w_packed_fp8, bias, residual, ldr, C, ldc, M, N, K, s, w_scale, a_scale);
             return launch_gemm_pipe<KR_EPI_NONE, true, true, true>(Ap, lda, Wp, bias, residual, ldr, C, ldc, M, N, K, s, w_scale, a_scale);
         case KR_EPI_SILU_MUL8:
             KR_CHECK_ARG(ldc >= N / 2 && !residual, "kr_gemm_fp8a: SILU_MUL8 takes no residual");
+            if (mx) return launch_gemm_pipe_mx<KR_EPI_SILU_MUL8>(A8, lda, w_packed_fp8, bias, residual, ldr, C, ldc, M, N, K, s, w_scale, a_scale);
             return launch_gemm_pipe<KR_EPI_SILU_MUL8, true, true, true>(Ap, lda, Wp, bias, residual, ldr, C, ldc, M, N, K, s, w_scale, a_scale);
         default:
             kr_set_error("kr_gemm_fp8a: epilogue %d (NONE and SILU_MUL8 only: the decoder's prefill linears)", epilogue);

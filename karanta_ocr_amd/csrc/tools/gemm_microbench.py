@@ -7,6 +7,7 @@ from karanta_ocr_amd._lib import EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8, lib, p
 
 L = lib()
 dev = "cuda:0"
+SCRATCH = torch.zeros(512 * 65536 // 4, dtype=torch.float32, device=dev)
 st = torch.cuda.Stream()
 S = st.cuda_stream
 SHAPES = [("vit qkv", 39200, 3840, 1280, EPI_NONE, 0), ("vit proj", 39200, 1280, 1280, EPI_NONE, 0),
@@ -30,7 +31,8 @@ def run(name, M, N, K, epi, packed, reps=5):
                 ("+ groups of 4", 512, 0, 4), ("+ groups of 8", 512, 0, 8), ("+ groups of 16", 512, 0, 16),
                 ("groups + tail, 2-buffer 128 kernel", 512, 1, None, 2), ("groups + unsplit deep-ring tail", 512, 1, None, 4, 1), ("default (groups where >= 8 n tiles, tail split, deep ring)", 512, 1, None),
                 ("automatic tile, 2-buffer", 0, 1, None, 2), ("automatic tile (default)", 0, 1, None)]
-    call = lambda: L.kr_gemm_bf16(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed, S)
+    call = lambda: L.kr_gemm_bf16_ws(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed,
+                                     ptr(SCRATCH), SCRATCH.numel() * 4, S)   # with the caller-owned split-K scratch, as the engine calls it
     for label, tile, tail, gm, *st in variants:
         if tile:
             os.environ["KARANTA_GEMM_TILE"] = str(tile)
@@ -62,6 +64,30 @@ def run(name, M, N, K, epi, packed, reps=5):
 
 if __name__ == "__main__":
     torch.zeros(1, device=dev)
+    if len(sys.argv) > 1 and sys.argv[1] == "stagger":   # KARANTA_GEMM_STAGGER sweep on the default configuration
+        import itertools
+        for name, M, N, K, epi, packed in SHAPES:
+            a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16(); w = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
+            nc = N // 2 if epi == EPI_SILU_MUL8 else N
+            c = torch.empty(M, nc, device=dev, dtype=torch.bfloat16); bias = torch.zeros(N, device=dev, dtype=torch.bfloat16)
+            e0, e1 = C.c_void_p(), C.c_void_p(); L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
+            res = []
+            for sg in (0, 2, 4, 6, 8, 0):
+                os.environ["KARANTA_GEMM_STAGGER"] = str(sg)
+                call = lambda: L.kr_gemm_bf16_ws(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi,
+                                                 packed, ptr(SCRATCH), SCRATCH.numel() * 4, S)
+                call(); torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(5):
+                    L.kr_event_record(e0, S)
+                    for _ in range(3):
+                        call()
+                    L.kr_event_record(e1, S); L.kr_event_synchronize(e1)
+                    ms = C.c_float(); L.kr_event_elapsed_ms(e0, e1, C.byref(ms)); best = min(best, ms.value / 3)
+                res.append(f"stagger {sg}: {best*1e3:7.1f} us {2.0*M*N*K/best/1e9:5.0f} TF/s")
+            print(f"{name:16s} " + " | ".join(res), flush=True)
+        os.environ.pop("KARANTA_GEMM_STAGGER", None)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "square":   # the shapes GEMM kernels are usually quoted on
         SHAPES = [("4096^3", 4096, 4096, 4096, EPI_NONE, 0), ("8192^3", 8192, 8192, 8192, EPI_NONE, 0),
                   ("16384x4096x4096", 16384, 4096, 4096, EPI_NONE, 0)]

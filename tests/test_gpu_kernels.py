@@ -1561,8 +1561,19 @@ def test_quantize_rows_fp8_is_bit_identical_to_the_host_quantiser(L, rows, K):
         L.kr_quantize_rows_fp8(ptr(xd), ldx, ptr(qd), ldq, ptr(sd), rows, K + 4, 0)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (255, 256, 64), (257, 272, 192), (700, 528, 320), (2049, 768, 1280), (300, 1536, 8960)])
-def test_gemm_fp8a_exact_on_small_integers(L, M, N, K):
+@pytest.fixture(params=[1, 0], ids=["mx-scaled-32x32x64", "fp8-16x16x32"])
+def fp8_mx(request):
+    """Both instruction forms of kr_gemm_fp8a: KARANTA_FP8_MX = 1 (default: v_mfma_scale_f32_32x32x64_f8f6f4, block scales 2^0,
+    twice the bf16 rate) and 0 (v_mfma_f32_16x16x32_fp8_fp8 in the bf16 kernel's pipeline)."""
+    import os
+    os.environ["KARANTA_FP8_MX"] = str(request.param)
+    yield request.param
+    os.environ.pop("KARANTA_FP8_MX", None)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 32, 64), (255, 256, 64), (257, 288, 192), (700, 544, 320), (2049, 768, 1280), (300, 1536, 8960),
+                                   (130, 16, 128)])
+def test_gemm_fp8a_exact_on_small_integers(L, fp8_mx, M, N, K):
     """kr_gemm_fp8a (both operands e4m3 codes through v_mfma_f32_16x16x32_fp8_fp8): integer activations and weights that are
     exact in e4m3, power-of-two scales on both sides -> exact result.  Catches a k-order mismatch between the A and W
     fragments, a wrong LDS swizzle of the 32-byte A rows, a wrong row / half address of the staging, a missing scale on
@@ -1600,7 +1611,7 @@ def test_gemm_fp8a_exact_on_small_integers(L, M, N, K):
 
 
 @pytest.mark.parametrize("epi", [EPI_NONE, EPI_SILU_MUL8])
-def test_quantize_then_gemm_fp8a_matches_the_fake_quantised_reference(L, epi):
+def test_quantize_then_gemm_fp8a_matches_the_fake_quantised_reference(L, fp8_mx, epi):
     """The W8A8 prefill pair as the engine runs it: kr_quantize_rows_fp8 on bf16 activations, kr_gemm_fp8a on the codes —
     against the oracle's statement of it (fake_quant_rows_fp8 of A, dequantised W, f32 product), bias / residual /
     SiLU*mul epilogues, a ragged M with a partial last tile."""
