@@ -2275,7 +2275,7 @@ def test_linear_narrow_x32_also_leaves_x_new_as_f32(L, M, K, parts):
     out_a = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV); out_b = torch.zeros_like(out_a)
     L.kr_linear_decode_narrow_x32(DEC_PLAIN, ptr(xd), K, ptr(pd) if parts else 0, 2 if parts else 0, ptr(xo) if parts else 0,
                                   K if parts else 0, ptr(xf), K + 4, ptr(Wd), 0, 0, ptr(nd), 1e-6, 0, 0, ptr(out_a), 0, N, M, N, K, 8, 1,
-                                  0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0)
+                                  0, 0, 0, 0, 0, 0, 0, 0, 0, 64, None, 0, 0, 0, 0)   # (no opts, no prefetch workgroups)
     narrow_call(L, DEC_PLAIN, ptr(xd), ptr(Wd), M, N, K, out=ptr(out_b), ldc=N, norm_w=ptr(nd), part_in=ptr(pd) if parts else 0,
                 x_out=ptr(xo) if parts else 0)
     torch.cuda.synchronize()
