@@ -401,7 +401,6 @@ class Engine:
         # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
         # reduction deferred to the next layer's qkv prologue (K = 1536 / 2048 / 3584 only)
         self.attn_fused_merge = os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"
-        self.resnorm_qkv = os.environ.get("KARANTA_RESNORM_QKV", "1") == "1"   # > 16 rows: kr_decode_resnorm + one direct qkv launch
         self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
         self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
@@ -422,6 +421,11 @@ class Engine:
         # still read once) and the qkv launch, whose norm prologue keeps whole rows per wave, runs ONCE PER 16-ROW RANGE
         # (33 MB of 14 GB streamed twice); o_proj / down_proj read their x fragments straight from L2 on two column tiles.
         self.row_split = self.B > 16 and t.hidden_size > 2048
+        # > 16 rows: kr_decode_resnorm + ONE direct qkv launch.  On where the fused launch would have to run per 16-row range
+        # (the 7B width: 4.73 -> 4.47 ms per step); at widths whose 32 rows fit the fused launch's LDS it is 1 % slower
+        # (Qwen2-VL-2B, same-box A/B: 1.957 vs 1.979 ms) and stays off.  KARANTA_RESNORM_QKV = 0 / 1 forces either.
+        env_rn = os.environ.get("KARANTA_RESNORM_QKV")
+        self.resnorm_qkv = (env_rn == "1") if env_rn is not None else self.row_split
         if self.row_split and t.hidden_size != 3584:
             raise KarantaHipError("max_batch > 16: hidden_size <= 2048 or == 3584 (the 7B width) only")
         self.fast_residual = self.fast_residual and self.wide_mode and not self.row_split

@@ -331,22 +331,29 @@ def test_fp8_weight_engine_matches_oracle_on_dequantised_weights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny-w512", "tiny-w3584"])
-def test_batches_above_16_rows_equal_solo_generation(name):
+@pytest.mark.parametrize("name", ["tiny-w512", "tiny-w3584", "tiny-w512+resnorm"])
+def test_batches_above_16_rows_equal_solo_generation(name, monkeypatch):
     """max_batch up to 32: 21 ragged pages decoded together give each page the tokens it gets alone; the slot scheduler
     runs 20 slots.  tiny-w512: two 16-row column tiles per weight fragment, all x rows in LDS (hidden_size <= 2048).
     tiny-w3584 (the 7B decoder width, BASELINE config 3's 32-rows-per-GPU variant): 32 x rows of 3584 do not fit the LDS,
     gate/up and lm_head stage K in two halves (dec_wide_kh_kernel), the qkv launch runs once per 16-row range, o_proj /
-    down_proj on two column tiles."""
+    down_proj on two column tiles; round 3: there the residual sum + RMSNorm run once (kr_decode_resnorm) and ONE direct qkv
+    launch covers all rows.  "+resnorm": that two-launch form forced on at the width where the fused launch is the default."""
     from karanta_ocr_amd._lib import KarantaHipError
     from karanta_ocr_amd.config import CONFIGS
     from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
     from karanta_ocr_amd.weights import random_weights
+    if name.endswith("+resnorm"):
+        name = name[:-len("+resnorm")]
+        monkeypatch.setenv("KARANTA_RESNORM_QKV", "1")
+        want_resnorm = True
+    else:
+        want_resnorm = name == "tiny-w3584"
     cfg = CONFIGS[name]
     w = random_weights(cfg, 909)
     eng = Engine(cfg, max_batch=21, s_max=512, max_patches=4096, max_prompt_tokens=4096, decode_splits=2)
     eng.load_weights(w)
-    assert eng.row_split == (name == "tiny-w3584") and eng.defer_down == (name == "tiny-w3584")
+    assert eng.row_split == (name == "tiny-w3584") and eng.defer_down == (name == "tiny-w3584") and eng.resnorm_qkv == want_resnorm
     rng = np.random.default_rng(77)
     pages = []
     for i in range(21):
