@@ -41,3 +41,60 @@ def test_a_failing_rank_fails_the_run():
 def test_world_size_mismatch_is_refused():
     r = _run(["--gpus", "2", "--dry-run"], WORLD_SIZE="1", RANK="0")
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_parity_block_compares_a_teacher_forced_engine_run_with_the_oracle_run():
+    """bench.py's `parity` entry (BASELINE.md's parity statement on every driver record): the engine is re-run TEACHER-FORCED
+    with the oracle's tokens, every step's logits compare, argmax equality is required on the decisive steps only.  A fake
+    engine stands in for the GPU: logits = the oracle's plus a known perturbation."""
+    import types
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    rng = np.random.default_rng(3)
+    steps, V = 9, 400
+    o_log = rng.standard_normal((steps, V)).astype(np.float32)
+    o_log[np.arange(steps), rng.integers(0, V, steps)] += 6.0          # a clear winner at every step
+    o_log[4] = 0.0
+    o_log[4, 7], o_log[4, 9] = 5.0, 4.9999                             # ... except a near-tie at step 4
+    o_tok = o_log.argmax(-1)
+    seen = {}
+
+    class FakeEngine:
+        def generate(self, pages, n, ignore_eos, return_logits, force_tokens):
+            seen.update(n=n, forced=np.asarray(force_tokens))
+            lg = o_log + 0.01
+            lg[4, 9] += 0.05                                           # the near-tie flips: allowed
+            return types.SimpleNamespace(logits=lg[None], tokens=[lg.argmax(-1)])
+
+    out = bench.parity_block(FakeEngine(), object(), {"tokens": o_tok, "logits": o_log})
+    assert seen["n"] == steps and seen["forced"].shape == (1, steps - 1) and (seen["forced"][0] == o_tok[:-1]).all()
+    assert out["pass"] is True and out["argmax_equal"] == "8/9" and out["decisive_steps"] == 8 and out["decisive_argmax_equal"] == "8/8"
+    assert 0.05 < out["max_abs_dlogit"] < 0.07 and out["tol_rel"] == bench.PARITY_TOL_REL
+
+    class WrongEngine(FakeEngine):
+        def generate(self, *a, **k):
+            r = FakeEngine.generate(self, *a, **k)
+            r.logits[0, 2] = -r.logits[0, 2]                           # a decisive step goes wrong
+            r.tokens = [r.logits[0].argmax(-1)]
+            return r
+
+    assert bench.parity_block(WrongEngine(), object(), {"tokens": o_tok, "logits": o_log})["pass"] is False
+
+
+def test_committed_pmc_traffic_is_quoted_only_on_the_kernel_source_it_was_measured_on(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed rocprofv3 --pmc pass; the file carries the hash of the
+    decode kernels' source and bench.py drops the figure (with the reason) when the tree's kernels differ."""
+    sys.path.insert(0, ROOT)
+    import bench
+    got, src = bench.pmc_traffic()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+    if committed["kernel_source_sha16"] == bench.kernel_source_sha16():
+        assert got and 0.9 < got / 55221248 < 1.2 and src == "profiles/r03_pmc_traffic.json"   # ~ the algorithmic bytes
+        assert os.path.exists(os.path.join(ROOT, committed["raw_csv"])), "the raw counter CSV is kept beside the summary"
+    else:
+        assert got is None and "another kr_decode.hip" in src
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda: "0" * 16)           # the kernels changed since the pass
+    got, why = bench.pmc_traffic()
+    assert got is None and "not quoted" in why
