@@ -678,7 +678,7 @@ __device__ __forceinline__ void stage_w8_rows64(const uint8_t* __restrict__ g, i
     }
 }
 
-template <int EPI>
+template <int EPI, bool TWO>
 __global__ void __launch_bounds__(512) gemm_pipe_mx_kernel(const uint8_t* __restrict__ A8p, int64_t lda, const uint8_t* __restrict__ W8p,
                                                            const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R, int64_t ldr,
                                                            kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K, int tiles_n,
@@ -711,6 +711,113 @@ __global__ void __launch_bounds__(512) gemm_pipe_mx_kernel(const uint8_t* __rest
     const int a_off2 = (wr * 128 + cl) * 64 + ((((2 * h + 1) ^ ((cl >> 2) & 3))) << 4);
     const int w_off = A_BYTES + (wc * 4 + (cl >> 4)) * 1024 + (2 * h) * 256 + (cl & 15) * 16;   // k-group 2h; 2h+1 is + 256
 
+    if constexpr (TWO) {
+        // TWO K-tiles per barrier pair (K % 128 == 0): the matrix bursts between two barriers are 8 MFMAs = 512 cycles instead of
+        // 256, against the same ~185 cycles a barrier interval costs besides its burst (both pipelined kernels measured 0.55-0.60
+        // MFMA-busy with 256-cycle bursts: profiles/r03_pmc_sq_fp8_gemm.txt).  The four LDS buffers are two PAIRS: an iteration reads
+        // the pair holding K-tiles 2i, 2i+1 and, in its first phase, restages the other pair (last read one iteration ago: its W
+        // rows five barriers, its last A rows three barriers earlier) with K-tiles 2i+2, 2i+3 — one whole iteration to land, drained
+        // (vmcnt(0): nothing else is in flight) before the iteration's last barrier.
+        const int ni = nk >> 1;
+        {
+            stage_w8_rows64(W8p, K, n0, N, 0, smem + A_BYTES, lane, wave);
+            stage_a8_rows64(A8p, lda, m0, M, 0, smem, lane, wave);
+            stage_w8_rows64(W8p, K, n0, N, XK, smem + XBUF + A_BYTES, lane, wave);
+            stage_a8_rows64(A8p, lda, m0, M, XK, smem + XBUF, lane, wave);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
+        for (int i = 0; i < ni; ++i) {
+            const char* cur = smem + (i & 1) * 2 * XBUF;
+            char* oth = smem + ((i + 1) & 1) * 2 * XBUF;
+            const bool more = i + 1 < ni;
+            // ---------------- phase 0: W fragments of both K-tiles + A m-tiles 0, 1 of both; the other pair is restaged
+            u32x4 wq[2][NT][2], xq[2][2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    wq[kt][t][0] = *reinterpret_cast<const u32x4*>(cur + kt * XBUF + w_off + t * 2048);
+                    wq[kt][t][1] = *reinterpret_cast<const u32x4*>(cur + kt * XBUF + w_off + t * 2048 + 256);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    xq[kt][t][0] = *reinterpret_cast<const u32x4*>(cur + kt * XBUF + a_off + t * 32 * 64);
+                    xq[kt][t][1] = *reinterpret_cast<const u32x4*>(cur + kt * XBUF + a_off2 + t * 32 * 64);
+                }
+            if (more) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    stage_w8_rows64(W8p, K, n0, N, (2 * i + 2 + kt) * XK, oth + kt * XBUF + A_BYTES, lane, wave);
+                    stage_a8_rows64(A8p, lda, m0, M, (2 * i + 2 + kt) * XK, oth + kt * XBUF, lane, wave);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            i32x8 wf[2][NT];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        wf[kt][t][e] = (int)wq[kt][t][0][e];
+                        wf[kt][t][4 + e] = (int)wq[kt][t][1][e];
+                    }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    i32x8 xf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xf[e] = (int)xq[kt][mt][0][e];
+                        xf[4 + e] = (int)xq[kt][mt][1][e];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[kt][nt], xf, acc[nt][mt], 0, 0, 0, ONE, 0, ONE);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- phase 1: A m-tiles 2, 3 of both K-tiles; the restaged pair must have landed
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    xq[kt][t][0] = *reinterpret_cast<const u32x4*>(cur + kt * XBUF + a_off + (2 + t) * 32 * 64);
+                    xq[kt][t][1] = *reinterpret_cast<const u32x4*>(cur + kt * XBUF + a_off2 + (2 + t) * 32 * 64);
+                }
+            // WAR: the OTHER wave row restages this pair right after the barrier below (its phase 0 of the next iteration runs
+            // one barrier ahead or behind): these reads — the pair's last — must have COMPLETED, not just been issued, when
+            // this wave arrives, so the LDS wait sits in front of the barrier here (the reading row has the slack: its
+            // partner is in a 512-cycle burst)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    i32x8 xf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xf[e] = (int)xq[kt][mt][0][e];
+                        xf[4 + e] = (int)xq[kt][mt][1][e];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][2 + mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[kt][nt], xf, acc[nt][2 + mt], 0, 0, 0, ONE, 0, ONE);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
     // ---- prologue: K-tiles 0..2 requested, K-tile 0 landed and visible (4 loads per K-tile and wave)
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -797,6 +904,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_mx_kernel(const uint8_t* __rest
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
+    }   // !TWO
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier
 
     // ---- epilogue: scales, bias / residual or SiLU*mul, bf16, through the wave's 16 KiB of LDS, whole-line stores
@@ -935,6 +1043,8 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
 
 inline int kr_cu_count();
 
+constexpr bool MX_TWO_DEFAULT = false;   // set by measurement (profiles/r03_fp8_gemm_bench.txt)
+
 template <int EPI>
 int launch_gemm_pipe_mx(const uint8_t* A8, int64_t lda, const uint8_t* W8, const kr_bf16* bias, const kr_bf16* R, int64_t ldr, kr_bf16* C,
                         int64_t ldc, int64_t M, int N, int K, kr_stream s, const float* w_scale, const float* a_scale) {
@@ -945,12 +1055,19 @@ int launch_gemm_pipe_mx(const uint8_t* A8, int64_t lda, const uint8_t* W8, const
     KR_CHECK_ARG(nwg < (1ll << 31), "kr_gemm_fp8a: grid too large");
     static KrPerDeviceOnce attr_set;
     if (attr_set.need()) {
-        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_mx_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_mx_kernel<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_mx_kernel<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     const char* genv = getenv("KARANTA_GEMM_GROUP_M");
     const int group_m = genv ? atoi(genv) : (tiles_n >= 8 ? 8 : 1);
-    gemm_pipe_mx_kernel<EPI><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A8, lda, W8, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg, w_scale,
-                                                                    group_m, a_scale);
+    const char* tenv = getenv("KARANTA_FP8_MX2");   // 1: two K-tiles per barrier pair where K % 128 == 0 (A/B, tests flip it)
+    const bool two = (tenv ? atoi(tenv) != 0 : MX_TWO_DEFAULT) && (K % 128) == 0;
+    if (two)
+        gemm_pipe_mx_kernel<EPI, true><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A8, lda, W8, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg,
+                                                                              w_scale, group_m, a_scale);
+    else
+        gemm_pipe_mx_kernel<EPI, false><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A8, lda, W8, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg,
+                                                                               w_scale, group_m, a_scale);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }

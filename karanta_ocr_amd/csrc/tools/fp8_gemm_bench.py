@@ -42,10 +42,11 @@ for name, N, K, epi in SHAPES:
     r = {}
     r["W8A16 (bf16 MFMA)"] = timed(lambda: L.kr_gemm_fp8(ptr(a), K, ptr(w8), ptr(ws), 0, 0, 0, ptr(c), nc, M, N, K, epi, S))
     r["quantise rows"] = timed(lambda: L.kr_quantize_rows_fp8(ptr(a), K, ptr(a8), K, ptr(a_s), M, K, S))
-    for mx, label in ((0, "W8A8 16x16x32 fp8"), (1, "W8A8 scaled 32x32x64")):
-        os.environ["KARANTA_FP8_MX"] = str(mx)
+    for mx, two, label in ((0, 0, "W8A8 16x16x32 fp8"), (1, 0, "W8A8 scaled 32x32x64"), (1, 1, "scaled, 2 K-tiles per barrier pair")):
+        os.environ["KARANTA_FP8_MX"], os.environ["KARANTA_FP8_MX2"] = str(mx), str(two)
         r[label] = timed(lambda: L.kr_gemm_fp8a(ptr(a8), K, ptr(a_s), ptr(w8), ptr(ws), 0, 0, 0, ptr(c), nc, M, N, K, epi, S))
     os.environ.pop("KARANTA_FP8_MX", None)
+    os.environ.pop("KARANTA_FP8_MX2", None)
     fl = 2.0 * M * N * K
     print(f"{name:8s} M={M} N={N} K={K}: " + " | ".join(f"{k} {v:8.1f} us" + (f" {fl / v / 1e6:5.0f} TF/s" if "quant" not in k else "") for k, v in r.items()),
           flush=True)

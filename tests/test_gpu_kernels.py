@@ -1561,18 +1561,20 @@ def test_quantize_rows_fp8_is_bit_identical_to_the_host_quantiser(L, rows, K):
         L.kr_quantize_rows_fp8(ptr(xd), ldx, ptr(qd), ldq, ptr(sd), rows, K + 4, 0)
 
 
-@pytest.fixture(params=[1, 0], ids=["mx-scaled-32x32x64", "fp8-16x16x32"])
+@pytest.fixture(params=[(1, 0), (1, 1), (0, 0)], ids=["mx-scaled-32x32x64", "mx-scaled-two-k-tiles-per-barrier-pair", "fp8-16x16x32"])
 def fp8_mx(request):
-    """Both instruction forms of kr_gemm_fp8a: KARANTA_FP8_MX = 1 (default: v_mfma_scale_f32_32x32x64_f8f6f4, block scales 2^0,
-    twice the bf16 rate) and 0 (v_mfma_f32_16x16x32_fp8_fp8 in the bf16 kernel's pipeline)."""
+    """The instruction forms of kr_gemm_fp8a: KARANTA_FP8_MX = 1 (default: v_mfma_scale_f32_32x32x64_f8f6f4, block scales 2^0,
+    twice the bf16 rate; KARANTA_FP8_MX2 = 1: two K-tiles per barrier pair where K % 128 == 0) and 0 (v_mfma_f32_16x16x32_fp8_fp8
+    in the bf16 kernel's pipeline)."""
     import os
-    os.environ["KARANTA_FP8_MX"] = str(request.param)
+    os.environ["KARANTA_FP8_MX"], os.environ["KARANTA_FP8_MX2"] = str(request.param[0]), str(request.param[1])
     yield request.param
     os.environ.pop("KARANTA_FP8_MX", None)
+    os.environ.pop("KARANTA_FP8_MX2", None)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 32, 64), (255, 256, 64), (257, 288, 192), (700, 544, 320), (2049, 768, 1280), (300, 1536, 8960),
-                                   (130, 16, 128)])
+                                   (130, 16, 128), (513, 320, 128), (300, 256, 3584)])
 def test_gemm_fp8a_exact_on_small_integers(L, fp8_mx, M, N, K):
     """kr_gemm_fp8a (both operands e4m3 codes through v_mfma_f32_16x16x32_fp8_fp8): integer activations and weights that are
     exact in e4m3, power-of-two scales on both sides -> exact result.  Catches a k-order mismatch between the A and W
