@@ -331,7 +331,7 @@ def test_fp8_weight_engine_matches_oracle_on_dequantised_weights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny-w512", "tiny-w3584", "tiny-w512+resnorm"])
+@pytest.mark.parametrize("name", ["tiny-w512", "tiny-w3584", "tiny-w512+resnorm", "tiny-w3584+fp8"])
 def test_batches_above_16_rows_equal_solo_generation(name, monkeypatch):
     """max_batch up to 32: 21 ragged pages decoded together give each page the tokens it gets alone; the slot scheduler
     runs 20 slots.  tiny-w512: two 16-row column tiles per weight fragment, all x rows in LDS (hidden_size <= 2048).
@@ -343,6 +343,9 @@ def test_batches_above_16_rows_equal_solo_generation(name, monkeypatch):
     from karanta_ocr_amd.config import CONFIGS
     from karanta_ocr_amd.scheduler import SlotRequest, SlotScheduler
     from karanta_ocr_amd.weights import random_weights
+    weight_dtype = "bf16"
+    if name.endswith("+fp8"):          # fp8 weights through the same >16-row launches (direct qkv on e4m3 codes)
+        name, weight_dtype = name[:-len("+fp8")], "fp8"
     if name.endswith("+resnorm"):
         name = name[:-len("+resnorm")]
         monkeypatch.setenv("KARANTA_RESNORM_QKV", "1")
@@ -351,8 +354,11 @@ def test_batches_above_16_rows_equal_solo_generation(name, monkeypatch):
         want_resnorm = name == "tiny-w3584"
     cfg = CONFIGS[name]
     w = random_weights(cfg, 909)
-    eng = Engine(cfg, max_batch=21, s_max=512, max_patches=4096, max_prompt_tokens=4096, decode_splits=2)
+    eng = Engine(cfg, max_batch=21, s_max=512, max_patches=4096, max_prompt_tokens=4096, decode_splits=2, weight_dtype=weight_dtype)
     eng.load_weights(w)
+    if weight_dtype == "fp8":
+        from karanta_ocr_amd.weights import fp8_dequantized_weights
+        w = fp8_dequantized_weights(w, cfg)      # what the oracle comparison below runs on
     assert eng.row_split == (name == "tiny-w3584") and eng.defer_down == (name == "tiny-w3584") and eng.resnorm_qkv == want_resnorm
     rng = np.random.default_rng(77)
     pages = []
