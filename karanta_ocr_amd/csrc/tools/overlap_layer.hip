@@ -13,7 +13,10 @@
 //           draining their write-through (sc1) stores, polled by one lane per consumer workgroup; the activation is read with
 //           16-byte sc1 loads (MI355X_MICROARCH.md, visibility: valid forms, row 1);
 //   mode 2: the same three branches with NO dependency at all (the concurrency ceiling: pure HBM time);
-//   mode 3: two branches — small on one, big + mid in stream order on the other (big -> mid is a kernel boundary).
+//   mode 3: two branches — small on one, big + mid in stream order on the other (big -> mid is a kernel boundary);
+//   mode 4, 5: mode 1 with a PACED prefetch: a waiting kernel requests its weights four 1 KiB pieces at a time with an s_sleep
+//           between the groups (~8 / ~16 us for a whole gate/up tile), so that the memory system never holds the whole stage's
+//           requests at once — the throttled-loader form of a persistent engine, at launch level.
 // After n layers every element of x must equal 3 n: a stale read or a broken dependency shows as a wrong count.  Every spin
 // is bounded (err[0] = 1 on timeout: the run is reported as failed, nothing hangs).
 // Build: hipcc -O3 --offload-arch=gfx950 overlap_layer.hip -o /tmp/overlap_layer
@@ -34,7 +37,7 @@ constexpr int SPIN_MAX = 1 << 18;
 template <int NCH, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) stage_kernel(const char* __restrict__ W, size_t wave_bytes_stride, const char* x_in, char* x_out,
                                                            const unsigned* wait_cnt, unsigned wait_n, unsigned* sig_cnt, int flags, int* err,
-                                                           unsigned long long* stamps) {
+                                                           unsigned long long* stamps, int pace) {
     extern __shared__ __attribute__((aligned(16))) char xs[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t widx = (size_t)blockIdx.x * WAVES + wave;
@@ -42,7 +45,14 @@ __global__ void __launch_bounds__(WAVES * 64) stage_kernel(const char* __restric
     u32x4 wbuf[NCH];
     const char* wp = W + widx * wave_bytes_stride + lane * 16;
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) wbuf[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)u * 1024));
+    for (int u = 0; u < NCH; ++u) {
+        wbuf[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)u * 1024));
+        if (pace > 0 && (u & 3) == 3) {            // paced prefetch: a pause after every 4 KiB per wave
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < pace; ++q) __builtin_amdgcn_s_sleep(32);   // ~2048 cycles ~ 0.9 us per unit
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     // 2. the dependency: one lane polls ONE counter
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (stamps && tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
@@ -117,10 +127,12 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<NB, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, XB));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<NM, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, XB));
     std::vector<float> hx(XB / 4);
-    const char* names[4] = {"one stream (kernel boundaries)                 ", "three branches + counters + sc1 activations      ",
-                            "three branches, NO dependency (HBM ceiling)     ", "two branches (small | big -> mid) + counters     "};
-    for (int mode = 0; mode < 4; ++mode) {
-        const int flags = (mode == 1 || mode == 3) ? 1 : 0;
+    const char* names[6] = {"one stream (kernel boundaries)                 ", "three branches + counters + sc1 activations      ",
+                            "three branches, NO dependency (HBM ceiling)     ", "two branches (small | big -> mid) + counters     ",
+                            "three branches + counters, prefetch paced ~8 us ", "three branches + counters, prefetch paced ~16 us"};
+    for (int mode = 0; mode < 6; ++mode) {
+        const int flags = (mode == 1 || mode >= 3) ? 1 : 0;
+        const int pace = mode == 4 ? 1 : mode == 5 ? 2 : 0;
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s[0], hipStreamCaptureModeThreadLocal));
         if (mode) {
@@ -130,14 +142,14 @@ int main(int argc, char** argv) {
         // kernel k of the chain (k = 3 i + stage) reads x[k & 1], writes x[(k + 1) & 1], waits on counter k - 1, signals counter k
         for (int i = 0; i < n; ++i) {
             const int l = i % L, k = 3 * i;
-            hipStream_t sa = s[0], sb = mode ? s[1] : s[0], sc = (mode == 1 || mode == 2) ? s[2] : sb;
+            hipStream_t sa = s[0], sb = mode ? s[1] : s[0], sc = (mode == 1 || mode == 2 || mode >= 4) ? s[2] : sb;
             stage_kernel<NS, 8><<<96, 512, XB, sa>>>(Ws + (size_t)l * small_b, (size_t)NS * 1024, x[k & 1], x[(k + 1) & 1], cnt + (k > 0 ? k - 1 : 0),
-                                                      (flags && k > 0) ? 192u : 0u, cnt + k, flags, err, stamps + (size_t)(k) * 16);
+                                                      (flags && k > 0) ? 192u : 0u, cnt + k, flags, err, stamps + (size_t)(k) * 16, 0);
             stage_kernel<NB, 5><<<224, 320, XB, sb>>>(Wb + (size_t)l * big_b, (size_t)NB * 1024, x[(k + 1) & 1], x[k & 1], cnt + k, flags ? 96u : 0u,
-                                                      cnt + k + 1, flags, err, stamps + (size_t)(k + 1) * 16);
+                                                      cnt + k + 1, flags, err, stamps + (size_t)(k + 1) * 16, pace);
             // mode 3: mid follows big in stream order: no counter wait, plain loads would do — kept sc1 for equal code
             stage_kernel<NM, 8><<<192, 512, XB, sc>>>(Wm + (size_t)l * mid_b, (size_t)NM * 1024, x[k & 1], x[(k + 1) & 1], cnt + k + 1,
-                                                      (flags && mode != 3) ? 224u : 0u, cnt + k + 2, flags, err, stamps + (size_t)(k + 2) * 16);
+                                                      (flags && mode != 3) ? 224u : 0u, cnt + k + 2, flags, err, stamps + (size_t)(k + 2) * 16, pace);
         }
         if (mode) {
             CK(hipEventRecord(join1, s[1])); CK(hipStreamWaitEvent(s[0], join1, 0));
@@ -161,7 +173,7 @@ int main(int argc, char** argv) {
         }
         printf("%s: %d layers, %.2f us per layer (%.2f TB/s of weights), wrong outputs %d, spin timeout %d\n", names[mode], n, best * 1e3 / n,
                (double)(small_b + big_b + mid_b) / (best * 1e-3 / n) / 1e12, bad, herr[0]);
-        if (mode == 1 || mode == 0) {   // stamps of workgroup 0 of the last layers: wait / read / compute shares (100 MHz ticks)
+        if (mode == 1 || mode == 0 || mode >= 4) {   // stamps of workgroup 0 of the last layers: wait / read / compute shares (100 MHz ticks)
             std::vector<unsigned long long> st(3 * n * 16);
             CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
             for (int st_k = 0; st_k < 3; ++st_k) {
