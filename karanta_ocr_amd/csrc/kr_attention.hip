@@ -170,6 +170,9 @@ extern "C" int kr_attn_debug_read(unsigned long long* out) {
 #ifndef KR_ATTN_VPRE
 #define KR_ATTN_VPRE(HD) ((HD) == 80 ? 3 : 0)
 #endif
+#ifndef KR_PIPE_VPRE
+#define KR_PIPE_VPRE 1   // pipelined kernel: V^T fragments read one step ahead of their PV
+#endif
 template <int HD>
 struct AttnCfg {
     static constexpr int KS = HD / 16;               // QK^T k-steps
@@ -563,6 +566,382 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
         }
 }
 
+#ifdef KR_ATTN_PIPE_EXPERIMENT
+// =====================================================================================
+// EXPERIMENT (r3, measured, NOT adopted; built only with -DKR_ATTN_PIPE_EXPERIMENT via tools/build_variant.py):
+// the same attention, software-pipelined INSIDE each wave
+// =====================================================================================
+// attn_varlen_kernel runs a tile as a dependent chain per wave — K reads -> QK^T -> max -> exp -> PV — so a wave's own
+// MFMAs never sit beside its own exponentials, and its MFMA chains are dependent back to back.  Here the unit is a
+// 32-key SUB-tile j and one step of a wave's stream is
+//     matrix pipe : PV(j) and QK^T(j + 2), alternating (adjacent MFMAs are independent; PV leads by two while the
+//                   K fragments land)
+//     vector ALU  : P(j + 1) = bf16(exp2(S(j + 1))) in the MFMA gaps (sched_group_barrier), then mask and maximum of the
+//                   S(j + 2) just finished
+//     rare branch : the lazy reference moves by d for S(j + 2): O (PV(j) is in it) and l are scaled by 2^-d, the one P
+//                   already formed from the old reference whose PV is still to come (P(j + 1)) is scaled with them, d is
+//                   taken from S(j + 2) and from the QK^T start tuple
+// i.e. scores are produced two sub-tiles ahead of their PV.  Tiles are staged TWO ahead (three LDS images: during
+// iteration t the waves read K of tile t + 1 and V^T of tiles t / t + 1 and write tile t + 2), one barrier per tile;
+// Q / K / V^T / P layouts, the ones row, PRESCALE and the branch-free staging are attn_varlen_kernel's.  The ISA is what
+// was asked for (hd 80: 211 registers, no spill; MFMAs alternating with 4-8 v_exp / v_cvt between them).
+// MEASURED (profiles/r03_attn_pipe_ablation.txt; same box, same operands, outputs within the kernel tests' tolerance):
+// 8 x 4900 tokens 1.071 ms against 1.068 for attn_varlen_kernel, 19 276 tokens 1.971 against 1.970 — NO gain, and two
+// earlier forms (QK^T one sub-tile ahead; the decision taken beside the next step's leading MFMAs) the same.  The
+// ablation switches below say why: without exponentials -5 %, without staging and barrier -15 %, without the K / V^T
+// fragment reads -10 %, all three -32 % (0.72 ms = the 22 MFMAs per tile alone, 1.5 PFLOP/s of matrix work), and the
+// parts ADD whatever their order in the stream — the loop is not bound by a dependency chain or by issue order but
+// by what the chip sustains under this mix (the clock it holds drops with the work done per cycle, MI355X_MICROARCH.md
+// 'DVFS give-back'), so only doing less per tile would help: fragment reads shared by 64 queries per wave (one wave per
+// SIMD on 512 registers) and LDS-DMA staging are the two levers left, ~5 % and ~8 % of this kernel.
+// the order of a step's MFMAs: entry i is PV number idx[i] (is_pv) or QK^T k-step idx[i]
+template <int NPV, int KS>
+struct PipeOrder {
+    bool is_pv[NPV + KS] = {};
+    int idx[NPV + KS] = {};
+    constexpr PipeOrder() {
+        int np = 0, nq = 0;
+        for (int i = 0; i < NPV + KS; ++i) {
+            const bool take_pv = (np < NPV) && (np < 2 || nq >= KS || ((i & 1) == 0));
+            is_pv[i] = take_pv;
+            idx[i] = take_pv ? np++ : nq++;
+        }
+    }
+};
+template <int HD, bool CAUSAL, int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) attn_varlen_pipe_kernel(
+    const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k, const kr_bf16* __restrict__ vt, kr_bf16* __restrict__ out,
+    const int32_t* __restrict__ qblk, const int32_t* __restrict__ qblk_len, int64_t nq_total, int q_heads, int group,
+    int64_t k_head_stride, int64_t vt_head_stride, float scale_log2e) {
+    using C = AttnCfg<HD>;
+    constexpr int NTHR = NW * 64;
+    constexpr int K_CH = 64 * C::KCH, V_CH = HD * 8, T_CH = K_CH + V_CH, PASSES = (T_CH + NTHR - 1) / NTHR;
+    constexpr int K_BYTES = 64 * C::KROW, V_BYTES = C::DT * 32 * C::VROW, IMG = K_BYTES + V_BYTES;
+    __shared__ __attribute__((aligned(16))) char img_s[3 * IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int bi = blockIdx.x / q_heads, head = blockIdx.x - bi * q_heads, kvh = head / group;
+    const int64_t q_row0 = qblk[4 * bi + 0];
+    const int n_q = qblk[4 * bi + 1];
+    const int64_t k_row0 = (int64_t)qblk[4 * bi + 2];
+    const int64_t vt_blk0 = (int64_t)qblk[4 * bi + 3];
+    const int kv_len_seg = qblk_len[2 * bi + 0];
+    const int q_pos0 = qblk_len[2 * bi + 1];
+    int kv_len = kv_len_seg;
+    if (CAUSAL) kv_len = min(kv_len, q_pos0 + n_q);
+    const int n_tiles = (kv_len + 63) >> 6;
+
+    constexpr bool ONES = C::DT * 32 > HD;
+    if (ONES) {
+        for (int e = tid; e < (C::DT * 32 - HD) * C::VROW / 8; e += NTHR) {
+            const unsigned v = e < 16 ? 0x3F803F80u : 0u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) reinterpret_cast<u32x2*>(img_s + i * IMG + K_BYTES + HD * C::VROW)[e] = (u32x2){v, v};
+        }
+    }
+
+    int ql = wave * 32 + lq;
+    const bool q_valid = ql < n_q;
+    if (!q_valid) ql = n_q - 1;
+    const kr_bf16* qp = q + ((int64_t)head * nq_total + q_row0 + ql) * HD + lh * 8;
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) qf[s] = ld8(qp + s * 16);
+    constexpr bool PRESCALE = (HD == 80) && KR_ATTN_PRESCALE;
+    if (PRESCALE) {
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = f2bf(bf2f(qf[s][j]) * scale_log2e);
+    }
+    f32x16 cinit;   // PRESCALE: -reference in every register (lane = query); else zero
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    const int qpos = q_pos0 + wave * 32 + lq;
+
+    const kr_bf16* kbase = k + (int64_t)kvh * k_head_stride + k_row0 * HD;
+    const kr_bf16* vbase = vt + (int64_t)kvh * vt_head_stride + vt_blk0 * (int64_t)(HD * 64);
+
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;   // m_run: the non-PRESCALE reference
+
+    bf16x8 treg[PASSES];
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int idx = p * NTHR + tid;
+            idx = idx < T_CH ? idx : T_CH - 1;
+            const int key = idx / C::KCH, c = idx - key * C::KCH;
+            int kg = t * 64 + key;
+            kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
+            const kr_bf16* kp = kbase + (int64_t)kg * HD + c * 8;
+            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;
+            treg[p] = ld8(idx < K_CH ? kp : vp);
+        }
+    };
+    auto store_tile = [&](char* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int idx = p * NTHR + tid;
+            idx = idx < T_CH ? idx : T_CH - 1;
+            const int key = idx / C::KCH, c = idx - key * C::KCH;
+            const int j = idx - K_CH;
+            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + (j >> 3) * C::VROW + (j & 7) * 16;
+            const u32x4 w = __builtin_bit_cast(u32x4, treg[p]);
+            u32x2* dstp = reinterpret_cast<u32x2*>(img + off);
+            dstp[0] = (u32x2){w[0], w[1]};
+            dstp[1] = (u32x2){w[2], w[3]};
+        }
+    };
+    auto read_k = [&](const char* k_s, int sub, bf16x8 (&kf)[C::KS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks)
+            kf[ks] = *reinterpret_cast<const bf16x8*>(k_s + k_lds_off<HD>(sub * 32 + lq, 2 * ks + lh));
+    };
+    auto read_v = [&](const char* v_s, int sub, bf16x8 (&vf)[C::DT][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int kb = (sub * 2 + ss) * 16 + 4 * lh;  // keys kb..kb+3 and kb+8..kb+11
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
+                vf[dt][ss] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+            }
+        }
+    };
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    auto mask_scores = [&](f32x16& s, int t, int sub) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = key < kv_len_seg && (!CAUSAL || key <= qpos);
+            s[r] = ok ? s[r] : -INFINITY;
+        }
+    };
+    auto max_scores = [&](const f32x16& s) __attribute__((always_inline)) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        const unsigned mb = __builtin_bit_cast(unsigned, mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+        return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    };
+    auto exp_scores = [&](const f32x16& s, bf16x8 (&pf)[2]) __attribute__((always_inline)) {
+        float psum = 0.f;
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+            f32x8 pv8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#ifdef KR_PIPE_NO_EXP
+                pv8[j] = s[h8 * 8 + j];
+#else
+                pv8[j] = PRESCALE ? __builtin_amdgcn_exp2f(s[h8 * 8 + j])
+                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(s[h8 * 8 + j], scale_log2e, -m_run));
+#endif
+                if (!ONES) psum += pv8[j];
+            }
+            pf[h8] = __builtin_convertvector(pv8, bf16x8);
+        }
+        l_run += psum;
+    };
+    // One step j: PV(j) (P = pf_in, V^T fragments vf read one step earlier) and QK^T(j + 2) (sub-tile (tk, subk), into
+    // s_acc) on the matrix pipe, alternating; beside them P(j + 1) = exp2(s_prev) into pf_out; then mask and maximum of the
+    // finished s_acc and, rarely, the reference move for it: O (PV(j) is in it) and l are scaled by 2^-d, the one P already
+    // formed from the old reference whose PV is still to come (pf_out) is scaled with them, and d is taken from s_acc and
+    // from the QK^T start tuple.
+    constexpr int NPV = 2 * C::DT, N_MFMA = NPV + C::KS;
+    auto step = [&](auto MASKC, f32x16& s_prev, f32x16& s_acc, int tk, int subk, bf16x8 (&pf_out)[2], const bf16x8 (&pf_in)[2],
+                    const char* k_s, const bf16x8 (&vf)[C::DT][2], const char* v_next, int sub_next,
+                    bf16x8 (&vf_next)[C::DT][2]) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(MASKC)::value;
+        asm volatile("" : "+v"(s_prev));   // the step's vector work stays inside the step
+        bf16x8 kf[C::KS];
+#ifdef KR_PIPE_NO_KREAD
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) kf[ks] = qf[ks];
+#else
+        read_k(k_s, subk, kf);
+#endif
+#ifdef KR_PIPE_NO_VREAD
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) vf_next[dt][ss] = vf[dt][ss];
+#else
+        read_v(v_next, sub_next, vf_next);
+#endif
+        f32x16 acc = PRESCALE ? cinit : zero16;
+        // MFMA i of the step (PipeOrder): PV leads by two (its operands are in registers, K fragments are landing), then
+        // the chains alternate: adjacent MFMAs never depend on each other
+        constexpr PipeOrder<NPV, C::KS> ORD{};
+#pragma unroll
+        for (int i = 0; i < N_MFMA; ++i) {
+            const int n = ORD.idx[i];
+            if (ORD.is_pv[i]) {
+#ifndef KR_PIPE_NO_PV
+                o[n % C::DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[n % C::DT][n / C::DT], pf_in[n / C::DT], o[n % C::DT], 0, 0, 0);
+#endif
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[n], qf[n], acc, 0, 0, 0);
+            }
+        }
+        exp_scores(s_prev, pf_out);
+        s_acc = acc;
+        if (MASK) mask_scores(s_acc, tk, subk);
+        float mx = max_scores(s_acc);
+#pragma unroll
+        for (int i = 0; i < N_MFMA; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, ONES ? 3 : 5, 0);
+        }
+        if (!PRESCALE) mx *= scale_log2e;
+        const float grow = PRESCALE ? mx : fmaxf(m_run, mx) - m_run;
+        if (__any(grow > 8.0f)) {
+            const float d = fmaxf(grow, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int h8 = 0; h8 < 2; ++h8)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf_out[h8][j] = f2bf(bf2f(pf_out[h8][j]) * alpha);
+            if (PRESCALE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    cinit[r] -= d;
+                    s_acc[r] -= d;
+                }
+            } else {
+                m_run += d;
+            }
+        }
+    };
+
+    if (n_tiles > 0) {
+        load_tile(0);
+        store_tile(img_s);
+        load_tile(n_tiles > 1 ? 1 : 0);
+        store_tile(img_s + IMG);
+        load_tile(n_tiles > 2 ? 2 : n_tiles - 1);
+        __syncthreads();
+        bf16x8 vfa[C::DT][2], vfb[C::DT][2], pfa[2], pfb[2];
+        f32x16 s0, s1;
+        // ---- prologue: S(0, 0) with the first reference = its own maximum, P(0, 0), S(0, 1) (not yet looked at), V^T(0, 0)
+        {
+            bf16x8 kf[C::KS];
+            read_k(img_s, 0, kf);
+            s0 = zero16;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s0, 0, 0, 0);
+            mask_scores(s0, 0, 0);
+            const float mx = max_scores(s0);
+            if (PRESCALE) {
+                const float d = mx > -INFINITY ? mx : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    cinit[r] = -d;
+                    s0[r] -= d;
+                }
+            } else {
+                m_run = mx > -INFINITY ? mx * scale_log2e : 0.f;
+            }
+            read_k(img_s, 1, kf);
+            s1 = PRESCALE ? cinit : zero16;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s1, 0, 0, 0);
+            exp_scores(s0, pfa);
+            mask_scores(s1, 0, 1);
+            float mx1 = max_scores(s1);   // the decision for (0, 1): O is still zero, P(0, 0) waits for its PV
+            if (!PRESCALE) mx1 *= scale_log2e;
+            const float grow = PRESCALE ? mx1 : fmaxf(m_run, mx1) - m_run;
+            if (__any(grow > 8.0f)) {
+                const float d = fmaxf(grow, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l_run *= alpha;
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pfa[h8][j] = f2bf(bf2f(pfa[h8][j]) * alpha);
+                if (PRESCALE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        cinit[r] -= d;
+                        s1[r] -= d;
+                    }
+                } else {
+                    m_run += d;
+                }
+            }
+            read_v(img_s + K_BYTES, 0, vfa);
+        }
+        auto tile_body = [&](auto MASKC, int t) __attribute__((always_inline)) {
+            const int cur = t % 3, nx = (t + 1) % 3, nn = (t + 2) % 3;
+            const char* v_s = img_s + cur * IMG + K_BYTES;
+            const char* k_s = img_s + nx * IMG;
+            // PV(t, 0) with QK^T(t + 1, 0); P of (t, 1); V^T(t, 1) for the next step
+            step(MASKC, s1, s0, t + 1, 0, pfb, pfa, k_s, vfa, v_s, 1, vfb);
+            // PV(t, 1) with QK^T(t + 1, 1); P of (t + 1, 0); V^T(t + 1, 0).  Past the last tile the image
+            // holds that tile again: those scores are never used, and no tile-count branch sits in the loop
+            step(MASKC, s0, s1, t + 1, 1, pfa, pfb, k_s, vfb, k_s + K_BYTES, 0, vfa);
+            // tile t + 2 (in registers since the previous barrier) -> the third image, last read (V^T of tile t - 1)
+            // before the previous barrier
+#ifndef KR_PIPE_NO_STAGE
+            store_tile(img_s + nn * IMG);
+#endif
+#ifndef KR_PIPE_NO_BARRIER
+            __syncthreads();
+#endif
+#ifndef KR_PIPE_NO_STAGE
+            load_tile(t + 3 < n_tiles ? t + 3 : n_tiles - 1);
+#endif
+        };
+        // iteration t forms the scores of tile t + 1: plain while every key of it is visible to every query of the block
+        int t_plain = kv_len_seg >> 6;
+        if (CAUSAL) t_plain = min(t_plain, (q_pos0 + 1) >> 6);
+        t_plain = min(t_plain - 1, n_tiles);
+        int t = 0;
+        for (; t < t_plain; ++t) tile_body(std::false_type{}, t);
+        for (; t < n_tiles; ++t) tile_body(std::true_type{}, t);
+    }
+
+    float l_tot;
+    if (ONES) {
+        static_assert(!ONES || HD % 32 == 16, "ones row register");
+        l_tot = __shfl(o[HD / 32][8], lq, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (!q_valid) return;
+    kr_bf16* op = out + (q_row0 + ql) * ((int64_t)q_heads * HD) + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = dt * 32 + 8 * i + 4 * lh;
+            if (d < HD) {
+                bf16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = f2bf(o[dt][4 * i + j] * inv);
+                *reinterpret_cast<bf16x4*>(op + d) = ov;
+            }
+        }
+}
+#endif  // KR_ATTN_PIPE_EXPERIMENT
+
 // =====================================================================================
 // decode: rotary + KV append for one new token per sequence
 // =====================================================================================
@@ -818,9 +1197,25 @@ static int attn_varlen_impl(const kr_bf16* q, const kr_bf16* k, const kr_bf16* v
     dim3 grid((unsigned)(n_qblk * q_heads));
     const float sl = scale * 1.4426950408889634f;
     const int group = q_heads / kv_heads;
+#ifdef KR_ATTN_PIPE_EXPERIMENT
+    const char* penv = getenv("KARANTA_ATTN_PIPE");   // experiment build: 0 = the product loop (same-library A/B)
+    const int pipe = penv ? atoi(penv) : 1;
+#define KR_LAUNCH_ATTN(HD_, C_, NW_)                                                                                       \
+    do {                                                                                                                   \
+        if (pipe)                                                                                                          \
+            attn_varlen_pipe_kernel<HD_, C_, NW_><<<grid, NW_ * 64, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total,     \
+                                                                                   q_heads, group, k_head_stride,          \
+                                                                                   vt_head_stride, sl);                    \
+        else                                                                                                               \
+            attn_varlen_kernel<HD_, C_, NW_><<<grid, NW_ * 64, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total,          \
+                                                                              q_heads, group, k_head_stride,               \
+                                                                              vt_head_stride, sl);                         \
+    } while (0)
+#else
 #define KR_LAUNCH_ATTN(HD_, C_, NW_)                                                                                       \
     attn_varlen_kernel<HD_, C_, NW_><<<grid, NW_ * 64, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total, q_heads, group, \
                                                                       k_head_stride, vt_head_stride, sl)
+#endif
 #define KR_LAUNCH_ATTN_Q(HD_, C_) do { if (q_block == 256) KR_LAUNCH_ATTN(HD_, C_, 8); else KR_LAUNCH_ATTN(HD_, C_, 4); } while (0)
     if (hd == 80) {
         if (causal) KR_LAUNCH_ATTN_Q(80, true); else KR_LAUNCH_ATTN_Q(80, false);
