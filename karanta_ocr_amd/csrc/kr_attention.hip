@@ -590,10 +590,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
 // earlier forms (QK^T one sub-tile ahead; the decision taken beside the next step's leading MFMAs) the same.  The
 // ablation switches below say why: without exponentials -5 %, without staging and barrier -15 %, without the K / V^T
 // fragment reads -10 %, all three -32 % (0.72 ms = the 22 MFMAs per tile alone, 1.5 PFLOP/s of matrix work), and the
-// parts ADD whatever their order in the stream — the loop is not bound by a dependency chain or by issue order but
-// by what the chip sustains under this mix (the clock it holds drops with the work done per cycle, MI355X_MICROARCH.md
-// 'DVFS give-back'), so only doing less per tile would help: fragment reads shared by 64 queries per wave (one wave per
-// SIMD on 512 registers) and LDS-DMA staging are the two levers left, ~5 % and ~8 % of this kernel.
+// parts ADD whatever their order in the stream, at 0.49 MFMA-busy and a clock that moves little (1.97 - 2.26 GHz over the
+// variants: not a DVFS effect).  The loop is not bound by a dependency chain, by issue order or by the two waves of a SIMD
+// marching in step: a tile's vector-ALU, LDS and staging work does not run beside its MFMAs on this SIMD in any order
+// tried, so only doing less per tile would help: fragment reads shared by 64 queries per wave (one wave per SIMD on 512
+// registers) and LDS-DMA staging are the two levers left, ~5 % and ~8 % of this kernel.
 // the order of a step's MFMAs: entry i is PV number idx[i] (is_pv) or QK^T k-step idx[i]
 template <int NPV, int KS>
 struct PipeOrder {
