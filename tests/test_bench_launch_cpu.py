@@ -98,3 +98,55 @@ def test_committed_pmc_traffic_is_quoted_only_on_the_kernel_source_it_was_measur
     monkeypatch.setattr(bench, "kernel_source_sha16", lambda: "0" * 16)           # the kernels changed since the pass
     got, why = bench.pmc_traffic()
     assert got is None and "not quoted" in why
+
+
+class _FakeArenaEngine:
+    """What bench.distribute_weights touches of an engine: the weight arena, its size, the stream, load_weights."""
+
+    def __init__(self, fill):
+        import torch
+        self.w = type("W", (), {})()
+        self.w.arena = torch.full((1 << 12,), fill, dtype=torch.uint8)
+        self.w.nbytes = self.w.arena.numel()
+        self.s = 0
+        self.loaded = None
+
+    def load_weights(self, w):
+        self.loaded = w
+        self.w.arena.fill_(int(w["fill"]))
+
+
+def test_failed_rccl_broadcast_is_reported_and_every_rank_generates_the_seeded_weights():
+    """N > 1 bench: a broadcast that raises (on every rank: dp.BroadcastError) leaves rccl_error in the record, the other ranks
+    generate the same seeded weights, the digests are still compared; --strict-rccl re-raises; a good broadcast reports its ranks."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    from karanta_ocr_amd.dp import BroadcastError
+
+    def failing(arena, rank, world, stream=0, info=None):
+        raise BroadcastError("kr_comm_init failed on at least one rank")
+
+    eng = _FakeArenaEngine(fill=0)          # a non-root rank: zeros until the weights arrive
+    root_digest = []
+
+    def gather(x):                          # the root holds the seeded weights (fill 7)
+        root = _FakeArenaEngine(fill=7)
+        root_digest.append(int(root.w.arena[:: max(1, root.w.arena.numel() // (1 << 22))].to(__import__("torch").int64).sum().item()))
+        return [root_digest[-1], x]
+
+    s, ranks, err = bench.distribute_weights(eng, 1, 2, failing, gather, lambda: {"fill": 7}, strict=False)
+    assert s is None and ranks is None and "kr_comm_init" in err and eng.loaded == {"fill": 7}
+    with pytest.raises(BroadcastError):
+        bench.distribute_weights(_FakeArenaEngine(0), 1, 2, failing, gather, lambda: {"fill": 7}, strict=True)
+    with pytest.raises(SystemExit, match="digests differ"):     # a rank that ends up with other bytes stops the run
+        bench.distribute_weights(_FakeArenaEngine(0), 1, 2, failing, gather, lambda: {"fill": 9}, strict=False)
+
+    def good(arena, rank, world, stream=0, info=None):
+        arena.fill_(7)
+        info["rccl_ranks"] = world
+        return 0.25
+
+    eng2 = _FakeArenaEngine(fill=0)
+    s, ranks, err = bench.distribute_weights(eng2, 1, 2, good, gather, lambda: {"fill": 7}, strict=False)
+    assert (s, ranks, err) == (0.25, 2, None) and eng2.loaded is None
