@@ -38,6 +38,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails on the legacy mode): keep the setting in every
+# rank's environment, before anything initialises the GPU runtime, without overriding what the launcher exported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 # Token ids of the Qwen2 chat template around a vision message (text first, image second, as

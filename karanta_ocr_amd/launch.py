@@ -195,6 +195,8 @@ def start_servers(model: str, gpus: Sequence[int], ports: Sequence[int], extra: 
     group = ServerGroup(gpus, ports)
     cmd0 = list(server_cmd or DEFAULT_SERVER_CMD)
     base_env = dict(os.environ if env is None else env)
+    # the RCCL weight broadcast shares device memory between the servers: dmabuf IPC (the legacy mode fails in hipIpcGetMemHandle)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for rank, (g, port) in enumerate(zip(gpus, ports)):
         e = dict(base_env, HIP_VISIBLE_DEVICES=str(g), OMP_NUM_THREADS=base_env.get("OMP_NUM_THREADS", "1"))
         if broadcast and n > 1:
