@@ -45,6 +45,9 @@ def main():
                     help="instead of whole steps: time ONE kind of launch as a chain over the layers' weights (graph of reps x "
                          "layers launches; the per-launch figure includes the dependent-launch gap): comma-separated list of "
                          "qkv,attn,merge,o,oheads,gateup,gateup32,down,merge+o")
+    ap.add_argument("--concurrent", action="store_true",
+                    help="launch the variants' graphs CONCURRENTLY, each engine on its own stream (e.g. `--batch 16 --concurrent base base` "
+                         "= two independent 16-row decode batches side by side), and report the wall time per step of the group")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     cfg = CONFIGS[a.model]
@@ -116,6 +119,26 @@ def main():
                 g = C.c_void_p()
                 L.kr_graph_end_capture(eng.s, C.byref(g))
                 graphs[spec] = g.value
+    if a.concurrent:
+        import time
+        kvb = cfg.text.kv_bytes_per_token
+        ts = []
+        for r in range(a.rounds + 1):
+            for _, eng in engines:
+                reset(eng)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                for spec, eng in engines:
+                    L.kr_graph_launch(graphs[spec], eng.s)
+            torch.cuda.synchronize()
+            if r:
+                ts.append((time.perf_counter() - t0) / a.steps * 1e3)
+        n = len(engines)
+        roof_ms = (n * cfg.decoder_weight_bytes(a.weights) + n * B * (a.ctx + a.steps / 2) * kvb) / 8e12 * 1e3
+        print(f"{n} x {B} rows side by side: median {np.median(ts):.4f} ms per step of the group, min {min(ts):.4f}  "
+              f"({n * B} rows per step; {roof_ms / np.median(ts) * 100:.1f} % of 8 TB/s on the bytes the group streams)", flush=True)
+        return
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
     times = {spec: [] for spec, _ in engines}
