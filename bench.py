@@ -72,7 +72,7 @@ def cpu_baseline(cfg, pv_page: np.ndarray, grid, ids: np.ndarray, t_out: int, we
     from oracle import qwen2vl_oracle as O  # checker / baseline only
 
     t_start = time.perf_counter()
-    N_DEC = 8
+    N_DEC = 16   # 58 ms per token on 16 cores: the parity block compares prefill + 16 decode steps for one more second
     try:  # BLAS threads = this job's CPU share (16 cores per GPU on the bench boxes), not every core of the host
         import threadpoolctl
         cores = min(16, os.cpu_count() or 1)
