@@ -66,7 +66,9 @@ __device__ __forceinline__ void stage_tile(const kr_bf16* __restrict__ g, int64_
 // instead of 8-byte pieces of 16 different rows per instruction: the direct form wrote C at ~2 TB/s with one
 // workgroup per CU and nothing to overlap it with (vit fc1: 233 of 642 us).  Values are identical either way.
 // LDSEPI / HAS_R are compile-time: runtime selects inside the unrolled (mt, nt) loops turn into a branch per accumulator.
-template <int EPI, int NT, int MT, bool LDSEPI, bool HAS_R>
+// CH > 0 (LDSEPI only): the scratch holds CH m-tiles (CH * 16 rows) at a time and is flushed after every CH of them — the persistent
+// kernel's epilogue, whose scratch is the 4 KiB per wave the staging ring leaves over.  Same values, same stores.
+template <int EPI, int NT, int MT, bool LDSEPI, bool HAS_R, int CH = 0>
 __device__ __forceinline__ void gemm_epilogue_impl(f32x4 (&acc)[NT][MT], const kr_bf16* __restrict__ bias,
                                                    const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc,
                                                    int64_t M, int N, int64_t m_base, int n_base, int fr, int fg, char* wlds_) {
@@ -75,6 +77,24 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x4 (&acc)[NT][MT], const k
     char* const wlds = wlds_;
     // scratch chunk (16 B) c of row r sits at c ^ swz(r): 2-way conflicts on the 8-byte writes, none on the reads
     auto swz = [](int r) { return HALF ? ((r >> 1) & 3) : (r & 7); };
+    // scratch rows [0, nmt * 16) = the m-tiles mt0 .. mt0 + nmt - 1: out as 16-byte-per-lane, row-contiguous stores.  Same wave,
+    // in-order LDS: its reads see its writes, and the next m-tiles' writes come after these reads
+    auto flush = [&](int mt0, int nmt) {
+        constexpr int LPR = ROWB / 16, RPI = 64 / LPR;   // lanes per row, rows per instruction
+        const int lane = fg * 16 + fr;
+        const int n_out = HALF ? (n_base >> 1) : n_base, n_lim = HALF ? (N >> 1) : N;
+#pragma unroll
+        for (int it = 0; it < MT * 16 / RPI; ++it) {
+            if (it < nmt * 16 / RPI) {
+                const int r = it * RPI + lane / LPR, c = lane % LPR;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + r * ROWB + ((c ^ swz(r)) << 4));
+                const int64_t m = m_base + mt0 * 16 + r;
+                const int n = n_out + c * 8;
+                if (m < M && n < n_lim) *reinterpret_cast<u32x4*>(C + m * ldc + n) = v;
+            }
+        }
+    };
+    constexpr int RM = CH > 0 ? CH : MT;   // m-tiles the scratch holds
     // ---------------- epilogue: lane holds 4 consecutive n for one m
     // Operand loads are unconditional (clamped addresses) and hoisted: a guarded load inside the (mt, nt) loops costs
     // one dependent L2 round trip per accumulator — 32 of them in a row were 8-13 us per tile.
@@ -102,12 +122,13 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x4 (&acc)[NT][MT], const k
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(g[j]) * u[j]);
                 if (LDSEPI) {
-                    const int r = mt * 16 + fr;
+                    const int r = (mt % RM) * 16 + fr;
                     if (fg < 2) *reinterpret_cast<bf16x4*>(wlds + r * ROWB + ((nt ^ swz(r)) << 4) + (fg & 1) * 8) = o;
                 } else if (fg < 2 && n < N && m < M) {
                     *reinterpret_cast<bf16x4*>(C + m * ldc + (n >> 1) + fg * 4) = o;
                 }
             }
+            if (LDSEPI && CH > 0 && (mt % RM) == RM - 1) flush(mt - (RM - 1), RM);
         }
     } else if (EPI == KR_EPI_SILU_MUL) {
 #pragma unroll
@@ -165,40 +186,29 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x4 (&acc)[NT][MT], const k
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
                 if (LDSEPI) {
-                    const int r = mt * 16 + fr;
+                    const int r = (mt % RM) * 16 + fr;
                     *reinterpret_cast<bf16x4*>(wlds + r * ROWB + (((nt * 2 + (fg >> 1)) ^ swz(r)) << 4) + (fg & 1) * 8) = o;
                 } else if (m < M && n < N) {
                     *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
                 }
             }
+            if (LDSEPI && CH > 0 && (mt % RM) == RM - 1) flush(mt - (RM - 1), RM);
         }
     }
-    if (LDSEPI) {  // same wave, in-order LDS: its reads see its writes
-        constexpr int LPR = ROWB / 16, RPI = 64 / LPR;   // lanes per row, rows per instruction
-        const int lane = fg * 16 + fr;
-        const int n_out = HALF ? (n_base >> 1) : n_base, n_lim = HALF ? (N >> 1) : N;
-#pragma unroll
-        for (int it = 0; it < MT * 16 / RPI; ++it) {
-            const int r = it * RPI + lane / LPR, c = lane % LPR;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + r * ROWB + ((c ^ swz(r)) << 4));
-            const int64_t m = m_base + r;
-            const int n = n_out + c * 8;
-            if (m < M && n < n_lim) *reinterpret_cast<u32x4*>(C + m * ldc + n) = v;
-        }
-    }
+    if (LDSEPI && CH == 0) flush(0, MT);
 }
 
 // LDSEPI kernels (the 256x256 tiles) are only launched with ldc % 8 == 0 and a 16-byte aligned C.
-template <int EPI, int NT, int MT, bool LDSEPI>
+template <int EPI, int NT, int MT, bool LDSEPI, int CH = 0>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NT][MT], const kr_bf16* __restrict__ bias,
                                               const kr_bf16* __restrict__ R, int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc,
                                               int64_t M, int N, int64_t m_base, int n_base, int fr, int fg, char* wlds) {
     constexpr bool L = LDSEPI && EPI != KR_EPI_SILU_MUL;
     if constexpr (EPI == KR_EPI_SILU_MUL || EPI == KR_EPI_SILU_MUL8) {
-        gemm_epilogue_impl<EPI, NT, MT, L, false>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
+        gemm_epilogue_impl<EPI, NT, MT, L, false, CH>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
     } else {
-        if (R) gemm_epilogue_impl<EPI, NT, MT, L, true>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
-        else gemm_epilogue_impl<EPI, NT, MT, L, false>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
+        if (R) gemm_epilogue_impl<EPI, NT, MT, L, true, CH>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
+        else gemm_epilogue_impl<EPI, NT, MT, L, false, CH>(acc, bias, R, ldr, C, ldc, M, N, m_base, n_base, fr, fg, wlds);
     }
 }
 
@@ -459,7 +469,17 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(u32x2 q) {
 // A8 (with W8): the activations are e4m3 codes too (one f32 scale per ROW of A: dynamic per-token quantisation,
 // kr_quantize_rows_fp8) and the products run on the fp8 matrix instruction, v_mfma_f32_16x16x32_fp8_fp8 — no conversion on
 // the way from LDS to the MFMA, half the A bytes through LDS; both scales multiply the f32 accumulators before the epilogue.
-template <int EPI, bool WPACK, bool W8, bool A8 = false>
+// PERSIST (r3 EXPERIMENT, -DKR_GEMM_PERSIST_EXPERIMENT): the workgroup walks the tile list (tiles blockIdx.x,
+// + gridDim.x, ...: the same tile every round as the one-tile-per-workgroup launch gives that CU) and requests the NEXT tile's first
+// three K-tiles before it runs the current tile's epilogue, whose LDS scratch is the 4 KiB per wave the ring leaves over (two m-tiles
+// at a time): the pipeline fill of a tile and the workgroup turnover sit under the previous tile's C write-out instead of in front
+// of every tile.  Same values as the product launch (GPU test on the variant library).  MEASURED (tools/gemm_microbench.py,
+// profiles/r03_gemm_persistent.txt): ViT qkv 355.9 us against 345.0, fc1 487.9 / 483.5, proj 122.2 / 121.1, fc2 411.3 / 407.8, prefill
+// gate/up 540.5 / 540.4 — no gain: with one workgroup per CU the hardware already starts the next workgroup while the finished
+// one's C stores drain, whereas the loop has to wait for them (vmcnt(0): loads and stores share the counter) before it may trust
+// the prefetched K-tiles.  What the K = 1280 shapes lose is inside the loop (0.0254 us per k and round against 0.0161 at the MFMA
+// rate) and in the epilogue itself, not in the turnover.
+template <int EPI, bool WPACK, bool W8, bool A8 = false, bool PERSIST = false>
 __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restrict__ A, int64_t lda, const kr_bf16* __restrict__ W,
                                                         const kr_bf16* __restrict__ bias, const kr_bf16* __restrict__ R,
                                                         int64_t ldr, kr_bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
@@ -481,17 +501,26 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
-    const unsigned wg = xcd_remap(blockIdx.x, nwg);
-    unsigned tm, tn;
-    tile_coords(wg, (unsigned)((M + 255) >> 8), (unsigned)tiles_n, (unsigned)group_m, tm, tn);
-    const int64_t m0 = (int64_t)tm * 256;
-    const int n0 = (int)tn * 256;
+    // tile `t` of the list: PERSIST: round r = t / gridDim.x takes ids [r * G, r * G + G_r) with the XCD remap inside the round
+    int64_t m0;
+    int n0;
+    auto set_tile = [&](unsigned t) {
+        unsigned id;
+        if constexpr (PERSIST) {
+            const unsigned r0 = (t / gridDim.x) * gridDim.x;
+            id = r0 + xcd_remap(t - r0, min(gridDim.x, nwg - r0));
+        } else {
+            id = xcd_remap(t, nwg);
+        }
+        unsigned tm, tn;
+        tile_coords(id, (unsigned)((M + 255) >> 8), (unsigned)tiles_n, (unsigned)group_m, tm, tn);
+        m0 = (int64_t)tm * 256;
+        n0 = (int)tn * 256;
+    };
+    unsigned tile = blockIdx.x;
+    set_tile(tile);
 
     f32x4 acc[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / PK;
     // fragment read offsets inside a buffer (row * 64 + swizzled chunk * 16)
@@ -533,10 +562,15 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     else if (nk == 2) wait_one();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
 
     bf16x8 wb[NT], xa[4];
     u32x2 xq[4];   // A8: the A fragments as 8 codes
+    for (;;) {   // one pass per tile (PERSIST: until the list ends)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs one barrier behind wave row 0
     for (int k = 0; k < nk; ++k) {
         const char* cur = smem + (k & 3) * PBUF;
         char* nxt = smem + ((k + 3) & 3) * PBUF;
@@ -608,10 +642,30 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier
+    const int64_t m0_cur = m0;
+    const int n0_cur = n0;
+    bool more_tiles = false;
+    if constexpr (PERSIST) {
+        // every fragment read of this tile is behind the last barrier: the ring is free.  The next tile's K-tiles 0..2 are
+        // requested now and land under the epilogue below
+        tile += gridDim.x;
+        more_tiles = tile < nwg;
+        if (more_tiles) {
+            set_tile(tile);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (t < nk) {
+                    char* buf = smem + t * PBUF;
+                    stage_w(t * PK, buf);
+                    stage_a(t * PK, buf);
+                }
+            }
+        }
+    }
     if constexpr (W8) {  // row scales of the quantised weights: lane holds 4 consecutive n per accumulator
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(w_scale + min(n0 + wc * 64 + nt * 16 + fg * 4, N - 4));
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(w_scale + min(n0_cur + wc * 64 + nt * 16 + fg * 4, N - 4));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -621,7 +675,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
     if constexpr (A8) {  // per-token scales of the quantised activations: the lane's batch row is the accumulator's column
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int64_t m = m0 + wr * 128 + mt * 16 + fr;
+            const int64_t m = m0_cur + wr * 128 + mt * 16 + fr;
             const float as = a_scale[m < M ? m : M - 1];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -629,7 +683,19 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const kr_bf16* __restric
                 for (int j = 0; j < 4; ++j) acc[nt][mt][j] *= as;
         }
     }
-    gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, fr, fg, smem + wave * (128 * 128));
+    if constexpr (PERSIST) {
+        gemm_epilogue<EPI, NT, MT, true, 2>(acc, bias, R, ldr, C, ldc, M, N, m0_cur + wr * 128, n0_cur + wc * 64, fr, fg,
+                                            smem + PSTAGES * PBUF + wave * 4096);
+        if (!more_tiles) break;
+        // the next tile's first K-tiles have landed (this wave's share) and the C stores are out; everybody's share after the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        gemm_epilogue<EPI, NT, MT, true>(acc, bias, R, ldr, C, ldc, M, N, m0_cur + wr * 128, n0_cur + wc * 64, fr, fg,
+                                         smem + wave * (128 * 128));
+        break;
+    }
+    }  // tiles
 }
 
 // -------------------------------------------------------------------------------------
@@ -1023,6 +1089,10 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     if (attr_set.need()) {
         KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8, A8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+#ifdef KR_GEMM_PERSIST_EXPERIMENT
+        KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, WPACK, W8, A8, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 8 * 4096));
+#endif
     }
     // measured (tools/gemm_microbench.py, r2): groups of 8 m tiles against m-major rows — ViT qkv (15 n tiles) 373 -> 350 us,
     // fc1 (20) 518 -> 496, prefill gate/up (70) 581 -> 562, 8192^3 856 -> 1390 TFLOP/s; with 5-6 n tiles an m-major run of
@@ -1031,8 +1101,18 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
     const int group_m = genv ? atoi(genv) : (tiles_n >= 8 ? 8 : 1);
     const char* senv = getenv("KARANTA_GEMM_STAGGER");
     const int stagger = senv ? atoi(senv) : 0;
-    gemm_pipe_kernel<EPI, WPACK, W8, A8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
-                                                                                (unsigned)nwg, w_scale, group_m, a_scale, stagger);
+#ifdef KR_GEMM_PERSIST_EXPERIMENT
+    // experiment build (tools/build_variant.py persist kr_gemm.hip -DKR_GEMM_PERSIST_EXPERIMENT): KARANTA_GEMM_PERSIST=0 (read per
+    // call: A/B, tests) selects the product launch in the same library
+    const char* penv = getenv("KARANTA_GEMM_PERSIST");
+    const bool persist = (penv ? atoi(penv) != 0 : true) && nwg > kr_cu_count();
+    if (persist)
+        gemm_pipe_kernel<EPI, WPACK, W8, A8, true><<<(unsigned)kr_cu_count(), 512, LDS + 8 * 4096, kr_hs(s)>>>(
+            A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n, (unsigned)nwg, w_scale, group_m, a_scale, 0);
+    else
+#endif
+        gemm_pipe_kernel<EPI, WPACK, W8, A8><<<(unsigned)nwg, 512, LDS, kr_hs(s)>>>(A, lda, W, bias, R, ldr, C, ldc, M, N, K, tiles_n,
+                                                                                    (unsigned)nwg, w_scale, group_m, a_scale, stagger);
     KR_CHECK_LAUNCH();
     if constexpr (!W8) {
         if (tail)

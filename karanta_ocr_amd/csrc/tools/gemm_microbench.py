@@ -30,7 +30,8 @@ def run(name, M, N, K, epi, packed, reps=5):
     variants = [("128-tile", 128, 0, 0), ("256-tile", 256, 0, 0), ("pipelined 256 m-major", 512, 0, 0),
                 ("+ groups of 4", 512, 0, 4), ("+ groups of 8", 512, 0, 8), ("+ groups of 16", 512, 0, 16),
                 ("groups + tail, 2-buffer 128 kernel", 512, 1, None, 2), ("groups + unsplit deep-ring tail", 512, 1, None, 4, 1), ("default (groups where >= 8 n tiles, tail split, deep ring)", 512, 1, None),
-                ("automatic tile, 2-buffer", 0, 1, None, 2), ("automatic tile (default)", 0, 1, None)]
+                ("automatic tile, 2-buffer", 0, 1, None, 2), ("automatic tile (default)", 0, 1, None),
+                ("automatic tile, persistent tile loop", 0, 1, None, 4, 16, 1), ("automatic tile, one tile per workgroup", 0, 1, None, 4, 16, 0)]
     call = lambda: L.kr_gemm_bf16_ws(ptr(a), K, ptr(w), 0 if epi == EPI_SILU_MUL8 else ptr(bias), 0, 0, ptr(c), nc, M, N, K, epi, packed,
                                      ptr(SCRATCH), SCRATCH.numel() * 4, S)   # with the caller-owned split-K scratch, as the engine calls it
     for label, tile, tail, gm, *st in variants:
@@ -43,6 +44,10 @@ def run(name, M, N, K, epi, packed, reps=5):
         else:
             os.environ.pop("KARANTA_GEMM_STAGES", None)
         os.environ["KARANTA_GEMM_TAIL_KSPLIT"] = str(st[1]) if len(st) > 1 else "16"
+        if len(st) > 2:
+            os.environ["KARANTA_GEMM_PERSIST"] = str(st[2])
+        else:
+            os.environ.pop("KARANTA_GEMM_PERSIST", None)
         os.environ["KARANTA_GEMM_TAIL"] = str(tail)
         if gm is None:
             os.environ.pop("KARANTA_GEMM_GROUP_M", None)

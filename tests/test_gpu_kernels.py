@@ -320,6 +320,46 @@ def test_gemm_tail_round_as_quarter_tiles(L, M, N, K, epi, packed):
         os.environ.pop("KARANTA_GEMM_TAIL_KSPLIT", None)
 
 
+@pytest.mark.parametrize("M,N,K,epi,packed", [(9800, 2560, 192, EPI_NONE, False),          # 390 tiles: 2 rounds on 256 CUs, the second partial
+                                               (9800, 5120, 1536, EPI_QUICK_GELU, False),   # 780 tiles = 3 rounds + 12 (tail launch)
+                                               (11152, 3072, 1536, EPI_GELU_ERF, True),     # 528 tiles, packed W, bias + residual
+                                               (11152, 4096, 1536, EPI_SILU_MUL8, True),    # the interleaved gate/up epilogue (64-byte rows)
+                                               (20000, 1280, 1280, EPI_NONE, False)])       # ragged last m tile, 5 n tiles (m-major list)
+def test_gemm_persistent_tile_loop_gives_the_one_tile_per_workgroup_values(L, M, N, K, epi, packed):
+    """Experiment build, KARANTA_GEMM_PERSIST=1: one workgroup per CU walks the tile list and requests the next tile's first K-tiles
+    before the current tile's epilogue (gemm_pipe_kernel<.., PERSIST>): exact on integers, the same k order and epilogue arithmetic as the
+    one-tile-per-workgroup launch (compiled separately: an element on a bf16 rounding boundary may land on either side),
+    reproducible, and right against the host reference on the first and last tiles' rows."""
+    import os
+    if "persist" not in os.path.basename(os.environ.get("KARANTA_HIP_LIB", "")):
+        pytest.skip("experiment build only: tools/build_variant.py persist kr_gemm.hip -DKR_GEMM_PERSIST_EXPERIMENT, then "
+                    "KARANTA_HIP_LIB=karanta_ocr_amd/csrc/_build/variants/libkaranta_hip.persist.so (measured, not adopted: DESIGN §5-r3)")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert -(-M // 256) * (N // 256) > cus, "shape no longer needs more than one round on this device"
+    rng = np.random.default_rng(M + N + K + 7)
+    os.environ["KARANTA_GEMM_TILE"] = "512"
+    try:
+        os.environ["KARANTA_GEMM_PERSIST"] = "1"
+        if epi == EPI_NONE:
+            A, W = ints(rng, M, K), ints(rng, N, K)
+            np.testing.assert_array_equal(run_gemm(L, A, W), ref_linear(A, W))
+        A, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+        bias = None if epi == EPI_SILU_MUL8 else rnd(rng, N, scale=0.1)
+        res = None if epi == EPI_SILU_MUL8 else rnd(rng, M, N)
+        got = run_gemm(L, A, W, bias, res, epi, packed=packed)
+        for _ in range(2):
+            np.testing.assert_array_equal(got, run_gemm(L, A, W, bias, res, epi, packed=packed))
+        os.environ["KARANTA_GEMM_PERSIST"] = "0"
+        one = run_gemm(L, A, W, bias, res, epi, packed=packed)
+        assert (got != one).mean() < 1e-5, f"{(got != one).sum()} elements differ from the one-tile-per-workgroup form"
+        assert_close_bf16(got, one, what="persistent tile loop vs one tile per workgroup")
+        rows = np.r_[0:300, M - 600:M]
+        assert_close_bf16(got[rows], ref_linear(A[rows], W, bias, None if res is None else res[rows], epi), what="persistent tile loop")
+    finally:
+        os.environ.pop("KARANTA_GEMM_TILE", None)
+        os.environ.pop("KARANTA_GEMM_PERSIST", None)
+
+
 def test_gemm_asymmetric_operands_catch_transposes(L):
     M, N, K = 128, 128, 64
     A = np.zeros((M, K), np.float32); A[np.arange(64), np.arange(64)] = 1  # rows 0..63 = identity on K
