@@ -413,6 +413,53 @@ def test_qwen2_5_vl_7b_width_matches_oracle():
         eng.close()
 
 
+def test_qwen2_5_vl_3b_width_matches_oracle():
+    """The architecture the reference's OWN fine-tunes start from (Qwen2.5-VL-3B,
+    /root/reference/configs/training/ocr/karanta_set_qwen_2_5_3B_vl.yaml:2) at production widths: the windowed vision tower
+    (eight blocks: window blocks 0-6, full attention in block 7; merger output 2048) and the 3B-width decoder — hidden 2048
+    (the K = 2048 instantiations of the decode kernels), 16 query / 2 KV heads, intermediate 11008 (down_proj in two K halves of
+    86 chunks), untied lm_head — two layers, one 1024x1024 scan: ViT merged output, prefill logits and 10 teacher-forced decode
+    steps against the oracle; the hipGraph path reproduces the oracle's greedy tokens up to the first undecisive step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = PW.truncated_config("Qwen2.5-VL-3B", 8, 2)
+    t = cfg.text
+    assert (t.hidden_size, t.num_heads, t.num_kv_heads, t.intermediate_size) == (2048, 16, 2, 11008) and cfg.vision.variant == "qwen2_5"
+    w = random_weights(cfg, 17, as_bits=True)
+    ids, pv, grid = PW.page_inputs(cfg, 341, 1024, 1024, MAXPIX_A, 14, 27, 91)
+    assert grid == (1, 70, 70)
+    steps = 11
+    eng = Engine(cfg, max_batch=1, s_max=2048, max_patches=len(pv), max_prompt_tokens=len(ids), decode_splits=16)
+    eng.load_weights(w)
+    try:
+        assert eng.wide_mode and eng.narrow_mode and eng.defer_down
+        got_img = eng.vit_forward(pv, [grid])
+        eng.stream.synchronize()
+        got_img = got_img.float().cpu().numpy()
+        ref_img = O.vit_forward(pv, [grid], w, cfg.vision, policy="bf16")
+        scale, vit_err = float(np.abs(ref_img).max()), float(np.abs(got_img - ref_img).max())
+        assert vit_err < 0.02 * scale, f"Qwen2.5-VL-3B ViT merged output off by {vit_err} (range {scale})"
+        o_tok, o_log = O.generate_greedy(cfg, w, ids[None], None, [grid], steps, policy="bf16", ignore_eos=True, return_logits=True,
+                                         image_embeds=ref_img)
+        page = PageRequest(ids, pv, [grid])
+        forced = eng.generate([page], steps, ignore_eos=True, return_logits=True, force_tokens=o_tok[:, :steps - 1])
+        tol = TOL_REL * float(np.abs(o_log[0, 0]).max())
+        f_errs = [float(np.abs(forced.logits[0, i] - o_log[0, i]).max()) for i in range(steps)]
+        assert f_errs[0] < tol, f"prefill logits off by {f_errs[0]} (tol {tol})"
+        f_decisive = PW.compare_teacher_forced(forced.tokens[0], forced.logits[0], o_tok[0], o_log[0], tol, "Qwen2.5-VL-3B widths (forced)")
+        _record("qwen2_5_vl_3b_w_v8_l2", vit_err=vit_err, vit_range=scale, tol=tol, forced_logit_err=f_errs,
+                margins=PW.margins(o_log[0]).tolist(), forced_decisive=f_decisive)
+        assert f_decisive >= 3, f"only {f_decisive} of {steps} teacher-forced steps were decisive"
+        graph = eng.generate([page], steps, ignore_eos=True)
+        m = PW.margins(o_log[0])
+        for i in range(steps):
+            if m[i] <= 2 * tol:
+                break
+            assert int(graph.tokens[0][i]) == int(o_tok[0, i]), f"graph step {i}"
+    finally:
+        eng.close()
+
+
 # ------------------------------------------------------------------------------------------------------------ (c)
 def test_config5_1700x2200_fp8_end_to_end_matches_oracle(m7b):
     """BASELINE.json config 5 end to end at the 7B widths (2 + 2 depth): one 1700x2200 newspaper scan at the hub
