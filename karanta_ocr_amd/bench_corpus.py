@@ -30,12 +30,12 @@ def main():
     ap.add_argument("--slots", type=int, default=32)
     ap.add_argument("--t-min", type=int, default=64)
     ap.add_argument("--t-max", type=int, default=512)
-    ap.add_argument("--chunk", type=int, default=16)
+    ap.add_argument("--chunk", type=int, default=8, help="decode steps between two looks at the finished flags (r3 sweep: 6-8 best)")
     ap.add_argument("--page", type=int, default=1024)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans (encoded once, cycled)")
     ap.add_argument("--admit", type=int, default=8, help="pages one admission may prefill together")
-    ap.add_argument("--admit-min", type=int, default=4, help="free slots (and waiting requests) an admission waits for while others decode")
-    ap.add_argument("--admit-max-wait", type=int, default=4, help="... but never longer than this many scheduler steps")
+    ap.add_argument("--admit-min", type=int, default=6, help="free slots (and waiting requests) an admission waits for while others decode")
+    ap.add_argument("--admit-max-wait", type=int, default=8, help="... but never longer than this many scheduler steps")
     ap.add_argument("--overlap-cus", type=int, default=None,
                     help="overlap admissions with decoding: ViT + prefill on a stream restricted to this many CUs "
                          "(kr_stream_create_cu_mask; 0 = an ordinary second stream; unset = admissions interrupt the decode graph)")

@@ -58,8 +58,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--greedy", action="store_true", help="ignore request temperatures")
     ap.add_argument("--admit-min", type=int, default=1,
                     help="while sequences decode, wait for this many free slots + waiting requests before an admission "
-                         "(4: +5 %% pages/s on a saturated server, profiles/r02_corpus_through_api.json; 1: lowest latency)")
-    ap.add_argument("--admit-max-wait", type=int, default=4, help="... but at most this many scheduler steps of 16 decode steps")
+                         "(6: +8 %% pages/s on a saturated server, profiles/r03_corpus_sweep.txt; 1: lowest latency)")
+    ap.add_argument("--admit-max-wait", type=int, default=8, help="... but at most this many scheduler steps of 8 decode steps")
     ap.add_argument("--quantization", default=None, choices=("fp8",),
                     help="decoder Linears as fp8 codes + row scales (vLLM's flag; implied by a checkpoint with a quantization_config)")
     ap.add_argument("--max-logprobs", type=int, default=None,

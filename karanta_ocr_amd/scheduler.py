@@ -41,7 +41,7 @@ class SlotScheduler:
     """`submit()` requests, call `step()` until `idle`; every step admits what fits, runs `chunk` decode steps and
     returns the requests that finished."""
 
-    def __init__(self, engine, max_tokens_cap: int, chunk: int = 16, eos_token_ids: Optional[Sequence[int]] = None,
+    def __init__(self, engine, max_tokens_cap: int, chunk: int = 8, eos_token_ids: Optional[Sequence[int]] = None,
                  max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False,
                  overlap: bool = False, guided: bool = False, logprobs: Optional[int] = None, admit_min: int = 1,
                  admit_max_wait: int = 4):

@@ -312,7 +312,7 @@ class LocalServer:
 
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
                  batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
-                 chunk: int = 16, honor_temperature: bool = True, max_logprobs: Optional[int] = None, admit_min: int = 1,
+                 chunk: int = 8, honor_temperature: bool = True, max_logprobs: Optional[int] = None, admit_min: int = 1,
                  admit_max_wait: int = 4, overlap_admissions: bool = False):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
         self.honor_temperature = bool(honor_temperature)   # False: every request is served greedy
