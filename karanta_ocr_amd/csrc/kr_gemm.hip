@@ -1077,10 +1077,14 @@ int launch_gemm_pipe(const kr_bf16* A, int64_t lda, const kr_bf16* W, const kr_b
         const char* env = getenv("KARANTA_GEMM_TAIL");
         const int64_t t = nwg % cus;
         // measured (tools/gemm_microbench.py, r2): a lone last round is cheaper than a full one (its few tiles have the
-        // chip's clocks and memory system to themselves), so the split pays where a tile is long — K >= 1536: prefill
-        // down_proj 414 -> 353 us, o_proj 81 -> 74, ViT fc2 460 -> 442, merger fc1 469 -> 435 — or the tail tiny (ViT proj,
-        // 2 tiles: 135 -> 127); at K = 1280 with 6-8 tail tiles it is neutral to slightly worse (fc1 521 -> 533)
-        if (nwg > cus && t > 0 && 2 * t <= cus && (K >= 1536 || t <= 4) && !(env && atoi(env) == 0)) {
+        // chip's clocks and memory system to themselves), so the split pays most where a tile is long — prefill down_proj
+        // 414 -> 353 us, o_proj 81 -> 74, ViT fc2 460 -> 442, merger fc1 469 -> 435.  Round 3 (tools/gemm_tail_probe.py, the
+        // tail on the 4-deep ring kernel, admission batches of 1..8 pages): at K = 1280 too every tail of <= cus / 2 tiles is
+        // neutral or better split — proj 3 pages (34 tail tiles) 64.7 -> 59.3 us, qkv 1 page (44) 65.0 -> 58.4, fc1 2 pages
+        // (12) 146.2 -> 136.5, fc1 8 pages (8) 499.7 -> 481.9 — so the round-2 condition "K >= 1536 or <= 4 tail tiles" is gone
+        const char* kenv = getenv("KARANTA_GEMM_TAIL_MINK");   // tuning sweeps: the K from which any tail of <= cus / 2 tiles is split
+        const int min_k = kenv ? atoi(kenv) : 0;
+        if (nwg > cus && t > 0 && 2 * t <= cus && (K >= min_k || t <= 4) && !(env && atoi(env) == 0)) {
             tail = (unsigned)t;
             nwg -= t;
         }
