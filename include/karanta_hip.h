@@ -63,6 +63,9 @@ int kr_stream_synchronize(kr_stream s);
  * (ViT + prefill: MFMA-bound, long-running workgroups) on such a stream beside the decode graph (HBM-bound, short
  * launches) on the main one — the reference gets the same overlap from vLLM's chunked prefill.  kr_stream_destroy frees it. */
 int kr_stream_create_cu_mask(kr_stream* out, int cus_enabled);
+/* The same with the mask bits [first_cu, first_cu + n_cus): a second stream on the COMPLEMENT of a kr_stream_create_cu_mask stream shares no
+ * compute unit with it (the decode graph beside an admission: neither launch waits for a workgroup slot of the other). */
+int kr_stream_create_cu_range(kr_stream* out, int first_cu, int n_cus);
 int kr_stream_destroy(kr_stream s);
 
 /* ------------------------------------------------------------------ profiling events

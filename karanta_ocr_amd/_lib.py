@@ -30,6 +30,7 @@ SIGNATURES = {
     "kr_set_device": [i32],
     "kr_stream_synchronize": [c_p],
     "kr_stream_create_cu_mask": [C.POINTER(c_p), i32],
+    "kr_stream_create_cu_range": [C.POINTER(c_p), i32, i32],
     "kr_stream_destroy": [c_p],
     "kr_event_create": [C.POINTER(c_p)],
     "kr_event_destroy": [c_p],

@@ -62,6 +62,21 @@ int kr_stream_create_cu_mask(kr_stream* out, int cus_enabled) {
     *out = reinterpret_cast<kr_stream>(st);
     return KR_OK;
 }
+int kr_stream_create_cu_range(kr_stream* out, int first_cu, int n_cus) {
+    KR_CHECK_ARG(out && first_cu >= 0 && n_cus > 0, "kr_stream_create_cu_range: bad args");
+    int dev = 0, cus = 0;
+    KR_CHECK_HIP(hipGetDevice(&dev));
+    KR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    KR_CHECK_ARG(cus > 0 && first_cu + n_cus <= cus, "kr_stream_create_cu_range: CUs [%d, %d) of %d", first_cu, first_cu + n_cus, cus);
+    const int words = (cus + 31) / 32;
+    uint32_t mask[32] = {0};
+    KR_CHECK_ARG(words <= 32, "kr_stream_create_cu_range: %d CUs", cus);
+    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    KR_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+    *out = reinterpret_cast<kr_stream>(st);
+    return KR_OK;
+}
 int kr_stream_destroy(kr_stream s) {
     KR_CHECK_ARG(s, "kr_stream_destroy: the default stream");
     KR_CHECK_HIP(hipStreamDestroy(kr_hs(s)));

@@ -45,6 +45,9 @@ def main():
                     help="instead of whole steps: time ONE kind of launch as a chain over the layers' weights (graph of reps x "
                          "layers launches; the per-launch figure includes the dependent-launch gap): comma-separated list of "
                          "qkv,attn,merge,o,oheads,gateup,gateup32,down,merge+o")
+    ap.add_argument("--cus", default=None,
+                    help="comma-separated CU counts: replay each variant's graph on a stream masked to the first N compute units "
+                         "(kr_stream_create_cu_mask) — what a decode step keeps when part of the chip is given to something else")
     ap.add_argument("--concurrent", action="store_true",
                     help="launch the variants' graphs CONCURRENTLY, each engine on its own stream (e.g. `--batch 16 --concurrent base base` "
                          "= two independent 16-row decode batches side by side), and report the wall time per step of the group")
@@ -138,6 +141,28 @@ def main():
         roof_ms = (n * cfg.decoder_weight_bytes(a.weights) + n * B * (a.ctx + a.steps / 2) * kvb) / 8e12 * 1e3
         print(f"{n} x {B} rows side by side: median {np.median(ts):.4f} ms per step of the group, min {min(ts):.4f}  "
               f"({n * B} rows per step; {roof_ms / np.median(ts) * 100:.1f} % of 8 TB/s on the bytes the group streams)", flush=True)
+        return
+    if a.cus:
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))
+        for n in [int(x) for x in a.cus.split(",")]:
+            ms_ = C.c_void_p()
+            L.kr_stream_create_cu_mask(C.byref(ms_), n)
+            for spec, eng in engines:
+                ts = []
+                for r in range(a.rounds + 1):
+                    reset(eng)
+                    L.kr_event_record(e0, ms_)
+                    for _ in range(a.steps // per_graph[spec]):
+                        L.kr_graph_launch(graphs[spec], ms_)
+                    L.kr_event_record(e1, ms_)
+                    L.kr_event_synchronize(e1)
+                    ms = C.c_float()
+                    L.kr_event_elapsed_ms(e0, e1, C.byref(ms))
+                    if r:
+                        ts.append(ms.value / a.steps)
+                print(f"{spec:30s} on {n:3d} CUs: median {np.median(ts):.4f} ms/step  min {min(ts):.4f}", flush=True)
+            L.kr_stream_destroy(ms_)
         return
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.kr_event_create(C.byref(e0)); L.kr_event_create(C.byref(e1))

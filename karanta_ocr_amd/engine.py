@@ -296,6 +296,12 @@ class Engine:
         env_cus = os.environ.get("KARANTA_ADMIT_CUS")
         self.admission_cus = int(env_cus) if env_cus is not None else (int(admission_cus) if admission_cus else 0)
         self._adm_stream_handle = None
+        # ... and, while an admission is in flight on it, the decode graph replays on a stream restricted to the OTHER compute units
+        # (kr_stream_create_cu_range): disjoint sets, so neither side waits for a workgroup slot of the other.  Measured alone
+        # (tools/decode_ab.py --cus): a 32-row step keeps 94 / 70 / 47 % of its speed on 75 / 50 / 25 % of the CUs.
+        self.disjoint_decode = os.environ.get("KARANTA_DISJOINT_DECODE", "1") != "0"
+        self._dec_stream, self._dec_stream_handle, self._adm_inflight = None, None, 0
+        self.n_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._resample_cache: Dict[tuple, tuple] = {}   # (h, w, rh, rw) -> device tables of the GPU image front end
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
         self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
@@ -1563,6 +1569,7 @@ class Engine:
             done.record(self._adm_stream)
         finally:
             self.stream, self.s = main
+        self._adm_inflight += 1
         return {"done": done, "rec": rec}
 
     def admit_ready(self, handle) -> bool:
@@ -1571,6 +1578,7 @@ class Engine:
     def admit_end(self, handle) -> List[int]:
         """Activate the admitted slots on the decode stream (waits for the admission stream there, not on the host)."""
         rec = handle["rec"]
+        self._adm_inflight = max(0, self._adm_inflight - 1)
         self.stream.wait_event(handle["done"])
         with torch.cuda.stream(self.stream):
             self._write_slot_state(rec["slots"], rec["lens"], rec["deltas"], rec["cs"], rec["temps"], rec["seeds"],
@@ -1579,7 +1587,26 @@ class Engine:
         return rec["lens"]
 
     def decode_steps(self, n: int):
-        """n decode steps over all slots (asynchronous on the engine's stream)."""
+        """n decode steps over all slots (asynchronous on the engine's stream).  While an admission is in flight on a CU-masked
+        stream the captured graph replays on the complementary compute units (same kernels, same grids: the same tokens), ordered
+        against the engine's stream by events on both sides."""
+        graph = self._graphs.get(self._graph_key(self.B))
+        if (graph is not None and self._adm_inflight > 0 and self.admission_cus > 0 and self.disjoint_decode
+                and self.admission_cus < self.n_cus):
+            if self._dec_stream is None:
+                h = C.c_void_p()
+                self.L.kr_stream_create_cu_range(C.byref(h), int(self.admission_cus), int(self.n_cus - self.admission_cus))
+                self._dec_stream_handle = h
+                self._dec_stream = torch.cuda.ExternalStream(h.value, device=self.device)
+            before = torch.cuda.Event()
+            before.record(self.stream)
+            self._dec_stream.wait_event(before)
+            for _ in range(n):
+                self.L.kr_graph_launch(graph, self._dec_stream.cuda_stream)
+            after = torch.cuda.Event()
+            after.record(self._dec_stream)
+            self.stream.wait_event(after)
+            return
         with torch.cuda.stream(self.stream):
             for _ in range(n):
                 graph = self._graphs.get(self._graph_key(self.B))
@@ -1634,3 +1661,8 @@ class Engine:
             self._adm_stream = None
             self.L.kr_stream_destroy(self._adm_stream_handle)
             self._adm_stream_handle = None
+        if self._dec_stream_handle is not None:
+            torch.cuda.synchronize(self.device)
+            self._dec_stream = None
+            self.L.kr_stream_destroy(self._dec_stream_handle)
+            self._dec_stream_handle = None
