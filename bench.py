@@ -633,7 +633,7 @@ def main():
                 "launches_timed": chain["launches"],
                 "avg_us_definition": "HIP events on the launch stream around a chain of back-to-back launches of this kernel, one per "
                                      "decoder layer's weights (no cache reuse), total / launches; compare the rocprofv3 kernel-trace "
-                                     "average of the same kernel in profiles/r02_kernel_trace_summary.txt",
+                                     "average of the same kernel in profiles/r03_kernel_trace_summary.txt",
                 # the same launch bracketed by events inside the timed decode steps (eager steps every --profile-every):
                 "in_step": {"event_bracket_us": round(prof["bracket_us"], 3), "empty_bracket_us": round(prof["null_bracket_us"], 3),
                             "dispatch_gap_us": round(floor_us, 3), "launches_timed": prof["launches"]},
