@@ -36,6 +36,11 @@ extern "C" {
 typedef void* kr_stream; /* hipStream_t */
 typedef uint16_t kr_bf16;
 
+/* kr_version() of the library this header describes: major * 100 + minor.  The major changes with every incompatible
+ * change of a signature or struct below (r4: kr_narrow_opts argument of round 3, packed 17..32-row family); a caller built
+ * against major X must refuse a library whose kr_version() / 100 != X. */
+#define KR_ABI_VERSION 400
+
 #define KR_OK 0
 #define KR_ERR_ARG (-1)    /* unsupported shape / null pointer */
 #define KR_ERR_HIP (-2)    /* HIP runtime error */
@@ -289,6 +294,8 @@ int kr_argmax(const float* logits, int64_t ld_logits, int vocab, int32_t* out, i
 #define KR_DEC_ROPE_KV 2
 #define KR_DEC_ARGMAX 3
 #define KR_DEC_SILU8 4      /* SILU with 8-row interleave: one tile per workgroup -> 2x the workgroups of KR_DEC_SILU */
+#define KR_DEC_OUT_XP 0x100 /* kr_linear_decode_wide*, OR-ed into KR_DEC_SILU8 at 17..32 rows: `out` is written in the packed
+                             * activation layout of kr_pack_rows32 (ldc ignored) — the input format of kr_linear_decode32 */
 int kr_linear_decode(int mode, const kr_bf16* x, int64_t ldx, const kr_bf16* w_packed, const kr_bf16* bias,
                      const kr_bf16* norm_w, float norm_eps, const kr_bf16* residual, int64_t ldr,
                      kr_bf16* out, float* out_f32, int64_t ldc, int M, int N, int K, int waves, int max_blocks, int ksplit,
@@ -371,6 +378,53 @@ int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t ldx, const f
                                 int ksplit, const float* cs_table, int cs_stride, const int32_t* prompt_len,
                                 const int32_t* ctx_len, kr_bf16* q_out, kr_bf16* kcache, kr_bf16* vtcache, int heads,
                                 int kv_heads, int s_max, const kr_narrow_opts* opts, kr_stream s);
+/* ---- decode batches of 17..32 rows (two 16-row MFMA column tiles): the continuous server's steady state and BASELINE
+ * config 3's 32-rows-per-GPU variant (the callers: bulk_processing/workers/inference_worker.py:331-339, one in-flight
+ * request per worker x workers per port).
+ *
+ * PACKED ACTIVATIONS ("XP").  The input of a decode linear at more than 16 rows is stored
+ *     [K/64 chunks][2 column tiles][2 k-steps of 32][64 lanes = 16 * (k/8 % 4) + row % 16][8] bf16      (4 KiB per chunk)
+ * i.e. element (row b, column k) at byte (k/64)*4096 + (b/16)*2048 + (k/32 % 2)*1024 + (16*(k/8 % 4) + b%16)*16 + (k%8)*2:
+ * the operand of one v_mfma_f32_16x16x32_bf16 is 1 KiB of contiguous memory in lane order, so a wave fetches it as eight
+ * whole cache lines (row-major x costs sixteen half lines per fragment, and at two column tiles a wave moves twice as many
+ * x bytes from L2 as weight bytes from HBM).  Producers: kr_pack_rows32 (from row-major rows; rows >= M are zero),
+ * kr_decode_resnorm32, kr_attn_decode_merge32, kr_linear_decode_wide(KR_DEC_SILU8 | KR_DEC_OUT_XP).  A buffer holds 32 rows
+ * whatever M is: K * 64 bytes. */
+int kr_pack_rows32(const kr_bf16* x, int64_t ldx, int M, int K, kr_bf16* xp, kr_stream s);
+
+/* kr_linear_decode_narrow's contract (modes KR_DEC_PLAIN and KR_DEC_ROPE_KV, bf16 or fp8 weights, deferred split-K into
+ * f32 slabs or one atomically accumulated slab, the zeroing job) for M <= 32 on packed activations, WITH THE NARROW LAUNCH'S
+ * SUMMATION ORDER: `waves_ref` and `ksplit` name the K partition the <= 16-row launch of the same layer uses (its `waves`
+ * and `ksplit` arguments) — the same chunk ranges accumulated from zero in ascending k, folded in the same order — so row b
+ * of the result has the bits kr_linear_decode_narrow gives for that row alone: a page's tokens do not depend on its batch.
+ * 8-wave workgroups; a 16-wave partition runs as two ranges per wave.  tiles_per_wg: 0 = automatic (two weight tiles share
+ * one ring of x fragments where that leaves >= 192 workgroups), 1, 2.  No norm prologue: x is kr_decode_resnorm32's output. */
+typedef struct kr_dec32 {
+    const kr_bf16* xp;            /* packed activations, K * 64 bytes */
+    const void* w_packed;         /* weights.pack_w16x32 (bf16) or pack_w16x64_fp8 (with w_scale) */
+    const float* w_scale;         /* fp8 weights: one f32 per output row; NULL for bf16 */
+    const kr_bf16* bias;          /* [N] or NULL (ROPE_KV: required) */
+    const kr_bf16* residual;      /* PLAIN: [M, ldr] or NULL */
+    int64_t ldr;
+    kr_bf16* out;                 /* PLAIN: bf16 [M, ldc] ... */
+    float* out_f32;               /* ... or f32 [M, ldc]; ksplit > 1: slabs [ksplit][M][ldc], or one slab with atomic_out */
+    int64_t ldc;
+    int32_t M, N, K;
+    int32_t waves_ref, ksplit;    /* the <= 16-row launch's K partition */
+    int32_t atomic_out;           /* ksplit == 2: both K ranges ADD into out_f32 (zeroed by an earlier launch) */
+    int32_t tiles_per_wg;
+    float* zero_ptr;              /* this launch also zeroes [zero_ptr, zero_ptr + zero_bytes) (16-byte multiples) */
+    uint64_t zero_bytes;
+    /* KR_DEC_ROPE_KV (as kr_linear_decode): */
+    const float* cs_table; int32_t cs_stride; const int32_t* prompt_len; const int32_t* ctx_len;
+    kr_bf16* q_out; kr_bf16* kcache; kr_bf16* vtcache; int32_t heads, kv_heads, s_max;
+} kr_dec32;
+int kr_linear_decode32(int mode, const kr_dec32* args, kr_stream s);
+
+/* kr_decode_resnorm with h written in the packed layout (h_xp: K * 64 bytes); x_out stays row-major. */
+int kr_decode_resnorm32(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
+                        int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h_xp, int M, int K, kr_stream s);
+
 /* n fp8 e4m3fn codes -> bf16 through the hardware conversion the kernels use (test hook: pins the number format). */
 int kr_fp8_to_bf16(const uint8_t* src, kr_bf16* dst, int64_t n, kr_stream s);
 
@@ -390,6 +444,11 @@ int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16*
  * (one small launch; the alternative to merging inside the consumer's prologue). */
 int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split,
                          kr_stream s);
+
+/* kr_attn_decode_merge with the merged heads written in the packed activation layout (row = sequence, column =
+ * head * 128 + d; batch <= 32; out_xp: heads * 128 * 64 bytes) — the o_proj launch of a 17..32-row batch reads it. */
+int kr_attn_decode_merge32(const float* workspace, kr_bf16* out_xp, int batch, int heads, int hd, int n_split,
+                           kr_stream s);
 
 /* GPU image front end.  kr_image_resize_bicubic_u8: HWC uint8 RGB [h][w][3] -> [rh][rw][3], bit-identical to
  * PIL's Image.resize(..., BICUBIC) (the HF PIL processor's resize, image_processing_pil_qwen2_vl.py:126-150):

@@ -47,6 +47,10 @@ SIGNATURES = {
     "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
     "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p],
     "kr_decode_resnorm": [c_p, i64, c_p, i32, i32, c_p, i64, c_p, f32, c_p, i64, i32, i32, c_p],
+    "kr_decode_resnorm32": [c_p, i64, c_p, i32, i32, c_p, i64, c_p, f32, c_p, i32, i32, c_p],
+    "kr_pack_rows32": [c_p, i64, i32, i32, c_p, c_p],
+    "kr_linear_decode32": [i32, c_p, c_p],
+    "kr_attn_decode_merge32": [c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_quantize_rows_fp8": [c_p, i64, c_p, i64, c_p, i64, i32, c_p],
     "kr_gemm_fp8a": [c_p, i64, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, c_p],
     "kr_gemm_bf16_ws": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p, C.c_size_t, c_p],
@@ -118,6 +122,18 @@ def narrow_opts(zero_ptr: int = 0, zero_bytes: int = 0, atomic_out: bool = False
         return None
     return C.byref(NarrowOpts(zero_ptr or None, int(zero_bytes), 1 if atomic_out else 0, int(part_rows)))
 
+class Dec32(C.Structure):
+    """kr_dec32 (include/karanta_hip.h): the arguments of kr_linear_decode32."""
+    _fields_ = [("xp", c_p), ("w_packed", c_p), ("w_scale", c_p), ("bias", c_p), ("residual", c_p), ("ldr", C.c_int64),
+                ("out", c_p), ("out_f32", c_p), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("waves_ref", C.c_int32), ("ksplit", C.c_int32), ("atomic_out", C.c_int32), ("tiles_per_wg", C.c_int32),
+                ("zero_ptr", c_p), ("zero_bytes", C.c_uint64),
+                ("cs_table", c_p), ("cs_stride", C.c_int32), ("prompt_len", c_p), ("ctx_len", c_p),
+                ("q_out", c_p), ("kcache", c_p), ("vtcache", c_p), ("heads", C.c_int32), ("kv_heads", C.c_int32), ("s_max", C.c_int32)]
+
+
+ABI_MAJOR = 4              # include/karanta_hip.h KR_ABI_VERSION / 100: the header this binding was written against
+DEC_OUT_XP = 0x100         # KR_DEC_OUT_XP
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_SILU_MUL, EPI_SILU_MUL8 = 0, 1, 2, 3, 4
 DEC_PLAIN, DEC_SILU, DEC_ROPE_KV, DEC_ARGMAX, DEC_SILU8 = 0, 1, 2, 3, 4
 
@@ -146,6 +162,9 @@ class _Lib:
                 setattr(self, name, fn)
             else:
                 setattr(self, name, self._checked(name, fn))
+        if self.kr_version() // 100 != ABI_MAJOR:
+            raise KarantaHipError(f"{path} reports kr_version() = {self.kr_version()}, this binding is written against ABI major "
+                                  f"{ABI_MAJOR} (include/karanta_hip.h): rebuild with `python -m karanta_ocr_amd.build`")
         self.experiments = hasattr(self._dll, "kr_oproj_heads")
         for name, argtypes in EXPERIMENT_SIGNATURES.items():
             if self.experiments:

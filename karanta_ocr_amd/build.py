@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libkaranta_hip.so")
-SOURCES = ["kr_api.hip", "kr_elementwise.hip", "kr_gemm.hip", "kr_attention.hip", "kr_decode.hip", "kr_image.hip", "kr_guide.hip", "kr_comm.hip",
+SOURCES = ["kr_api.hip", "kr_elementwise.hip", "kr_gemm.hip", "kr_attention.hip", "kr_decode.hip", "kr_decode32.hip", "kr_image.hip", "kr_guide.hip", "kr_comm.hip",
            "kr_selftest.hip"]
 HEADERS = [os.path.join(CSRC, "kr_common.h"), os.path.join(os.path.dirname(HERE), "include", "karanta_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

@@ -37,6 +37,10 @@ def build_parser() -> argparse.ArgumentParser:
                          "serves them; prefill GEMMs 1.9x faster, logits move by a few per cent of their range) — default: bf16 activations")
     ap.add_argument("--max-model-len", type=int, default=16384)
     ap.add_argument("--max-num-seqs", type=int, default=8, help="decode slots (<= 32; above 16: hidden_size <= 2048 or == 3584)")
+    ap.add_argument("--max-num-batched-tokens", type=int, default=None,
+                    help="prompt tokens one admission (ViT + prefill of the requests entering free slots together) may hold: sizes "
+                         "the engine's activation buffers (vLLM's flag for its prefill budget).  Default: max(--max-model-len, 16384) — "
+                         "eight 1024x1024 pages at the class-default max_pixels; image patches per admission: 4x this")
     ap.add_argument("--tensor-parallel-size", type=int, default=1)
     ap.add_argument("--data-parallel-size", type=int, default=1)
     ap.add_argument("--gpu-memory-utilization", type=float, default=None)
@@ -84,7 +88,9 @@ def parse_args(argv: Optional[List[str]] = None):
     if args.max_logprobs is not None and not 0 <= args.max_logprobs <= 20:
         ap.error("--max-logprobs must be in 0..20")
     if not 1 <= args.max_num_seqs <= 32:
-        ap.error("--max-num-seqs must be in 1..32 (above 16: models up to hidden_size 2048)")
+        ap.error("--max-num-seqs must be in 1..32 (above 16: hidden_size <= 2048 or == 3584)")
+    if args.max_num_batched_tokens is not None and args.max_num_batched_tokens < args.max_model_len:
+        ap.error("--max-num-batched-tokens must be >= --max-model-len (the longest prompt one request may carry)")
     args.model_dir = model
     args.served_model_name = args.served_model_name or os.path.basename(os.path.normpath(model))
     args.ignored = unknown
@@ -122,6 +128,20 @@ def preprocessor_pixels(model_dir: str):
     return ok(lo), ok(hi)
 
 
+def admission_budget(args, cfg, max_pixels: int):
+    """(max_prompt_tokens, max_patches) of the engine: what ONE admission (the requests that enter free slots together: one
+    ViT + prefill pass) may hold — not a multiple of the slot count.  The scheduler fills an admission up to these budgets
+    (scheduler.SlotScheduler._admit) and a request larger than them is refused with 400, so the token budget is at least
+    --max-model-len; a prompt holds at most as many image tokens as tokens, i.e. 4x as many patches (2x2 merge), plus one
+    partial 64-patch block per page.  (Round 3 sized both by max_num_seqs: 2.1 M patches / 262 k tokens of activation
+    buffers — tens of GB at the 7B width — for 32 slots with a hub preprocessor_config.json.)"""
+    tokens = int(args.max_num_batched_tokens or max(args.max_model_len, 16384))
+    merge2 = cfg.vision.spatial_merge_size ** 2
+    per_page = min(max_pixels // (cfg.vision.patch_size ** 2), merge2 * args.max_model_len) + 64
+    patches = max(merge2 * tokens + 64 * args.max_num_seqs, per_page)
+    return tokens, patches
+
+
 def make_server(args, log=print):
     """Engine + front end + LocalServer from parsed arguments (weights and tokenizer from args.model_dir)."""
     from . import image_processing as IP
@@ -143,9 +163,11 @@ def make_server(args, log=print):
         raise ValueError(f"min_pixels {min_pixels} > max_pixels {max_pixels}")
     log(f"image preprocessing: min_pixels={min_pixels} max_pixels={max_pixels} "
         f"({'--max-pixels' if args.max_pixels else 'preprocessor_config.json' if ck_max else 'class default'})")
-    patches_per_page = max_pixels // (cfg.vision.patch_size ** 2) + 64
+    max_prompt_tokens, max_patches = admission_budget(args, cfg, max_pixels)
+    log(f"admission budget: {max_prompt_tokens} prompt tokens / {max_patches} image patches per ViT + prefill pass, "
+        f"{args.max_num_seqs} decode slots of {args.max_model_len} tokens")
     eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 63) // 64 * 64,
-                 max_patches=args.max_num_seqs * patches_per_page, max_prompt_tokens=args.max_num_seqs * args.max_model_len // 2,
+                 max_patches=max_patches, max_prompt_tokens=max_prompt_tokens,
                  weight_dtype=weight_dtype, fp8_activations=bool(getattr(args, "fp8_activations", False)) or None)
     # one server: read the checkpoint.  A launch.py group: rank 0 reads it ONCE, the arena goes to the other GPUs over
     # RCCL / xGMI (north_star: "RCCL broadcast of weights over xGMI"); a failure stops every server of the group
@@ -164,7 +186,9 @@ def make_server(args, log=print):
                        max_logprobs=args.max_logprobs, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait)
 
 
-def main(argv: Optional[List[str]] = None, make=make_server) -> int:
+def main(argv: Optional[List[str]] = None, make=make_server, on_ready=None) -> int:
+    """on_ready(httpd, server, stop_event): called once the port is bound (tests and embedding callers; a real deployment
+    stops the server with SIGTERM / SIGINT, as the pipeline does: /root/reference/karanta/pipeline.py:745-751)."""
     from .serving import serve_http
 
     args = parse_args(argv)
@@ -179,7 +203,8 @@ def main(argv: Optional[List[str]] = None, make=make_server) -> int:
             signal.signal(sig, lambda *_: stop.set())
         except ValueError:      # not the main thread (tests)
             pass
-    args.on_ready(httpd, srv, stop) if hasattr(args, "on_ready") else None
+    if on_ready is not None:
+        on_ready(httpd, srv, stop)
     stop.wait()
     httpd.shutdown()
     srv.close()

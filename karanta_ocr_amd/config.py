@@ -271,4 +271,5 @@ def from_hf_config_dict(d: dict, name: str = "hf") -> ModelConfig:
         vision_start_token_id=d.get("vision_start_token_id", 151652),
         vision_end_token_id=d.get("vision_end_token_id", 151653),
         eos_token_ids=eos,
+        pad_token_id=int(d["pad_token_id"]) if d.get("pad_token_id") is not None else eos[-1],
     )

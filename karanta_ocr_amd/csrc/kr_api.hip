@@ -15,7 +15,8 @@ void kr_set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int kr_version(void) { return 100; }
+// major * 100 + minor; the major changes with every incompatible change of include/karanta_hip.h (callers check it: _lib.py)
+int kr_version(void) { return KR_ABI_VERSION; }
 
 const char* kr_last_error(void) { return g_err; }
 

@@ -79,6 +79,14 @@ __device__ __forceinline__ bf16x8 ld8_nt(const kr_bf16* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
 }
 
+// ---------------------------------------------------------------- packed activations of 17..32-row decode batches (XP layout)
+// [K/64 chunks][2 column tiles of 16 rows][2 k-steps of 32][64 lanes = (fg, fr)][8] bf16: the operand of one
+// v_mfma_f32_16x16x32_bf16 (16 rows x 32 k) is 1 KiB of contiguous memory in lane order, as a weight fragment is
+// (include/karanta_hip.h, kr_pack_rows32).  Byte offset of element (row b, column k):
+__host__ __device__ __forceinline__ int64_t kr_xp_byte_offset(int b, int k) {
+    return (int64_t)(k >> 6) * 4096 + (b >> 4) * 2048 + ((k >> 5) & 1) * 1024 + ((((k >> 3) & 3) * 16 + (b & 15)) * 16) + (k & 7) * 2;
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

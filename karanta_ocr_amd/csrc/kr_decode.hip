@@ -85,6 +85,9 @@ struct DecLinArgs {
     // carry a zeroing job for the accumulator the NEXT down_proj will add into
     int part_atomic;
     float* zero_ptr; int zero_n16;
+    // SILU8 output in the XP layout of 17..32-row batches (kr_common.h, kr_xp_byte_offset): the down_proj launch of such a
+    // batch (kr_linear_decode32) reads its x fragments as whole cache lines
+    int out_xp;
 };
 
 // One 64-wide K chunk of a 16-row weight tile in registers, and where its operands sit.
@@ -737,7 +740,10 @@ __device__ __forceinline__ void dec_wide_body(const WideHot& h, const DecLinArgs
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[mt][j]) * u4[j]);
-                    *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
+                    if (MT == 2 && a.out_xp)
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.out) + kr_xp_byte_offset(b, t * 8 + fg * 4)) = o;
+                    else
+                        *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
                 }
             } else if (EPI == DEPI_ARGMAX) {  // running argmax over this wave's tiles, written once after the loop
                 const int n = t * 16 + fg * 4;
@@ -838,12 +844,12 @@ int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
 // the weight ring), keeps the first half in registers for staging and re-reads the second half (L2) when its turn comes.
 // Ring depth 7 (28 chunks per half = 4 x 7: slots stay static).  TMAX = tiles a wave may own (lm_head of the 7B model
 // on 256 x 8 waves: 9504 tiles -> 5).
-template <int EPI, bool W8>
+template <int EPI, bool W8, int U>
 __global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, const kr_bf16* wpk, const kr_bf16* norm_w, int64_t ldx, int M,
                                                           int N, int wide_blocks, int wide_waves, float norm_eps, const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WC = WChunk<W8>;
-    constexpr int NCH = 56, CH = 28, U = 7, KHALF = CH * 64, HC = KHALF / 8;   // 224 16-byte pieces per half row
+    constexpr int NCH = 56, CH = 28, KHALF = CH * 64, HC = KHALF / 8;   // 224 16-byte pieces per half row; U = ring depth (7 or 14)
     constexpr int NR = 4, RLH = 4, TMAX = 5, MT = 2;
     constexpr int XROW = KHALF * 2 + 16;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1004,7 +1010,10 @@ __global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, cons
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = f2bf(act_silu(acc[i][mt][j]) * u4[j]);
-                    *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
+                    if (a.out_xp)
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.out) + kr_xp_byte_offset(b, t * 8 + fg * 4)) = o;
+                    else
+                        *reinterpret_cast<bf16x4*>(a.out + (int64_t)b * a.ldc + t * 8 + fg * 4) = o;
                 }
             } else {   // ARGMAX
                 const int n = t * 16 + fg * 4;
@@ -1040,10 +1049,12 @@ int launch_wide_kh(DecLinArgs& a, int blocks, int waves, kr_stream s) {
                      "kr_linear_decode_wide: %d tiles over %d x %d waves is more than 5 tiles per wave", a.N >> 4, blocks, waves);
         KR_CHECK_ARG(!a.x_is_f32 && !a.bias && !a.residual, "kr_linear_decode_wide: K-halves take bf16 x, no bias / residual");
         const size_t lds = (size_t)32 * (28 * 64 * 2 + 16);
-        auto fn = &dec_wide_kh_kernel<EPI, W8>;
+        static const int ring = [] { const char* e = getenv("KARANTA_KH_RING"); return e ? atoi(e) : 7; }();
+        auto fn = ring == 14 ? &dec_wide_kh_kernel<EPI, W8, 14> : &dec_wide_kh_kernel<EPI, W8, 7>;
         static KrPerDeviceOnce attr;
         if (attr.need()) {
-            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_wide_kh_kernel<EPI, W8, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_wide_kh_kernel<EPI, W8, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         fn<<<blocks, 512, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.ldx, a.M, a.N, a.wide_blocks, a.wide_waves, a.norm_eps, a);
         KR_CHECK_LAUNCH();
@@ -1978,7 +1989,8 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
 // (Cheaper end-to-end than replicating the merge in every o_proj workgroup's prologue: measured.)
 // NS > 0: all n_split records are requested at once (one memory round trip instead of two dependent loops).
 template <int NS>
-__global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict__ ws, kr_bf16* __restrict__ out, int n_split) {
+__global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict__ ws, kr_bf16* __restrict__ out, int n_split, int heads_xp) {
+    // heads_xp > 0: out is the XP layout of a 17..32-row batch (row = sequence, column = head * 128 + d), heads_xp = heads
     constexpr int HD = 128, REC = HD + 4;
     const int bh = blockIdx.x, d = threadIdx.x;
     float acc = 0.f, ll = 0.f;
@@ -2010,7 +2022,13 @@ __global__ void __launch_bounds__(128) attn_merge_kernel(const float* __restrict
             ll += w[p * REC + HD + 1] * sc;
         }
     }
-    out[(int64_t)bh * HD + d] = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+    const kr_bf16 r = __builtin_bit_cast(kr_bf16, f2bf(ll > 0.f ? acc / ll : 0.f));
+    if (heads_xp > 0) {
+        const int b = bh / heads_xp, hh = bh - b * heads_xp;
+        *reinterpret_cast<kr_bf16*>(reinterpret_cast<char*>(out) + kr_xp_byte_offset(b, hh * HD + d)) = r;
+    } else {
+        out[(int64_t)bh * HD + d] = r;
+    }
 }
 
 // =====================================================================================
@@ -2258,6 +2276,12 @@ static int wide_impl(int mode, const kr_bf16* x, int64_t ldx, const void* w_pack
     a.residual = residual; a.ldr = ldr; a.out = out; a.out_f32 = out_f32; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.ksplit = 1; a.amax_val = amax_val; a.amax_idx = amax_idx;
     a.wide_blocks = blocks; a.wide_waves = waves;
+    if (mode & KR_DEC_OUT_XP) {   // SILU8 output in the packed layout of 17..32-row batches
+        KR_CHECK_ARG((mode & ~KR_DEC_OUT_XP) == DEPI_SILU8 && M > 16 && (N / 2) % 64 == 0 && ((uintptr_t)out & 15) == 0,
+                     "kr_linear_decode_wide: KR_DEC_OUT_XP is for SILU8 at 17..32 rows, N/2 %% 64 == 0");
+        a.out_xp = 1;
+        mode &= ~KR_DEC_OUT_XP;
+    }
     switch (mode) {
         case DEPI_PLAIN:
             KR_CHECK_ARG((out || out_f32) && ldc >= N && (ldc & 3) == 0 && (!residual || (ldr & 3) == 0), "kr_linear_decode_wide: PLAIN output");
@@ -2440,7 +2464,7 @@ template <int RL>
 __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ parts,
                                                           int n_part, int part_rows, kr_bf16* __restrict__ x_out, int64_t ldxo,
                                                           const kr_bf16* __restrict__ norm_w, float eps, kr_bf16* __restrict__ h,
-                                                          int64_t ldh, int M, int K) {
+                                                          int64_t ldh, int M, int K, int h_xp) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6), kc = K >> 3;
     if (b >= M) return;
     bf16x8 xv[RL], nw[RL];
@@ -2487,41 +2511,64 @@ __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restr
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[i][j]) * bfround(bf2f(xv[i][j]) * rs));
-            *reinterpret_cast<bf16x8*>(h + (int64_t)b * ldh + c * 8) = o;
+            if (h_xp) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(h) + kr_xp_byte_offset(b, c * 8)) = o;
+            else *reinterpret_cast<bf16x8*>(h + (int64_t)b * ldh + c * 8) = o;
         }
     }
+}
+
+int resnorm_impl(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out, int64_t ldxo,
+                 const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, int h_xp, kr_stream s) {
+    KR_CHECK_ARG(x && norm_w && h, "kr_decode_resnorm: null pointer");
+    KR_CHECK_ARG(M >= 1 && M <= 32 && K > 0 && K % 8 == 0 && K <= 4096, "kr_decode_resnorm: M=%d K=%d (M <= 32, K %% 8, K <= 4096)", M, K);
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && (h_xp ? (K % 64 == 0 && ((uintptr_t)h & 15) == 0) : (ldh >= K && (ldh & 7) == 0)),
+                 "kr_decode_resnorm: ldx / ldh");
+    KR_CHECK_ARG(n_part_in >= 0 && n_part_in <= 8 && (n_part_in == 0 || (part_in && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0)),
+                 "kr_decode_resnorm: partial sums need a separate x_out");
+    KR_CHECK_ARG(n_part_in == 0 || part_rows == 0 || part_rows >= M, "kr_decode_resnorm: part_rows %d < M %d", part_rows, M);
+    const int pr = part_rows > 0 ? part_rows : M, blocks = (M + 3) / 4;
+    if (K <= 1536) dec_resnorm_kernel<3><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    else if (K <= 2048) dec_resnorm_kernel<4><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    else dec_resnorm_kernel<8><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
 }
 }  // namespace
 
 extern "C" int kr_decode_resnorm(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
                                  int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, kr_stream s) {
-    KR_CHECK_ARG(x && norm_w && h, "kr_decode_resnorm: null pointer");
-    KR_CHECK_ARG(M >= 1 && M <= 32 && K > 0 && K % 8 == 0 && K <= 4096, "kr_decode_resnorm: M=%d K=%d (M <= 32, K %% 8, K <= 4096)", M, K);
-    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && ldh >= K && (ldh & 7) == 0, "kr_decode_resnorm: ldx / ldh");
-    KR_CHECK_ARG(n_part_in >= 0 && n_part_in <= 8 && (n_part_in == 0 || (part_in && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0)),
-                 "kr_decode_resnorm: partial sums need a separate x_out");
-    KR_CHECK_ARG(n_part_in == 0 || part_rows == 0 || part_rows >= M, "kr_decode_resnorm: part_rows %d < M %d", part_rows, M);
-    const int pr = part_rows > 0 ? part_rows : M, blocks = (M + 3) / 4;
-    if (K <= 1536) dec_resnorm_kernel<3><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K);
-    else if (K <= 2048) dec_resnorm_kernel<4><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K);
-    else dec_resnorm_kernel<8><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K);
+    return resnorm_impl(x, ldx, part_in, n_part_in, part_rows, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, 0, s);
+}
+
+extern "C" int kr_decode_resnorm32(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
+                                   int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h_xp, int M, int K, kr_stream s) {
+    return resnorm_impl(x, ldx, part_in, n_part_in, part_rows, x_out, ldxo, norm_w, norm_eps, h_xp, 0, M, K, 1, s);
+}
+
+static int merge_impl(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split, int xp, kr_stream s) {
+    KR_CHECK_ARG(workspace && out && batch > 0 && heads > 0 && n_split > 0, "kr_attn_decode_merge: bad args");
+    KR_CHECK_ARG(hd == 128, "kr_attn_decode_merge: hd=%d (only 128)", hd);
+    KR_CHECK_ARG(!xp || (batch <= 32 && ((uintptr_t)out & 15) == 0), "kr_attn_decode_merge32: batch=%d (<= 32)", batch);
+    const int hx = xp ? heads : 0;
+    switch (n_split) {
+        case 4: attn_merge_kernel<4><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split, hx); break;
+        case 8: attn_merge_kernel<8><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split, hx); break;
+        case 16: attn_merge_kernel<16><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split, hx); break;
+        case 32: attn_merge_kernel<32><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split, hx); break;
+        default: attn_merge_kernel<0><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split, hx);
+    }
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
 
 extern "C" int kr_attn_decode_merge(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split,
                                     kr_stream s) {
-    KR_CHECK_ARG(workspace && out && batch > 0 && heads > 0 && n_split > 0, "kr_attn_decode_merge: bad args");
-    KR_CHECK_ARG(hd == 128, "kr_attn_decode_merge: hd=%d (only 128)", hd);
-    switch (n_split) {
-        case 4: attn_merge_kernel<4><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
-        case 8: attn_merge_kernel<8><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
-        case 16: attn_merge_kernel<16><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
-        case 32: attn_merge_kernel<32><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split); break;
-        default: attn_merge_kernel<0><<<batch * heads, 128, 0, kr_hs(s)>>>(workspace, out, n_split);
-    }
-    KR_CHECK_LAUNCH();
-    return KR_OK;
+    return merge_impl(workspace, out, batch, heads, hd, n_split, 0, s);
+}
+
+extern "C" int kr_attn_decode_merge32(const float* workspace, kr_bf16* out_xp, int batch, int heads, int hd, int n_split,
+                                      kr_stream s) {
+    return merge_impl(workspace, out_xp, batch, heads, hd, n_split, 1, s);
 }
 
 extern "C" int kr_gumbel_argmax_guided(const float* logits, int64_t ld_logits, int vocab, const float* temperature,

@@ -20,6 +20,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirna
 from karanta_ocr_amd._lib import lib  # noqa: E402
 from karanta_ocr_amd.config import CONFIGS  # noqa: E402
 from karanta_ocr_amd.engine import Engine  # noqa: E402
+from karanta_ocr_amd.csrc.tools.experiment_engine import ExperimentEngine  # noqa: E402
+
+EXPERIMENT_KEYS = {"fast_residual", "attn_fused_merge", "merge_in_o_proj", "_prefetch_mode", "_extra_nulls", "experiment"}
+EXPERIMENT_ENV = {"KARANTA_PREFETCH", "KARANTA_FAST_RESIDUAL", "KARANTA_ATTN_FUSED", "KARANTA_MERGE_IN_OPROJ", "KARANTA_EXTRA_NULLS"}
 
 
 def fill_random(arena: torch.Tensor):
@@ -44,7 +48,8 @@ def main():
     ap.add_argument("--chain", default=None,
                     help="instead of whole steps: time ONE kind of launch as a chain over the layers' weights (graph of reps x "
                          "layers launches; the per-launch figure includes the dependent-launch gap): comma-separated list of "
-                         "qkv,attn,merge,o,oheads,gateup,gateup32,down,merge+o")
+                         "qkv,qkv0,attn,merge,o,oheads,gateup,gateup32,down,merge+o; the 17..32-row packed family: resnorm32,qkv32,"
+                         "merge32,o32,gateupxp,down32,down32t1,down32t2; round 3's > 16-row forms: resnorm,qkvd")
     ap.add_argument("--cus", default=None,
                     help="comma-separated CU counts: replay each variant's graph on a stream masked to the first N compute units "
                          "(kr_stream_create_cu_mask) — what a decode step keeps when part of the chip is given to something else")
@@ -70,8 +75,10 @@ def main():
                 over[k] = v
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
-        eng = Engine(cfg, max_batch=B, s_max=s_max, max_patches=64, max_prompt_tokens=64,
-                     decode_splits=int(over.pop("n_split", 16)), weight_dtype=a.weights)
+        cls = ExperimentEngine if (EXPERIMENT_KEYS & set(over) or EXPERIMENT_ENV & set(env)) else Engine
+        over.pop("experiment", None)
+        eng = cls(cfg, max_batch=B, s_max=s_max, max_patches=64, max_prompt_tokens=64,
+                  decode_splits=int(over.pop("n_split", 16)), weight_dtype=a.weights)
         over.pop("steps_per_graph", None)     # handled where the graph is captured
         for k, v in old.items():
             if v is None:
@@ -189,7 +196,7 @@ def main():
 
 def chains(a, engines, reset):
     """Per-launch time of single kinds of decode launches (see --chain)."""
-    from karanta_ocr_amd._lib import DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, ptr
+    from karanta_ocr_amd._lib import DEC_OUT_XP, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, ptr
     L = lib()
     B = a.batch
     e0, e1 = C.c_void_p(), C.c_void_p()
@@ -207,7 +214,7 @@ def chains(a, engines, reset):
             elif kind == "qkv0":                   # no pending slabs: the prologue reads x only
                 eng._dec_narrow(DEC_ROPE_KV, eng.d_x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                                 kc=kc, vc=vc, **eng._w8kw(p + "qkv.w"))
-            elif kind.startswith("down") and len(kind) > 4:      # down<ksplit>[w<waves>]: e.g. down3, down4w8
+            elif kind.startswith("down") and len(kind) > 4 and not kind.startswith("down32"):      # down<ksplit>[w<waves>]: e.g. down3, down4w8
                 import re
                 m = re.fullmatch(r"down(\d)(?:w(\d+))?", kind)
                 ks, wv = int(m.group(1)), int(m.group(2) or 16)
@@ -215,6 +222,27 @@ def chains(a, engines, reset):
                     eng._slabs_x = torch.zeros(8, eng.B, t.hidden_size, dtype=torch.float32, device=eng.device)
                 eng._dec_narrow(DEC_PLAIN, eng.d_act, w.view(p + "down.w"), B, out_f32=eng._slabs_x, waves=wv, ksplit=ks,
                                 **eng._w8kw(p + "down.w"))
+            elif kind in ("resnorm", "resnorm32"):
+                args = (ptr(eng.d_x), eng.d_x.stride(0), ptr(eng.d_part[:1]), 1, B, ptr(eng.d_x2), eng.d_x2.stride(0), ptr(w.view(p + "ln1.w")),
+                        t.rms_norm_eps, ptr(eng.d_h))
+                if kind == "resnorm32":
+                    L.kr_decode_resnorm32(*args, B, t.hidden_size, eng.s)
+                else:
+                    L.kr_decode_resnorm(*args, eng.d_h.stride(0), B, t.hidden_size, eng.s)
+            elif kind == "qkvd":
+                eng._dec_narrow(DEC_ROPE_KV, eng.d_h, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), kc=kc, vc=vc, **eng._w8kw(p + "qkv.w"))
+            elif kind == "qkv32":
+                eng._dec32(DEC_ROPE_KV, eng.d_h, w.view(p + "qkv.w"), B, 8, bias=w.view(p + "qkv.b"), kc=kc, vc=vc, **eng._w8kw(p + "qkv.w"))
+            elif kind == "merge32":
+                L.kr_attn_decode_merge32(ptr(eng.d_ws), ptr(eng.d_o), B, H, hd, eng.n_split, eng.s)
+            elif kind == "o32":
+                eng._dec32(DEC_PLAIN, eng.d_o, w.view(p + "o.w"), B, eng.o_waves, out=eng.d_x, res=eng.d_x, **eng._w8kw(p + "o.w"))
+            elif kind == "gateupxp":
+                eng._dec_wide(DEC_SILU8 | DEC_OUT_XP, eng.d_x, w.view(p + "gate_up.w"), B, out=eng.d_act, norm_w=w.view(p + "ln2.w"),
+                              **eng._w8kw(p + "gate_up.w"))
+            elif kind in ("down32", "down32t1", "down32t2"):
+                eng._dec32(DEC_PLAIN, eng.d_act, w.view(p + "down.w"), B, eng.down_waves_small, ksplit=2, out_f32=eng.d_part,
+                           tiles_per_wg={"down32": 0, "down32t1": 1, "down32t2": 2}[kind], **eng._w8kw(p + "down.w"))
             elif kind == "attn":
                 L.kr_attn_decode_fused(ptr(eng.d_q), kc, vc, ptr(eng.d_ctx), 0, ptr(eng.d_ws), 0, B, H, KVH, hd, eng.s_max, eng.n_split,
                                        hd ** -0.5, eng.s)

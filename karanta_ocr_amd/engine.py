@@ -23,7 +23,7 @@ import torch
 
 from . import image_processing as IP
 from . import positions as POS
-from ._lib import (DEC_ARGMAX, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8,
+from ._lib import (DEC_ARGMAX, DEC_OUT_XP, DEC_PLAIN, DEC_ROPE_KV, DEC_SILU8, Dec32, EPI_GELU_ERF, EPI_NONE, EPI_QUICK_GELU, EPI_SILU_MUL8,
                    KarantaHipError, lib, narrow_opts, ptr)
 from .config import ModelConfig
 from .weights import pack_w16x64, to_bf16_bits
@@ -268,9 +268,7 @@ class DeviceGuide:
 class Engine:
     def __init__(self, cfg: ModelConfig, device: str = "cuda:0", max_batch: int = 8, s_max: int = 4096,
                  max_patches: int = 8 * 5476, max_prompt_tokens: int = 8 * 2048, decode_splits: int = 16,
-                 weight_dtype: str = "bf16", fast_residual: Optional[bool] = None, fp8_activations: Optional[bool] = None,
-                 admission_cus: Optional[int] = None):
-        self._want_fast_residual = (os.environ.get("KARANTA_FAST_RESIDUAL", "0") == "1") if fast_residual is None else bool(fast_residual)
+                 weight_dtype: str = "bf16", fp8_activations: Optional[bool] = None, admission_cus: Optional[int] = None):
         if not torch.cuda.is_available():
             raise KarantaHipError("no HIP device: the karanta MI355X engine has no CPU fallback")
         self.L = lib()
@@ -304,14 +302,11 @@ class Engine:
         self.n_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._resample_cache: Dict[tuple, tuple] = {}   # (h, w, rh, rw) -> device tables of the GPU image front end
         self.persist_blocks = int(os.environ.get("KARANTA_PERSIST_BLOCKS", "512"))  # 2 persistent workgroups per CU (swept: 256..1024)
-        self._extra_nulls = int(os.environ.get("KARANTA_EXTRA_NULLS", "0"))
-        self._prefetch_mode = int(os.environ.get("KARANTA_PREFETCH", "0"))
-        self._pf_blocks = int(os.environ.get("KARANTA_PREFETCH_BLOCKS", "256"))
-        self._pf_stream = None
-        self.merge_in_o_proj = os.environ.get("KARANTA_MERGE_IN_OPROJ", "0") == "1"  # measured slower; kept for A/B
-        if not self.L.experiments and (self._prefetch_mode or self._want_fast_residual or os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"):
-            raise KarantaHipError("KARANTA_PREFETCH / KARANTA_FAST_RESIDUAL / KARANTA_ATTN_FUSED are decode experiments: build a library "
-                                  "with -DKR_EXPERIMENTS (csrc/tools/build_variant.py) and load it through KARANTA_HIP_LIB")
+        if type(self) is Engine and any(os.environ.get(k, "0") not in ("", "0") for k in
+                                        ("KARANTA_PREFETCH", "KARANTA_FAST_RESIDUAL", "KARANTA_ATTN_FUSED", "KARANTA_MERGE_IN_OPROJ")):
+            raise KarantaHipError("KARANTA_PREFETCH / KARANTA_FAST_RESIDUAL / KARANTA_ATTN_FUSED / KARANTA_MERGE_IN_OPROJ are decode "
+                                  "experiments: they run on csrc/tools/experiment_engine.ExperimentEngine with a -DKR_EXPERIMENTS "
+                                  "library (csrc/tools/build_variant.py, KARANTA_HIP_LIB), not on the product engine")
         v, t = cfg.vision, cfg.text
         if v.head_dim not in (80, 128) or t.head_dim != 128:
             raise KarantaHipError(f"unsupported head dims vit={v.head_dim} llm={t.head_dim}")
@@ -385,15 +380,16 @@ class Engine:
         # 8-wave workgroups with a 5-deep ring then beat 16-wave ones (7B step 2.992 -> 2.975 ms)
         if t.hidden_size // 16 >= 192:
             self.down_waves_small = 8
-        self.d_xacc = z(B, t.hidden_size, dtype=torch.float32)     # fast-residual mode: f32 residual accumulator
         self.d_qkv = z(B, t.qkv_dim)
-        self.d_h = z(B, t.hidden_size)   # batches above 16 rows: the normalised rows of kr_decode_resnorm (the qkv launch's x)
+        # batches above 16 rows keep the inputs of their decode linears in the PACKED layout of kr_linear_decode32 (32 row
+        # slots whatever the batch): d_h (normalised rows of kr_decode_resnorm32), d_o (merged heads), d_act (SiLU * up)
+        Bp = 32 if B > 16 else B
+        self.d_h = z(Bp, t.hidden_size)
         self.d_q = z(B, t.num_heads, t.head_dim)
-        self.d_o = z(B, t.q_dim)
-        self.d_act = z(B, t.intermediate_size)
+        self.d_o = z(Bp, t.q_dim)
+        self.d_act = z(Bp, t.intermediate_size)
         self.d_logits = z(B, t.vocab_size, dtype=torch.float32)
         self.d_ws = z(B * t.num_heads * self.n_split * (t.head_dim + 4), dtype=torch.float32)
-        self.d_cnt = z(B * t.num_kv_heads, dtype=torch.int32)  # arrival counters of the in-launch attention merge
         # waves per workgroup of the narrow decode linears: enough waves that every wave still
         # streams >= 2 K-chunks, no cross-workgroup reduction (each fence/atomic hop costs microseconds)
         self.wv_qkv = self._waves(t.hidden_size // 64)
@@ -406,15 +402,10 @@ class Engine:
                 setattr(self, "wv_" + name, int(v_))
         # qkv / o_proj / down_proj: kr_linear_decode_narrow; down_proj split over 2 workgroups per tile with the
         # reduction deferred to the next layer's qkv prologue (K = 1536 / 2048 / 3584 only)
-        self.attn_fused_merge = os.environ.get("KARANTA_ATTN_FUSED", "0") == "1"
         self.narrow_mode = os.environ.get("KARANTA_NARROW", "1") == "1"
         self.narrow_o = self.narrow_mode and os.environ.get("KARANTA_NARROW_O", "1") == "1"
         self.defer_down = (self.narrow_mode and os.environ.get("KARANTA_DEFER_DOWN", "1") == "1"
                            and t.hidden_size in (1536, 2048, 3584))
-        # FAST-RESIDUAL mode (KARANTA_FAST_RESIDUAL=1, Engine(fast_residual=True)): o_proj split by attention head with
-        # the split-KV merge in its prologue and float atomics into an f32 residual accumulator — one launch fewer per
-        # layer (no attn_merge_kernel).  Sums in arrival order: not bit-reproducible; the default stays deterministic.
-        self.fast_residual = bool(getattr(self, "_want_fast_residual", False)) and self.narrow_mode
         # gate/up and lm_head: one wave per 16-row tile (kr_linear_decode_wide) when K allows it
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
@@ -432,9 +423,14 @@ class Engine:
         # (Qwen2-VL-2B, same-box A/B: 1.957 vs 1.979 ms) and stays off.  KARANTA_RESNORM_QKV = 0 / 1 forces either.
         env_rn = os.environ.get("KARANTA_RESNORM_QKV")
         self.resnorm_qkv = (env_rn == "1") if env_rn is not None else self.row_split
+        # > 16 rows: the packed-activation family (kr_linear_decode32) for qkv (behind kr_decode_resnorm32), o_proj and
+        # down_proj; KARANTA_DEC32=0: round 3's two-column-tile instantiations of the narrow kernel (row-major x fragments)
+        # ... with kr_decode_resnorm32 + the packed qkv launch also at the widths whose fused qkv launch fits (KARANTA_RESNORM32_QKV)
+        self.resnorm32_qkv = os.environ.get("KARANTA_RESNORM32_QKV", "1") == "1"
+        self.family32 = (self.B > 16 and self.narrow_mode and self.narrow_o and t.intermediate_size % 64 == 0 and t.q_dim % 64 == 0
+                         and t.hidden_size % 64 == 0 and os.environ.get("KARANTA_DEC32", "1") == "1")
         if self.row_split and t.hidden_size != 3584:
             raise KarantaHipError("max_batch > 16: hidden_size <= 2048 or == 3584 (the 7B width) only")
-        self.fast_residual = self.fast_residual and self.wide_mode and not self.row_split
         if self.fp8 and not (self.wide_mode and self.narrow_mode):
             raise KarantaHipError("fp8 weights need the wide / narrow decode kernels: hidden_size % 512 == 0 and <= 4096")
         # one argmax partial per wave of the lm_head launch; the launch geometry depends on the row count (8 waves above
@@ -472,19 +468,6 @@ class Engine:
         self.d_invfreq = torch.from_numpy(POS.rope_inv_freq(t.head_dim, t.rope_theta)).to(dev)
         self.d_last = z(B, dtype=torch.int32)
         torch.cuda.synchronize(dev)
-
-    def _pf_events(self, layer: int):
-        """(fork, join) events of layer `layer`'s prefetch branch, and the side stream they need (created on first use)."""
-        if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=self.device)
-            self._pf_ev = {}
-        ev = self._pf_ev.get(layer)
-        if ev is None:
-            a, b = C.c_void_p(), C.c_void_p()
-            self.L.kr_event_create(C.byref(a))
-            self.L.kr_event_create(C.byref(b))
-            ev = self._pf_ev[layer] = (a, b)
-        return ev
 
     @staticmethod
     def _waves(nchunks: int) -> int:
@@ -527,12 +510,11 @@ class Engine:
                                 ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
 
     def _dec_narrow(self, mode, x, W, M, out=None, out_f32=None, bias=None, norm_w=None, res=None, waves=8, ksplit=1,
-                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, x_out_f32=None, part_rows=0, row0=0,
-                    zero=None, atomic_out=False, prefetch=None):
+                    part_in=None, x_out=None, kc=0, vc=0, w8=None, w_scale=None, part_rows=0, row0=0,
+                    zero=None, atomic_out=False, **experiment):
         """kr_linear_decode_narrow: one workgroup per tile (pair); ksplit > 1 = deferred split-K slabs in out_f32.
         w8 / w_scale: the fp8 copy of W and its row scales (kr_linear_decode_narrow_fp8).  zero (an f32 tensor the launch
-        also zeroes), atomic_out, part_rows: the launch's kr_narrow_opts.  x_out_f32 / prefetch = (address, bytes, blocks):
-        experiment builds only (kr_linear_decode_narrow_x32)."""
+        also zeroes), atomic_out, part_rows: the launch's kr_narrow_opts."""
         t = self.cfg.text
         N, K = W.shape
         o = out if out is not None else out_f32
@@ -546,17 +528,27 @@ class Engine:
                 ptr(self.d_plen[row0:]), ptr(self.d_ctx[row0:]), ptr(self.d_q[row0:]),
                 kc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if kc else 0,
                 vc + 2 * row0 * t.num_kv_heads * self.s_max * t.head_dim if vc else 0, t.num_heads, t.num_kv_heads, self.s_max, opts)
-        if x_out_f32 is not None or prefetch is not None:
-            # experiment builds: workgroup 0 also stores x_new as the f32 accumulator's start value (fast-residual mode);
-            # prefetch workgroups ride on the launch
-            pf = prefetch or (0, 0, 0)
-            self.L.kr_linear_decode_narrow_x32(*head, ptr(x_out_f32), x_out_f32.stride(0) if x_out_f32 is not None else 0,
-                                               ptr(w8 if w8 is not None else W), ptr(w_scale), *tail, int(pf[0]), int(pf[1]), int(pf[2]),
-                                               self.s)
+        if experiment:      # csrc/tools/experiment_engine.py (x_out_f32, prefetch: kr_linear_decode_narrow_x32)
+            self._dec_narrow_experiment(head, tail, W, w8, w_scale, **experiment)
         elif w8 is not None:
             self.L.kr_linear_decode_narrow_fp8(*head, ptr(w8), ptr(w_scale), *tail, self.s)
         else:
             self.L.kr_linear_decode_narrow(*head, ptr(W), *tail, self.s)
+
+    def _dec32(self, mode, xp, W, M, waves_ref, out=None, out_f32=None, bias=None, res=None, ksplit=1, atomic_out=False, zero=None,
+               kc=0, vc=0, w8=None, w_scale=None, tiles_per_wg=0):
+        """kr_linear_decode32: the decode linears of a 17..32-row batch on PACKED activations (xp: kr_pack_rows32 layout, written
+        by kr_decode_resnorm32 / kr_attn_decode_merge32 / the gate/up launch with DEC_OUT_XP), with the K partition of the
+        <= 16-row launch of the same layer (waves_ref, ksplit): row for row the bits that launch produces."""
+        t = self.cfg.text
+        N, K = W.shape
+        o = out if out is not None else out_f32
+        a = Dec32(ptr(xp), ptr(w8 if w8 is not None else W), ptr(w_scale), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
+                  ptr(out), ptr(out_f32), o.stride(-2) if o is not None else 0, M, N, K, waves_ref, ksplit, 1 if atomic_out else 0,
+                  tiles_per_wg, ptr(zero) if zero is not None else None, zero.numel() * 4 if zero is not None else 0,
+                  ptr(self.d_cs), self.max_new, ptr(self.d_plen), ptr(self.d_ctx), ptr(self.d_q), kc or None, vc or None,
+                  t.num_heads, t.num_kv_heads, self.s_max)
+        self.L.kr_linear_decode32(mode, C.byref(a), self.s)
 
     down_waves_small = 16         # waves per down_proj workgroup at <= 16 rows (instance attribute for sweeps)
     o_waves = 8                   # waves per o_proj workgroup at <= 16 rows
@@ -595,20 +587,11 @@ class Engine:
         wb, ww = self._wide_geometry(self.cfg.text.vocab_size, M)
         return wb * ww
 
-    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None, x_f32=None, x_out=None,
-                  amax_row0: int = 0):
-        """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream.
-        x_f32 (fast-residual mode): the rows come from the f32 residual accumulator instead of x; x_out receives their
-        bf16 rounding (workgroup 0)."""
+    def _dec_wide(self, mode, x, W, M, out=None, out_f32=None, norm_w=None, w8=None, w_scale=None, amax_row0: int = 0):
+        """kr_linear_decode_wide: `wide_blocks` workgroups (one per CU), each wave an independent weight stream."""
         N, K = W.shape
         blocks, waves = self._wide_geometry(N, M)
         o = out if out is not None else out_f32
-        if x_f32 is not None:
-            self.L.kr_linear_decode_wide_x32(mode, ptr(x_f32), x_f32.stride(0), ptr(x_out), x_out.stride(0) if x_out is not None else 0,
-                                             ptr(w8 if w8 is not None else W), ptr(w_scale), ptr(norm_w), self.cfg.text.rms_norm_eps,
-                                             ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0, M, N, K, blocks, waves,
-                                             ptr(self.d_amax_v), ptr(self.d_amax_i), self.s)
-            return
         av, ai = self.d_amax_v.view(-1)[amax_row0 * blocks * waves:], self.d_amax_i.view(-1)[amax_row0 * blocks * waves:]
         tail = (0, ptr(norm_w), self.cfg.text.rms_norm_eps, 0, 0, ptr(out), ptr(out_f32), o.stride(0) if o is not None else 0,
                 M, N, K, blocks, waves, ptr(av), ptr(ai), self.s)
@@ -1118,153 +1101,100 @@ class Engine:
 
     # ------------------------------------------------------------------ decode
     def _decode_step_launches(self, B: int):
-        """One decode step = 6 launches per layer + 2 (Qwen2VLDecoderLayer TF:559-624, final norm
-        TF:839, lm_head TF:1320-1323): [(down_proj slabs +) RMSNorm+QKV+bias+M-RoPE+KV append] -> attention
-        partials -> merge -> [o_proj+residual] -> [RMSNorm+gate/up+SiLU*mul] -> [down_proj (+residual | slabs)]."""
+        """One decode step = 6 launches per layer + 2 (Qwen2VLDecoderLayer TF:559-624, final norm TF:839, lm_head
+        TF:1320-1323): [(down_proj slab +) RMSNorm + QKV + bias + M-RoPE + KV append] -> attention partials -> merge ->
+        [o_proj + residual] -> [RMSNorm + gate/up + SiLU*mul] -> [down_proj (+ residual | slab)].  Above 16 rows the residual
+        sum + RMSNorm may run as a launch of their own (kr_decode_resnorm32) and the narrow linears read PACKED activations
+        (kr_linear_decode32): same sums, row for row.  The measured-and-not-adopted variants of this sequence (prefetch
+        branches, fast-residual mode, in-launch merges) live in csrc/tools/experiment_engine.py."""
         t, L, w, s = self.cfg.text, self.L, self.w, self.s
         H, KVH, hd = t.num_heads, t.num_kv_heads, t.head_dim
         nl = t.num_layers
-        x, x_other = self.d_x, self.d_x2   # residual stream: swaps buffers at every deferred reduction
-        pending = False                    # down_proj slabs of the previous layer waiting in d_part
+        f32 = B > 16 and self.family32            # packed-activation family of 17..32-row batches
+        x, x_other = self.d_x, self.d_x2          # residual stream: swaps buffers at every deferred reduction
+        pending = False                           # down_proj's split-K sums of the previous layer waiting in d_part
+        slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packs them
+        one_slab = self.atomic_slab and self.defer_down
         for i in range(nl):
             p = f"llm.{i}."
-            # the cache tensor is [layers, max_batch, ...]: hand the kernels layer i's base
-            kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])
-            if self._prefetch_mode == 1:  # diagnostic: serial prefetch of this layer's weights into the Infinity Cache
-                a0 = w.layout[p + "ln1.w"][0]
-                a1 = w.layout[p + "down.w"][0] + 2 * int(np.prod(w.layout[p + "down.w"][1]))
-                L.kr_prefetch(w.arena.data_ptr() + a0, a1 - a0, 512, s)
-            joined = None
-            if self._prefetch_mode in (2, 3):
-                # SECOND GRAPH BRANCH (VERDICT r1 next #2 (i)): while this layer's latency-bound chain qkv -> attention ->
-                # merge -> o_proj runs (25 us moving 25 MB), a side stream pulls the layer's MLP weights (mode 2: gate/up +
-                # down, 82.5 MB of the 2B model; mode 3: down only) into the 256 MB Infinity Cache; the branch joins
-                # before the gate/up launch.  In a stream capture the event pair forks / joins the graph.
-                first = "gate_up.w" if self._prefetch_mode == 2 else "down.w"
-                a0 = w.layout[p + first][0]
-                a1 = w.layout[p + "down.w"][0] + 2 * int(np.prod(w.layout[p + "down.w"][1]))
-                if self.fp8 and w.has(p + "down.w8"):
-                    a0 = w.layout[p + ("gate_up.w8" if self._prefetch_mode == 2 else "down.w8")][0]
-                    a1 = w.layout[p + "down.s"][0]
-                ef, joined = self._pf_events(i)
-                L.kr_event_record(ef, s)
-                L.kr_stream_wait_event(self._pf_stream.cuda_stream, ef)
-                L.kr_prefetch(w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks, self._pf_stream.cuda_stream)
-                L.kr_event_record(joined, self._pf_stream.cuda_stream)
-            fast = self.fast_residual
-            xacc = self.d_xacc if fast else None     # qkv's workgroup 0 leaves x_new there as f32; o_proj adds into it
-            pf = None
-            if self._prefetch_mode in (4, 5, 6) and self.narrow_mode:
-                # PIGGYBACK PREFETCH (experiment builds): the qkv launch occupies 64 of the 256 CUs; extra workgroups of the
-                # same launch pull this layer's down_proj weights (mode 4), gate/up + down (5) or gate/up (6) into the
-                # Infinity Cache
-                lo = "down.w" if self._prefetch_mode == 4 else "gate_up.w"
-                hi = "gate_up.w" if self._prefetch_mode == 6 else "down.w"
-                sfx = "8" if (self.fp8 and w.has(p + "down.w8")) else ""
-                a0 = w.layout[p + lo + sfx][0]
-                a1 = w.layout[p + hi + sfx][0] + (1 if sfx else 2) * int(np.prod(w.layout[p + hi + sfx][1]))
-                pf = (w.arena.data_ptr() + a0, a1 - a0, self._pf_blocks)
-            if self.narrow_mode:
-                ranges = self._row_ranges(B)
-                slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packs them
-                one_slab = self.atomic_slab and self.defer_down
-                # this layer's down_proj will ADD into accumulator (i + 1) & 1: the (first) qkv launch zeroes it (it was last
-                # read by layer i - 1's qkv launch, which is complete)
-                zero = slabs[(i + 1) & 1] if (one_slab and i + 1 < nl) else None
-                if B > 16 and self.resnorm_qkv and xacc is None and pf is None:
-                    # ABOVE 16 ROWS: the residual sum + RMSNorm run ONCE for the batch (kr_decode_resnorm: bit-identical rows),
-                    # then ONE qkv launch over all rows reads its x fragments straight from L2 — instead of every one of the
-                    # 64-144 workgroups staging 32 rows of x + slab (294 KB at the 2B width) and, at the 7B width, two launches
-                    # over 16-row ranges that stream the weights twice (r3 kernel trace, 7B at 32 rows: 2 x 15.8 us per layer)
-                    pin = (slabs[i & 1:(i & 1) + 1] if one_slab else slabs) if pending else None
-                    L.kr_decode_resnorm(ptr(x), x.stride(0), ptr(pin), int(pin.shape[0]) if pin is not None else 0, B,
-                                        ptr(x_other), x_other.stride(0), ptr(w.view(p + "ln1.w")), t.rms_norm_eps, ptr(self.d_h),
-                                        self.d_h.stride(0), B, t.hidden_size, s)
-                    if pending:
-                        x, x_other = x_other, x
-                        pending = False
-                    self._dec_narrow(DEC_ROPE_KV, self.d_h, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), kc=kc, vc=vc, zero=zero,
-                                     **self._w8kw(p + "qkv.w"))
-                elif pending:
-                    for k, (r0, m) in enumerate(ranges):
-                        pin = slabs[i & 1:(i & 1) + 1, r0:] if one_slab else slabs[:, r0:]
-                        self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
-                                         norm_w=w.view(p + "ln1.w"), part_in=pin, x_out=x_other[r0:], kc=kc, vc=vc,
-                                         x_out_f32=None if xacc is None else xacc[r0:], part_rows=B if len(ranges) > 1 else 0,
-                                         row0=r0, zero=zero if k == 0 else None, prefetch=pf if k == 0 else None,
-                                         **self._w8kw(p + "qkv.w"))
-                    x, x_other = x_other, x
-                    pending = False
-                else:
-                    for k, (r0, m) in enumerate(ranges):
-                        self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
-                                         norm_w=w.view(p + "ln1.w"), kc=kc, vc=vc, x_out_f32=None if xacc is None else xacc[r0:],
-                                         row0=r0, zero=zero if k == 0 else None, prefetch=pf if k == 0 else None,
-                                         **self._w8kw(p + "qkv.w"))
-            else:
+            kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])     # the cache tensors are [layers, max_batch, ...]
+            # ---- 1. (x += down_proj sums of layer i - 1) -> RMSNorm -> QKV + bias + M-RoPE + KV append
+            if not self.narrow_mode:
                 self._dec(DEC_ROPE_KV, x, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), norm_w=w.view(p + "ln1.w"),
                           waves=self.wv_qkv, kc=kc, vc=vc)
-            if self.attn_fused_merge and not fast:  # the last split workgroup of each (sequence, kv head) merges: no merge launch
-                L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_o), ptr(self.d_ws), ptr(self.d_cnt),
-                                       B, H, KVH, hd, self.s_max, self.n_split, hd ** -0.5, s)
             else:
-                L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd,
-                                       self.s_max, self.n_split, hd ** -0.5, s)
-            if fast:
-                # [merge of head h's partials + W_o[:, head h] + atomic add into the f32 residual]: no merge launch
-                w8o, sco = self._w8(p + "o.w")
-                L.kr_oproj_heads(ptr(self.d_ws), self.n_split, ptr(w8o if w8o is not None else w.view(p + "o.w")), ptr(sco),
-                                 ptr(self.d_xacc), self.d_xacc.stride(0), B, t.hidden_size, H, s)
-            elif self.attn_fused_merge:
-                if self.narrow_o:
-                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.o_waves if B <= 16 else 8, **self._w8kw(p + "o.w"))
+                # this layer's down_proj will ADD into accumulator (i + 1) & 1: the qkv launch zeroes it (it was last read by
+                # layer i - 1's qkv launch, which is complete)
+                zero = slabs[(i + 1) & 1] if (one_slab and i + 1 < nl) else None
+                pin = ((slabs[i & 1:(i & 1) + 1] if one_slab else slabs) if pending else None)
+                if B > 16 and (self.resnorm_qkv or f32 and self.resnorm32_qkv):
+                    # the residual sum + RMSNorm ONCE for the batch (bit-identical rows), then ONE qkv launch over all rows
+                    args = (ptr(x), x.stride(0), ptr(pin), int(pin.shape[0]) if pin is not None else 0, B, ptr(x_other),
+                            x_other.stride(0), ptr(w.view(p + "ln1.w")), t.rms_norm_eps, ptr(self.d_h))
+                    if f32:
+                        L.kr_decode_resnorm32(*args, B, t.hidden_size, s)
+                        self._dec32(DEC_ROPE_KV, self.d_h, w.view(p + "qkv.w"), B, 8, bias=w.view(p + "qkv.b"), kc=kc, vc=vc,
+                                    zero=zero, **self._w8kw(p + "qkv.w"))
+                    else:
+                        L.kr_decode_resnorm(*args, self.d_h.stride(0), B, t.hidden_size, s)
+                        self._dec_narrow(DEC_ROPE_KV, self.d_h, w.view(p + "qkv.w"), B, bias=w.view(p + "qkv.b"), kc=kc, vc=vc,
+                                         zero=zero, **self._w8kw(p + "qkv.w"))
                 else:
-                    self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
-            elif self.merge_in_o_proj:
-                self._dec(DEC_PLAIN, None, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o,
-                          attn_partials=self.d_ws)
+                    for k, (r0, m) in enumerate(self._row_ranges(B)):     # one launch, or one per 16-row range (row_split)
+                        self._dec_narrow(DEC_ROPE_KV, x[r0:], w.view(p + "qkv.w"), m, bias=w.view(p + "qkv.b"),
+                                         norm_w=w.view(p + "ln1.w"), part_in=pin[:, r0:] if pin is not None else None,
+                                         x_out=x_other[r0:] if pin is not None else None, kc=kc, vc=vc,
+                                         part_rows=B if (pin is not None and self.row_split and B > 16) else 0, row0=r0,
+                                         zero=zero if k == 0 else None, **self._w8kw(p + "qkv.w"))
+                if pending:
+                    x, x_other = x_other, x
+                    pending = False
+            # ---- 2. split-KV attention partials, 3. their merge
+            L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd, self.s_max, self.n_split,
+                                   hd ** -0.5, s)
+            if f32:
+                L.kr_attn_decode_merge32(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
             else:
                 L.kr_attn_decode_merge(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
-                if self.narrow_o:
-                    self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.o_waves if B <= 16 else 8, **self._w8kw(p + "o.w"))
-                else:
-                    self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
-            if joined is not None:
-                L.kr_stream_wait_event(s, joined)
+            # ---- 4. o_proj + residual
+            if f32:
+                self._dec32(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, self.o_waves, out=x, res=x, **self._w8kw(p + "o.w"))
+            elif self.narrow_o:
+                self._dec_narrow(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.o_waves if B <= 16 else 8,
+                                 **self._w8kw(p + "o.w"))
+            else:
+                self._dec(DEC_PLAIN, self.d_o, w.view(p + "o.w"), B, out=x, res=x, waves=self.wv_o)
+            # ---- 5. RMSNorm + gate/up + SiLU*mul (the kernel bench.py's roofline object is measured on)
             if self._prof_on:
                 # [e0][e1] gate/up [e2]: the empty bracket e0..e1 measures what two back-to-back event
                 # packets cost by themselves; it is subtracted from the bracket around the launch
                 (e0, e1), (e2, _) = self._prof_event_pair(), self._prof_event_pair()
                 L.kr_event_record(e0, s)
                 L.kr_event_record(e1, s)
-            if fast:   # reads the accumulated f32 residual, rounds it once; workgroup 0 leaves the bf16 rows in x
-                self._dec_wide(DEC_SILU8, None, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
-                               x_f32=self.d_xacc, x_out=x, **self._w8kw(p + "gate_up.w"))
-            elif self.wide_mode:
-                self._dec_wide(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
-                               **self._w8kw(p + "gate_up.w"))
+            if self.wide_mode:
+                self._dec_wide(DEC_SILU8 | (DEC_OUT_XP if f32 else 0), x, w.view(p + "gate_up.w"), B, out=self.d_act,
+                               norm_w=w.view(p + "ln2.w"), **self._w8kw(p + "gate_up.w"))
             else:
-                self._dec(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"),
-                          waves=self.wv_wide)
+                self._dec(DEC_SILU8, x, w.view(p + "gate_up.w"), B, out=self.d_act, norm_w=w.view(p + "ln2.w"), waves=self.wv_wide)
             if self._prof_on:
                 L.kr_event_record(e2, s)
-            if self.defer_down and i + 1 < nl:
-                # 2 workgroups per tile; the slabs are added to x by the next layer's qkv prologue
-                if self.atomic_slab:
-                    acc = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)[(i + 1) & 1]
-                    self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=acc, waves=self._down_waves(B), ksplit=2,
-                                     atomic_out=True, **self._w8kw(p + "down.w"))
-                else:
-                    self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=self.d_part, waves=self._down_waves(B),
-                                     ksplit=2, **self._w8kw(p + "down.w"))
-                pending = True
+            # ---- 6. down_proj: two K ranges per tile whose sums the next layer's first launch adds to x (deferred split-K),
+            # or (last layer / widths without the deferral) down_proj + residual
+            defer = self.defer_down and i + 1 < nl
+            acc = slabs[(i + 1) & 1] if (defer and self.atomic_slab) else (self.d_part if defer else None)
+            if f32:
+                self._dec32(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, self.down_waves_small, ksplit=2 if defer else 1,
+                            out_f32=acc, atomic_out=defer and self.atomic_slab, out=None if defer else x, res=None if defer else x,
+                            **self._w8kw(p + "down.w"))
+            elif defer:
+                self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out_f32=acc, waves=self._down_waves(B), ksplit=2,
+                                 atomic_out=self.atomic_slab, **self._w8kw(p + "down.w"))
             elif self.narrow_mode:
                 self._dec_narrow(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self._down_waves(B),
                                  **self._w8kw(p + "down.w"))
             else:
                 self._dec(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, out=x, res=x, waves=self.wv_down)
-            for _ in range(self._extra_nulls):  # diagnostic: price of one more (empty) launch in the chain
-                L.kr_launch_null(s)
+            pending = defer
         self._lm_head_and_sample(B, x)
 
     # ------------------------------------------------------------------ live kernel timing (bench.py roofline)
@@ -1639,18 +1569,6 @@ class Engine:
         """Host-side stop (length limit): the slot idles from the next step on."""
         with torch.cuda.stream(self.stream):
             self.d_fin[slot:slot + 1].fill_(1)
-
-    def set_fast_residual(self, on: bool):
-        """Switch between the deterministic decode step (split-KV merge launch + slab reductions) and the fast-residual
-        one (per-head o_proj with float atomics); captured graphs of the other mode are dropped."""
-        on = bool(on) and self.narrow_mode and self.wide_mode and not self.row_split and self.L.experiments   # an experiment build only
-        if on != self.fast_residual:
-            self.stream.synchronize()
-            for g in self._graphs.values():
-                self.L.kr_graph_destroy(g)
-            self._graphs.clear()
-            self.fast_residual = on
-        return self.fast_residual
 
     def close(self):
         for g in self._graphs.values():

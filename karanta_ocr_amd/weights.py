@@ -246,6 +246,24 @@ def pack_w16x64(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(w.reshape(n // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)).reshape(n, k)
 
 
+def pack_rows32(x: np.ndarray) -> np.ndarray:
+    """Row-major activations ``[M <= 32, K]`` -> the packed layout of 17..32-row decode batches
+    ``[K/64][2][2][4][16][8]`` (include/karanta_hip.h, kr_pack_rows32; rows >= M are zero): element (row b, column k)
+    sits at chunk k // 64, column tile b // 16, k-step (k // 32) % 2, lane group (k // 8) % 4, lane row b % 16, k % 8 —
+    the operand of one ``v_mfma_f32_16x16x32_bf16`` is 1 KiB of contiguous memory in lane order.  Returned flat."""
+    m, k = x.shape
+    if m > 32 or k % 64:
+        raise ValueError(f"pack_rows32: shape {x.shape} (at most 32 rows, K % 64 == 0)")
+    full = np.zeros((32, k), x.dtype)
+    full[:m] = x
+    return np.ascontiguousarray(full.reshape(2, 16, k // 64, 2, 4, 8).transpose(2, 0, 3, 4, 1, 5)).reshape(-1)
+
+
+def unpack_rows32(xp: np.ndarray, k: int) -> np.ndarray:
+    """Inverse of :func:`pack_rows32`: flat packed buffer -> ``[32, K]``."""
+    return np.ascontiguousarray(np.asarray(xp).reshape(k // 64, 2, 2, 4, 16, 8).transpose(1, 4, 0, 2, 3, 5)).reshape(32, k)
+
+
 # ----------------------------------------------------------------------------- fp8 (OCP e4m3fn) weight-only quantisation
 # BASELINE.json config 5: decoder Linears in fp8 with one fp32 scale per output channel, activations / lm_head / ViT in
 # bf16.  gfx950 converts OCP e4m3fn (4 exponent bits, bias 7, 3 mantissa bits, max 448, no infinities) in hardware

@@ -374,15 +374,10 @@ def test_cli_main_serves_until_signalled_and_metrics_endpoint():
     port = _free_port()
     ready = threading.Event()
     box = {}
-    orig = cli.parse_args
-    def parse(argv):
-        a = orig(argv)
-        a.on_ready = lambda httpd, srv, stop: (box.update(stop=stop), ready.set())
-        return a
-    cli.parse_args = parse
+    on_ready = lambda httpd, srv, stop: (box.update(stop=stop), ready.set())
     try:
         t = threading.Thread(target=lambda: box.update(rc=cli.main(["serve", "/m", "--port", str(port), "--host", "127.0.0.1",
-                                                                   "--served-model-name", "karantaocr"], make=make)))
+                                                                   "--served-model-name", "karantaocr"], make=make, on_ready=on_ready)))
         t.start()
         assert ready.wait(10)
         body = json.dumps({"model": "karantaocr", "messages": [{"role": "user", "content": "x"}], "max_tokens": 8}).encode()
@@ -394,7 +389,7 @@ def test_cli_main_serves_until_signalled_and_metrics_endpoint():
         t.join(10)
         assert box.get("rc") == 0
     finally:
-        cli.parse_args = orig
+        box.get("stop") and box["stop"].set()
 
 
 class GuidedFakeEngine(FakeEngine):
