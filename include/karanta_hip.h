@@ -546,6 +546,10 @@ int kr_selftest_mfma(kr_stream s);
 /* Diagnostic: microseconds per kernel of a dependent chain of `n` tiny kernels (`blocks` x 256
  * threads; dirty != 0: each block also writes 4 KiB) replayed from a hipGraph on stream `s`. */
 int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, float* us_per_kernel);
+/* Diagnostic: the read-only streaming rate (GB/s, best of `reps` launches timed with HIP events on `s`) of `blocks` x 256
+ * threads reading [ptr, ptr + bytes) once with 16-byte nontemporal loads, 8 in flight per lane — the measured counterpart of
+ * the vendor HBM peak when the range is far larger than the 256 MB Infinity Cache. */
+int kr_probe_stream_read(const void* ptr, size_t bytes, int blocks, int reps, kr_stream s, float* gbytes_per_s);
 /* Launches an empty kernel (1 wave): calibrates the cost of a HIP-event bracket around one launch. */
 int kr_launch_null(kr_stream s);
 

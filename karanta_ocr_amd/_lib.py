@@ -94,6 +94,7 @@ SIGNATURES = {
     "kr_bcast_weights": [c_p, c_p, C.c_size_t, i32, c_p],
     "kr_selftest_mfma": [c_p],
     "kr_probe_launch_floor": [c_p, i32, i32, i32, C.POINTER(f32)],
+    "kr_probe_stream_read": [c_p, C.c_size_t, i32, i32, c_p, C.POINTER(f32)],
     "kr_launch_null": [c_p],
 }
 _RESTYPES = {"kr_last_error": C.c_char_p}

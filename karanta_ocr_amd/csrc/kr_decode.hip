@@ -844,13 +844,17 @@ int launch_wide_m(DecLinArgs& a, int blocks, int waves, kr_stream s) {
 // the weight ring), keeps the first half in registers for staging and re-reads the second half (L2) when its turn comes.
 // Ring depth 7 (28 chunks per half = 4 x 7: slots stay static).  TMAX = tiles a wave may own (lm_head of the 7B model
 // on 256 x 8 waves: 9504 tiles -> 5).
-template <int EPI, bool W8, int U>
+template <int EPI, bool W8, bool KEEP>
 __global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, const kr_bf16* wpk, const kr_bf16* norm_w, int64_t ldx, int M,
                                                           int N, int wide_blocks, int wide_waves, float norm_eps, const DecLinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WC = WChunk<W8>;
-    constexpr int NCH = 56, CH = 28, KHALF = CH * 64, HC = KHALF / 8;   // 224 16-byte pieces per half row; U = ring depth (7 or 14)
-    constexpr int NR = 4, RLH = 4, TMAX = 5, MT = 2;
+    // ring depth 7 (r4: a 14-deep ring — 28 KB per wave in flight across the restaging barrier — measured 74.9 us against 49.8)
+    constexpr int NCH = 56, CH = 28, U = 7, KHALF = CH * 64, HC = KHALF / 8;   // 224 16-byte pieces per half row
+    // KEEP (launches with at most two tiles per wave: the 7B decoder's gate/up, 2368 tiles over 256 x 8 waves): the second half
+    // of the wave's rows is requested again right after the prologue and waits in registers; up to five tiles per wave
+    // (lm_head) the accumulators take those registers and the second half is re-read from L2 when its turn comes
+    constexpr int NR = 4, RLH = 4, TMAX = KEEP ? 2 : 5, MT = 2;
     constexpr int XROW = KHALF * 2 + 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = wide_waves, nblk = wide_blocks;
@@ -859,7 +863,7 @@ __global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, cons
     const bool has_norm = norm_w != nullptr;
     const int t0 = blockIdx.x + nblk * wave;
 
-    // ---- rows wave, wave + W, ...: first half kept, second half only for the statistic
+    // ---- rows wave, wave + W, ...: first half kept, second half only for the statistic (it is requested again later)
     bf16x8 x0[NR][RLH], x1[NR][RLH], nw0[RLH];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -924,8 +928,26 @@ __global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, cons
             }
         }
     };
+    auto load_second_half = [&]() {
+#pragma unroll
+        for (int i = 0; i < RLH; ++i) nw0[i] = ld8((has_norm ? norm_w : x) + (has_norm ? KHALF : 0) + min(lane + i * 64, HC - 1) * 8);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int b = wave + r * W;
+            const kr_bf16* xp = x + (int64_t)(b < M ? b : 0) * ldx + KHALF;
+#pragma unroll
+            for (int i = 0; i < RLH; ++i) x1[r][i] = ld8(xp + min(lane + i * 64, HC - 1) * 8);
+        }
+    };
     stage(x0, nw0);
     __syncthreads();
+    if constexpr (KEEP) {   // the second half again, requested NOW (behind the initial ring, ahead of every refill): in registers long
+        //                     before the restaging barrier, where a re-read queues behind the whole ring in flight (loads return in
+        //                     issue order) — gate/up at the 7B width, 32 rows: 49.9 us with the re-read at the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        load_second_half();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     f32x4 acc[TMAX][MT];
 #pragma unroll
@@ -940,16 +962,8 @@ __global__ void __launch_bounds__(512) dec_wide_kh_kernel(const kr_bf16* x, cons
     for (int kh = 0; kh < 2; ++kh) {
         if (kh == 1) {
             __syncthreads();                 // every wave has read the first half
-            // second half of the rows: re-read (they are in L2), normalise with the statistic of the whole row
-#pragma unroll
-            for (int i = 0; i < RLH; ++i) nw0[i] = ld8((has_norm ? norm_w : x) + (has_norm ? KHALF : 0) + min(lane + i * 64, HC - 1) * 8);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int b = wave + r * W;
-                const kr_bf16* xp = x + (int64_t)(b < M ? b : 0) * ldx + KHALF;
-#pragma unroll
-                for (int i = 0; i < RLH; ++i) x1[r][i] = ld8(xp + min(lane + i * 64, HC - 1) * 8);
-            }
+            // second half of the rows, normalised with the statistic of the whole row: re-read here (L2), or (KEEP) already back
+            if constexpr (!KEEP) load_second_half();
             stage(x1, nw0);
             __syncthreads();
         }
@@ -1045,16 +1059,18 @@ template <int EPI, bool W8>
 int launch_wide_kh(DecLinArgs& a, int blocks, int waves, kr_stream s) {
     if constexpr (EPI == DEPI_SILU8 || EPI == DEPI_ARGMAX) {
         KR_CHECK_ARG(waves == 8, "kr_linear_decode_wide: 17..32 rows at K = 3584 run 8 waves per workgroup (got %d)", waves);
-        KR_CHECK_ARG(((a.N >> 4) + blocks * waves - 1) / (blocks * waves) <= 5,
-                     "kr_linear_decode_wide: %d tiles over %d x %d waves is more than 5 tiles per wave", a.N >> 4, blocks, waves);
+        const int tiles_per_wave = ((a.N >> 4) + blocks * waves - 1) / (blocks * waves);
+        KR_CHECK_ARG(tiles_per_wave <= 5, "kr_linear_decode_wide: %d tiles over %d x %d waves is more than 5 tiles per wave", a.N >> 4,
+                     blocks, waves);
         KR_CHECK_ARG(!a.x_is_f32 && !a.bias && !a.residual, "kr_linear_decode_wide: K-halves take bf16 x, no bias / residual");
         const size_t lds = (size_t)32 * (28 * 64 * 2 + 16);
-        static const int ring = [] { const char* e = getenv("KARANTA_KH_RING"); return e ? atoi(e) : 7; }();
-        auto fn = ring == 14 ? &dec_wide_kh_kernel<EPI, W8, 14> : &dec_wide_kh_kernel<EPI, W8, 7>;
+        auto fn = tiles_per_wave <= 2 ? &dec_wide_kh_kernel<EPI, W8, true> : &dec_wide_kh_kernel<EPI, W8, false>;
         static KrPerDeviceOnce attr;
         if (attr.need()) {
-            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_wide_kh_kernel<EPI, W8, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_wide_kh_kernel<EPI, W8, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_wide_kh_kernel<EPI, W8, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_wide_kh_kernel<EPI, W8, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         fn<<<blocks, 512, lds, kr_hs(s)>>>(a.x, a.wp, a.norm_w, a.ldx, a.M, a.N, a.wide_blocks, a.wide_waves, a.norm_eps, a);
         KR_CHECK_LAUNCH();
@@ -1748,6 +1764,9 @@ int launch_oproj_heads(const float* ws, const void* wp, const float* w_scale, fl
 // =====================================================================================
 // grid = (n_split, kv_heads, batch); WAVES waves; wave `part` = split*WAVES + wave walks 32-key units
 // part, part + WAVES*n_split, ...   Layouts as in kr_attention.hip (K rows, V^T 64-key blocks).
+#ifndef KR_ATTN_DEC_LD        // -DKR_ATTN_DEC_LD=ld8: default-policy K / V^T loads (A/B builds, csrc/tools/build_variant.py)
+#define KR_ATTN_DEC_LD ld8_nt
+#endif
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
                                                                   const kr_bf16* __restrict__ vtcache,
@@ -1795,11 +1814,11 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
         for (int kt = 0; kt < 2; ++kt) {
             const kr_bf16* kp = kc + (int64_t)(key0 + 8 * (fr >> 2) + 4 * kt + (fr & 3)) * HD + fg * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kk[kt][i] = ld8_nt(kp + i * 32);
+            for (int i = 0; i < 4; ++i) kk[kt][i] = KR_ATTN_DEC_LD(kp + i * 32);
         }
         const kr_bf16* vp = vc + (int64_t)(u >> 1) * (HD * 64) + (u & 1) * 32 + fg * 8;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vv[dt] = ld8_nt(vp + (dt * 16 + fr) * 64);
+        for (int dt = 0; dt < DT; ++dt) vv[dt] = KR_ATTN_DEC_LD(vp + (dt * 16 + fr) * 64);
     };
     int u = part;
     if (u < nu) load_unit(u, kf, vf);

@@ -124,6 +124,52 @@ extern "C" int kr_probe_launch_floor(kr_stream s, int n, int blocks, int dirty, 
     return KR_OK;
 }
 
+// Read-only streaming rate of this device ("report achieved-vs-measured-stream too"): every wave keeps
+// 8 independent 16-byte nontemporal loads per lane in flight over a caller-owned range (the weight arena: far larger than the
+// 256 MB Infinity Cache), nothing is written.  bench.py puts the figure next to the 8 TB/s vendor peak on its JSON line.
+namespace {
+__global__ void __launch_bounds__(256) stream_read_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(p + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k];
+    }
+    for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink) sink[0] = 1;  // keeps the loads alive
+}
+}  // namespace
+
+extern "C" int kr_probe_stream_read(const void* ptr_, size_t bytes, int blocks, int reps, kr_stream s, float* gbytes_per_s) {
+    KR_CHECK_ARG(ptr_ && ((uintptr_t)ptr_ & 15) == 0 && bytes >= (1u << 20) && blocks > 0 && reps > 0 && gbytes_per_s,
+                 "kr_probe_stream_read: bad args");
+    hipEvent_t e0, e1;
+    KR_CHECK_HIP(hipEventCreate(&e0));
+    KR_CHECK_HIP(hipEventCreate(&e1));
+    const u32x4* p = reinterpret_cast<const u32x4*>(ptr_);
+    stream_read_kernel<<<blocks, 256, 0, kr_hs(s)>>>(p, bytes / 16, nullptr);   // warm-up (code object, TLB)
+    float best = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        KR_CHECK_HIP(hipEventRecord(e0, kr_hs(s)));
+        stream_read_kernel<<<blocks, 256, 0, kr_hs(s)>>>(p, bytes / 16, nullptr);
+        KR_CHECK_HIP(hipEventRecord(e1, kr_hs(s)));
+        KR_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        KR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        const float rate = (float)((double)(bytes / 16 * 16) / 1e9 / ((double)ms * 1e-3));
+        best = rate > best ? rate : best;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    KR_CHECK_LAUNCH();
+    *gbytes_per_s = best;
+    return KR_OK;
+}
+
 // A kernel that does nothing: bench.py brackets it with the same two HIP events it puts around the
 // roofline kernel, to calibrate the bracket's own cost (event packets + dispatch latency) live.
 namespace { __global__ void null_kernel() {} }

@@ -1432,6 +1432,11 @@ class Engine:
         self._last_batch = self.B
         self._ensure_history(max_new_tokens)
         self._req_max_new = int(max_new_tokens)
+        # a scheduler rebuilt after an exception may have left an overlapped admission in flight: without this the counter stays
+        # above zero and every later decode_steps() replays the graph on the complement CU subset
+        if self._adm_stream is not None:
+            self._adm_stream.synchronize()
+        self._adm_inflight = 0
         with torch.cuda.stream(self.stream):
             self.d_fin.fill_(1)
             self.d_temp.zero_()

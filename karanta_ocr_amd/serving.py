@@ -152,9 +152,29 @@ class ChatFrontend:
             def raise_exception(msg):
                 raise jinja2.exceptions.TemplateError(msg)
 
-            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)   # transformers' settings
+            def tojson(x, ensure_ascii=False, indent=None, separators=None, sort_keys=False):
+                import json as _json
+                return _json.dumps(x, ensure_ascii=ensure_ascii, indent=indent, separators=separators, sort_keys=sort_keys)
+
+            def strftime_now(fmt):
+                import datetime
+                return datetime.datetime.now().strftime(fmt)
+
+            # the environment transformers renders chat templates in (utils/chat_template_utils.py): sandboxed, trim / lstrip blocks,
+            # loop controls ({% break %} / {% continue %}), tojson without HTML escaping, raise_exception, strftime_now
+            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True, extensions=["jinja2.ext.loopcontrols"])
+            env.filters["tojson"] = tojson
             env.globals["raise_exception"] = raise_exception
-            self._template = env.from_string(chat_template)
+            env.globals["strftime_now"] = strftime_now
+            try:
+                self._template = env.from_string(chat_template)
+            except jinja2.exceptions.TemplateSyntaxError as e:
+                # a template this environment cannot compile must not keep the server from starting: say so and serve with
+                # the hand-coded Qwen2-VL turns
+                import sys
+                print(f"[karanta] chat template of the checkpoint does not compile ({e}); falling back to the hand-coded "
+                      f"Qwen2-VL template", file=sys.stderr, flush=True)
+                self._template = None
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
         # True: only decode the image here; the engine resizes / normalises / patchifies it on the GPU
         # (Engine.patches_from_images, bit-identical to the host path) and 3 bytes per pixel cross PCIe
@@ -204,9 +224,12 @@ class ChatFrontend:
                 c = [({"type": "image", "image": ""} if p.get("type") in ("image_url", "image") else p) for p in c]
             msgs.append({**m, "content": c})
         try:
-            text = self._template.render(messages=msgs, add_generation_prompt=True, add_vision_id=False)
+            text = self._template.render(messages=msgs, add_generation_prompt=True, add_vision_id=False, bos_token="",
+                                         eos_token="<|im_end|>", pad_token="<|endoftext|>", unk_token="")
         except jinja2.exceptions.TemplateError as e:
             raise BadRequest(f"chat template: {e}") from e
+        except Exception as e:  # noqa: BLE001  — a template bug on this request's shape is the client's 400, not a 500
+            raise BadRequest(f"chat template: {type(e).__name__}: {e}") from e
         sp = self._special_ids()
         ids: List[int] = []
         k = 0
@@ -235,11 +258,13 @@ class ChatFrontend:
             raise BadRequest("max_tokens must be >= 1")
         ids: List[int] = []
         pvs, grids, images, n_toks = [], [], [], []
-        if req["messages"][0].get("role") != "system":
+        hand = self._template is None        # the hand-coded Qwen2-VL turns; with the checkpoint's own template only the images are
+        #                                      collected here and the template decides roles, order and text (no double tokenisation)
+        if hand and req["messages"][0].get("role") != "system":
             ids += self._turn("system", self.tok.encode(DEFAULT_SYSTEM))
         for msg in req["messages"]:
             role, content = msg.get("role"), msg.get("content")
-            if role not in ("system", "user", "assistant"):
+            if hand and role not in ("system", "user", "assistant"):
                 raise BadRequest(f"unsupported role {role!r}")
             body: List[int] = []
             parts = [{"type": "text", "text": content}] if isinstance(content, str) else content
@@ -248,7 +273,8 @@ class ChatFrontend:
             for part in parts:
                 kind = part.get("type")
                 if kind == "text":
-                    body += self.tok.encode(part.get("text", ""))
+                    if hand:
+                        body += self.tok.encode(part.get("text", ""))
                 elif kind in ("image_url", "image"):
                     url = part["image_url"]["url"] if kind == "image_url" else part["image"]
                     try:
@@ -273,9 +299,11 @@ class ChatFrontend:
                     body += [self.cfg.vision_start_token_id] + [self.cfg.image_token_id] * n_tok + [self.cfg.vision_end_token_id]
                 else:
                     raise BadRequest(f"unsupported content part {kind!r}")
-            ids += self._turn(role, body)
-        ids += [self.tok.im_start] + self.tok.encode("assistant") + [self.tok.newline]
-        if self._template is not None:      # the checkpoint's own template replaces the hand-coded turns
+            if hand:
+                ids += self._turn(role, body)
+        if hand:
+            ids += [self.tok.im_start] + self.tok.encode("assistant") + [self.tok.newline]
+        else:
             ids = self._ids_from_template(req["messages"], n_toks)
         if len(ids) + max_tokens > self.max_model_len:
             raise BadRequest(f"prompt ({len(ids)} tokens) + max_tokens ({max_tokens}) exceeds max_model_len {self.max_model_len}")

@@ -116,3 +116,23 @@ def test_cli_serve_with_the_real_server_factory_answers_the_reference_request(tm
         box["stop"].set()
         th.join(60)
     assert box.get("rc") == 0
+
+
+@pytest.mark.parametrize("name,fp8", [("tiny", False), ("tiny-w512", True)])
+def test_checkpoint_parity_tool_on_a_synthetic_directory(tmp_path, name, fp8):
+    """`python -m oracle.checkpoint_parity <model dir>`: what a maintainer with real weights runs — engine
+    and full-depth oracle on the same checkpoint directory, per-step logit error, argmax equality and the two decoded strings
+    (call sequence of /root/reference/karanta/training/test_trained_model.py:76-99)."""
+    from PIL import Image
+    from oracle import checkpoint_parity as CP
+    d = str(tmp_path / "ckpt")
+    SC.write_checkpoint(d, CONFIGS[name], 3, "v4", fp8, max_pixels=200704)
+    img = str(tmp_path / "scan.png")
+    Image.fromarray(IP.synthetic_page(5, 168, 224)).save(img)
+    rep = CP.run(d, [img], 1, 8, "bf16", 100352, CP.REFERENCE_PROMPT, log=lambda *a: None)
+    assert len(rep["pages"]) == 2 and rep["pass"], rep
+    for p in rep["pages"]:
+        assert p["max_rel_err"] < p["tol_rel"] and p["steps"] == 8 and isinstance(p["engine_text"], str)
+        assert p["prompt_tokens"] > p["image_tokens"] > 0
+    assert CP.main([d, "--page", img, "--steps", "4", "--policy", "fp32", "--max-pixels", "100352", "--json", str(tmp_path / "r.json")]) in (0, 1)
+    assert json.load(open(tmp_path / "r.json"))["pages"][0]["page"] == img

@@ -599,3 +599,24 @@ def test_checkpoint_chat_template_is_applied_when_the_model_dir_ships_one(tmp_pa
     assert S.load_chat_template(d) == QWEN2VL_SHAPED_TEMPLATE
     (tmp_path / "chat_template.jinja").write_text("J")
     assert S.load_chat_template(d) == "J"
+
+
+def test_chat_template_environment_is_the_one_transformers_renders_in():
+    """loop controls, tojson, strftime_now and the special-token variables are available to a checkpoint's template; a
+    template that does not compile falls back to the hand-coded turns instead of keeping the server from starting; a template that
+    fails on one request's shape answers 400; roles the hand-coded turns reject are the template's business."""
+    tpl = ("{% for m in messages %}{% if m['role'] == 'skip' %}{% continue %}{% endif %}<|im_start|>{{ m['role'] }}\n"
+           "{{ m['content'] if m['content'] is string else (m['content'] | tojson) }}{{ eos_token }}\n{% endfor %}"
+           "{{ strftime_now('%Y')[:0] }}{% if add_generation_prompt %}<|im_start|>assistant\n{% endif %}")
+    tok = S.ByteTokenizer(CFG)
+    f = S.ChatFrontend(CFG, tok, chat_template=tpl)
+    got = f.parse({"messages": [{"role": "skip", "content": "dropped"}, {"role": "tool", "content": "né"}], "max_tokens": 4})
+    want = [tok.im_start] + tok.encode("tool") + [tok.newline] + tok.encode("né") + [tok.im_end, tok.newline, tok.im_start]
+    want += tok.encode("assistant") + [tok.newline]
+    assert got.input_ids.tolist() == want
+    broken = S.ChatFrontend(CFG, tok, chat_template="{% for m in messages %}{{ m.content }")     # does not compile
+    assert broken._template is None
+    assert broken.parse({"messages": [{"role": "user", "content": "x"}], "max_tokens": 2}).input_ids.size > 0
+    bad = S.ChatFrontend(CFG, tok, chat_template="{{ messages[5]['content'] }}{{ 1 // 0 }}")
+    with pytest.raises(S.BadRequest):
+        bad.parse({"messages": [{"role": "user", "content": "x"}], "max_tokens": 2})
