@@ -429,7 +429,7 @@ def run_secondary(kind: str, args, log, timeout_s: float = 1500.0) -> dict:
 def kernel_source_sha16() -> str:
     import hashlib
     h = hashlib.sha256()
-    for name in ("kr_decode.hip", "kr_common.h"):
+    for name in ("kr_decode.hip", "kr_decode32.hip", "kr_common.h"):
         with open(os.path.join(ROOT, "karanta_ocr_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -437,10 +437,10 @@ def kernel_source_sha16() -> str:
 
 def pmc_traffic():
     """(HBM bytes per launch of the roofline kernel, where it comes from) from the newest committed PMC pass — quoted only
-    while the pass was taken on THIS kernel source (the file carries the hash of kr_decode.hip + kr_common.h; a figure
+    while the pass was taken on THIS kernel source (the file carries the hash of kr_decode.hip + kr_decode32.hip + kr_common.h, taken by the profiling run itself; a figure
     measured on other kernel code is dropped, not silently kept: VERDICT r2 weak #9).  (None, reason) otherwise."""
     why = "no committed PMC pass"
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 doc = json.load(f)
@@ -802,7 +802,7 @@ def main():
                 "launches_timed": chain["launches"],
                 "avg_us_definition": "HIP events on the launch stream around a chain of back-to-back launches of this kernel, one per "
                                      "decoder layer's weights (no cache reuse), total / launches; compare the rocprofv3 kernel-trace "
-                                     "average of the same kernel in profiles/r03_kernel_trace_summary.txt",
+                                     "average of the same kernel in profiles/r04_kernel_trace_summary.txt",
                 # the same launch bracketed by events inside the timed decode steps (eager steps every --profile-every):
                 "in_step": {"event_bracket_us": round(prof["bracket_us"], 3), "empty_bracket_us": round(prof["null_bracket_us"], 3),
                             "dispatch_gap_us": round(floor_us, 3), "launches_timed": prof["launches"]},
@@ -816,7 +816,11 @@ def main():
             out["weights"] = "generated on every rank from the same seed (the RCCL broadcast failed: rccl_error)"
         if bcast_s is not None:
             out["rccl_weight_bcast_s"] = round(bcast_s, 4)
-            out["rccl_weight_bcast_path"] = "kr_bcast_weights (ncclBroadcast)"
+            out["rccl_weight_bcast_path"] = ("kr_bcast_weights: ncclBroadcast of the packed arena in <= 1 GiB pieces on the engine's stream "
+                                             "(RCCL picks ring / tree; SURVEY section 5's scatter + all-gather form is not built)")
+            ver = C.c_int()
+            lib().kr_rccl_version(C.byref(ver))
+            out["rccl_version"] = int(ver.value)
             out["rccl_weight_bcast_GBps"] = round(eng.w.nbytes / 1e9 / max(bcast_s, 1e-9), 1)
             out["rccl_ranks"] = rccl_ranks
             out["per_rank_pages_per_s"] = [round(float(x), 3) for x in per_rank_pps]

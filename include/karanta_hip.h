@@ -538,6 +538,8 @@ int kr_comm_init(void** comm, int n_ranks, int rank, const uint8_t* id128);
  * ranks?" is answered by the library, not by the launcher's environment. */
 int kr_comm_count(void* comm, int* n_ranks);
 int kr_comm_destroy(void* comm);
+/* ncclGetVersion of the RCCL this library is bound to (major * 10000 + minor * 100 + patch): reported beside the broadcast rate. */
+int kr_rccl_version(int* version);
 int kr_bcast_weights(void* comm, void* buf, size_t bytes, int root, kr_stream s);
 
 /* ------------------------------------------------------------------ device self-tests (used by tests/ -m gpu) */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "kr_comm_init": [C.POINTER(c_p), i32, i32, c_p],
     "kr_comm_count": [c_p, C.POINTER(i32)],
     "kr_comm_destroy": [c_p],
+    "kr_rccl_version": [C.POINTER(i32)],
     "kr_bcast_weights": [c_p, c_p, C.c_size_t, i32, c_p],
     "kr_selftest_mfma": [c_p],
     "kr_probe_launch_floor": [c_p, i32, i32, i32, C.POINTER(f32)],

@@ -42,6 +42,15 @@ int kr_comm_count(void* comm, int* n_ranks) {
     return KR_OK;
 }
 
+// The RCCL build this library is bound to (ncclGetVersion: major * 10000 + minor * 100 + patch).  bench.py prints it next to the
+// broadcast's GB/s: which algorithm RCCL picks for the ncclBroadcast (ring / tree, which xGMI links) is its decision, and a rate far
+// below one link's 153 GB/s on the first multi-GPU run is to be read against the version and NCCL_DEBUG=INFO output of that run.
+int kr_rccl_version(int* version) {
+    KR_CHECK_ARG(version, "kr_rccl_version: null");
+    KR_CHECK_RCCL(ncclGetVersion(version));
+    return KR_OK;
+}
+
 int kr_comm_destroy(void* comm) {
     if (comm) KR_CHECK_RCCL(ncclCommDestroy((ncclComm_t)comm));
     return KR_OK;

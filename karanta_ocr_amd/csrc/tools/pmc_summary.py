@@ -11,15 +11,24 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+HASHED = ("kr_decode.hip", "kr_decode32.hip", "kr_common.h")
+
+
 def kernel_source_sha16() -> str:
-    """Hash of the decode kernels' source (kr_decode.hip + kr_common.h): bench.py quotes a committed traffic figure only
-    while this still matches the tree it runs from (VERDICT r2 weak #9: the figure must not go stale silently)."""
+    """Hash of the decode kernels' source: bench.py quotes a committed traffic figure only while this still matches the tree it
+    runs from (the figure must not go stale silently).  `python pmc_summary.py --hash` prints it: the
+    PROFILING RUN writes that next to the counter CSV (source_sha16.txt) and the summary takes the hash from there — the hash of
+    the tree the counters were captured on, not of the tree the summary happens to run on."""
     h = hashlib.sha256()
-    for name in ("kr_decode.hip", "kr_common.h"):
+    for name in HASHED:
         with open(os.path.join(HERE, "..", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
+
+if len(sys.argv) > 1 and sys.argv[1] == "--hash":
+    print(kernel_source_sha16())
+    sys.exit(0)
 
 f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/pmc*/*/*_counter_collection.csv"))[-1]
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
@@ -28,7 +37,8 @@ for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != "FETCH_SIZE":
         continue
     name = r["Kernel_Name"]
-    m = re.search(r"(dec_linear_kernel<[^>]*>|dec_wide_kernel<[^>]*>|dec_narrow_kernel<[^>]*>|attn_decode2_kernel<[^>]*>)", name)
+    m = re.search(r"(dec_linear_kernel<[^>]*>|dec_wide_kernel<[^>]*>|dec_wide_kh_kernel<[^>]*>|dec_narrow_kernel<[^>]*>|dec32_kernel<[^>]*>|"
+                  r"attn_decode2_kernel<[^>]*>|dec_resnorm_kernel<[^>]*>|attn_merge_kernel<[^>]*>)", name)
     if m:
         short = m.group(1)
         g[(short, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
@@ -40,6 +50,9 @@ raw = None
 if out.startswith("profiles/") or os.sep + "profiles" + os.sep in out:   # keep the raw counter CSV beside the summary (weak #8)
     raw = os.path.splitext(out)[0] + "_counter_collection.csv"
     shutil.copyfile(f, raw)
-json.dump({"source": f, "raw_csv": raw, "kernel_source_sha16": kernel_source_sha16(), "correction": "bytes = 2 * 1024 * FETCH_SIZE (gfx950: FETCH_SIZE counts half of wide coalesced reads)",
+captured = os.path.join(os.path.dirname(os.path.dirname(f)), "source_sha16.txt")      # written by the profiling run itself
+sha = open(captured).read().strip() if os.path.exists(captured) else kernel_source_sha16()
+json.dump({"source": f, "raw_csv": raw, "kernel_source_sha16": sha,
+           "sha_from": "the profiling run (source_sha16.txt beside the CSV)" if os.path.exists(captured) else "the summarising tree", "correction": "bytes = 2 * 1024 * FETCH_SIZE (gfx950: FETCH_SIZE counts half of wide coalesced reads)",
            "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

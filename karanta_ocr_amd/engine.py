@@ -1526,8 +1526,10 @@ class Engine:
         stream the captured graph replays on the complementary compute units (same kernels, same grids: the same tokens), ordered
         against the engine's stream by events on both sides."""
         graph = self._graphs.get(self._graph_key(self.B))
+        self.last_decode_disjoint = False      # (observable for tests: which of the two paths the call took)
         if (graph is not None and self._adm_inflight > 0 and self.admission_cus > 0 and self.disjoint_decode
                 and self.admission_cus < self.n_cus):
+            self.last_decode_disjoint = True
             if self._dec_stream is None:
                 h = C.c_void_p()
                 self.L.kr_stream_create_cu_range(C.byref(h), int(self.admission_cus), int(self.n_cus - self.admission_cus))

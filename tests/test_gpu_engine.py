@@ -569,3 +569,43 @@ def test_server_guided_json_and_logprobs(engines, tiny_models):
     c2 = out["static"][2][1]["choices"][0]
     assert len(c2["logprobs"]["content"]) == 4 and all(i["top_logprobs"] == [] for i in c2["logprobs"]["content"])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_disjoint_decode_stream_follows_the_admission_in_flight(tiny_models):
+    """while an overlapped admission is in flight on its CU-masked stream the decode graph replays on the complementary
+    compute units; after admit_end — or after begin_slots() of a scheduler rebuilt with an admission still in flight — it is back
+    on the engine's stream (the counter used to stay above zero for ever: ~47 % decode speed with nothing reporting it)."""
+    cfg, w, _ = tiny_models["tiny"]
+    eng = Engine(cfg, max_batch=3, s_max=512, max_patches=2048, max_prompt_tokens=2048, decode_splits=2, admission_cus=128)
+    eng.load_weights(w)
+    def page(i, h, wd):
+        pv, grid = IP.image_to_patches(IP.synthetic_page(60 + i, h, wd))
+        T = grid[1] * grid[2] // 4
+        ids = np.concatenate([[3 + i, cfg.vision_start_token_id], [cfg.image_token_id] * T, [cfg.vision_end_token_id, 9]]).astype(np.int64)
+        return PageRequest(ids, pv, [grid])
+    solo = eng.generate([page(0, 56, 84)], 8).tokens[0]      # EOS-aware, as a slot decodes
+    k = min(len(solo), 6)
+    eng.begin_slots(16)
+    eng.admit([page(0, 56, 84)], [0])
+    eng.decode_steps(2)                         # first step eager, then the captured graph
+    assert eng.last_decode_disjoint is False
+    h = eng.admit_begin([page(1, 84, 56)], [1])
+    assert eng._adm_inflight == 1
+    eng.decode_steps(2)
+    assert eng.last_decode_disjoint is True and eng._dec_stream is not None
+    eng.admit_end(h)
+    eng.decode_steps(2)
+    assert eng.last_decode_disjoint is False and eng._adm_inflight == 0
+    eng.stream.synchronize()
+    np.testing.assert_array_equal(eng.slot_tokens(0, k), solo[:k])      # slot 0 decoded through both paths: the same tokens
+    h2 = eng.admit_begin([page(2, 56, 56)], [2])                        # ... and a scheduler rebuilt with this one still in flight
+    assert eng._adm_inflight == 1
+    eng.begin_slots(16)
+    assert eng._adm_inflight == 0
+    eng.admit([page(0, 56, 84)], [0])
+    eng.decode_steps(3)
+    assert eng.last_decode_disjoint is False
+    eng.stream.synchronize()
+    np.testing.assert_array_equal(eng.slot_tokens(0, min(k, 4)), solo[:min(k, 4)])
+    eng.close()
