@@ -176,7 +176,9 @@ int kr_gemv_bf16(const kr_bf16* x, int64_t ldx, const kr_bf16* W, const kr_bf16*
  * multiple of 64 inside that segment:
  *   q_out  [q_heads][token row][hd]                    (head stride q_head_stride elements)
  *   k_out  [kv_heads][rows][hd]: token j -> row blk_k_row0[i] + j   (head stride k_head_stride)
- *   vt_out [kv_heads][blocks][hd][64]: V transposed, block blk_vt_blk[i], zero padded
+ *   vt_out [kv_heads][blocks][2][hd][32]: V transposed in 64-token blocks, each block as two contiguous 32-token halves
+ *          (element (channel d, token j of the block) at ((j / 32) * hd + d) * 32 + j % 32; round 4: a decode-attention wave reads
+ *          a 32-key unit as whole cache lines — rounds 1-3 stored [hd][64]), block blk_vt_blk[i], zero padded
  * For the decoder, k_out / vt_out are the KV cache of one layer. hd in {80, 128}. */
 int kr_qkv_prep(const kr_bf16* qkv, int64_t ld_qkv, int q_off, int k_off, int v_off,
                 const float* cos, const float* sin,
@@ -193,7 +195,7 @@ int kr_rope2d_vision(kr_bf16* x, const float* cos, const float* sin, int64_t n, 
 
 /* Flash-style attention over variable-length segments, fp32 online softmax, bf16 P (as
  * eager_attention_forward TF:317-339 computes it: softmax in fp32, cast, P*V).
- *   q : [q_heads, nq_total, hd]   k : [kv_heads, *, hd] rows   vt : [kv_heads, *, hd, 64] blocks
+ *   q : [q_heads, nq_total, hd]   k : [kv_heads, *, hd] rows   vt : [kv_heads, *, 2, hd, 32] blocks (kr_qkv_prep's layout)
  *   out : [nq_total, q_heads*hd]
  * Work list: qblk[4*i+0..3] = {q_row0 (global row of first query), n_q_rows (<=128),
  *   k_row0 (global k row of the segment's key 0), vt_block0}; qblk_len[2*i+0..1] =
@@ -224,7 +226,8 @@ int kr_embed_scatter(const int32_t* src, const kr_bf16* table, const kr_bf16* im
 
 /* KV cache of one model:
  *   kcache  : [layers, batch, kv_heads, s_max, hd]
- *   vtcache : [layers, batch, kv_heads, s_max/64, hd, 64]   (V transposed in 64-token blocks)
+ *   vtcache : [layers, batch, kv_heads, s_max/64, 2, hd, 32]   (V transposed in 64-token blocks of two contiguous 32-token
+ *             halves: kr_qkv_prep's layout; every writer and reader of the cache in this library uses it)
  * zero-initialised by the caller (masked keys are multiplied by P = 0, so they must be finite). */
 
 /* SURVEY §8 b2 names kept as thin standalone operators (tests call them directly). */

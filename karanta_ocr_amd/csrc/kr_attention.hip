@@ -4,7 +4,8 @@
 // Data layout in HBM (chosen for the matrix cores, not inherited from any framework):
 //   Q   : [heads, n, hd]                     rotated, bf16
 //   K   : [kv_heads, rows, hd]               rotated, bf16 (decoder: the KV cache itself)
-//   V^T : [kv_heads, blocks, hd, 64]         V transposed inside 64-token blocks, so that the
+//   V^T : [kv_heads, blocks, 2, hd, 32]      V transposed inside 64-token blocks, each block as two contiguous 32-key halves
+//                                            (kr_common.h, kr_vt_off; rounds 1-3: [hd, 64]), so that the
 //                                            P*V MFMA operand (8 consecutive keys for one d)
 //                                            is one contiguous 16-byte read per lane.
 #include "kr_common.h"
@@ -128,10 +129,11 @@ __global__ void __launch_bounds__(256) qkv_prep_kernel(const kr_bf16* __restrict
         }
         __syncthreads();
         kr_bf16* vt = vt_out + (int64_t)head * vt_head_stride + blk_vt_blk[i] * (int64_t)(HD * 64);
-        for (int e = threadIdx.x; e < HD * 8; e += 256) {
-            const int d = e >> 3, c = e & 7;
+        for (int e = threadIdx.x; e < HD * 8; e += 256) {   // e = the 16-byte piece in MEMORY order: consecutive threads, whole lines
+            const int half = e >= HD * 4 ? 1 : 0, rem = e - half * (HD * 4);
+            const int d = rem >> 2, c = half * 4 + (rem & 3);
             const unsigned* r = vt_s + d * VT_RS + c * 4;
-            *reinterpret_cast<u32x4*>(vt + d * 64 + c * 8) = (u32x4){r[0], r[1], r[2], r[3]};
+            *reinterpret_cast<u32x4*>(vt + e * 8) = (u32x4){r[0], r[1], r[2], r[3]};      // = vt + kr_vt_off(d, c * 8, HD)
         }
         __syncthreads();
     }
@@ -181,6 +183,15 @@ struct AttnCfg {
     static constexpr int KROW = (HD == 128) ? 256 : (KCH + 1) * 16;  // LDS K row bytes (hd=80: 176, conflict-free)
     static constexpr int VROW = 136;                 // LDS V^T row bytes (64 keys + 8 B pad: conflict-free b64 reads)
 };
+
+// Chunk `vi` of a V^T block in MEMORY order — the block is [2 halves][HD][32 keys] (kr_common.h, kr_vt_off), a chunk is 8 keys of
+// one channel — goes to row d = channel, 16-byte piece 4 * half + (vi & 3) of the [HD][64 keys] LDS image.  The staging loads
+// stay linear over the block (whole lines), only the LDS destination knows about the halves.
+template <int HD>
+__device__ __forceinline__ int vt_lds_piece(int vi, int vrow) {
+    const int half = vi >= HD * 4 ? 1 : 0, rem = vi - half * (HD * 4);
+    return (rem >> 2) * vrow + (half * 4 + (rem & 3)) * 16;
+}
 
 template <int HD>
 __device__ __forceinline__ int k_lds_off(int key, int c) {
@@ -297,7 +308,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
             int kg = t * 64 + key;
             kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
             const kr_bf16* kp = kbase + (int64_t)kg * HD + c * 8;
-            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;
+            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;   // the block in MEMORY order (see vt_lds_piece)
             treg[p] = ld8(idx < K_CH ? kp : vp);
         }
     };
@@ -307,8 +318,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
             int idx = p * NTHR + tid;
             idx = idx < T_CH ? idx : T_CH - 1;
             const int key = idx / C::KCH, c = idx - key * C::KCH;
-            const int j = idx - K_CH;
-            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + (j >> 3) * C::VROW + (j & 7) * 16;
+            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + vt_lds_piece<HD>(idx - K_CH, C::VROW);
             const u32x4 w = __builtin_bit_cast(u32x4, treg[p]);
             u32x2* dstp = reinterpret_cast<u32x2*>(img + off);
             dstp[0] = (u32x2){w[0], w[1]};
@@ -681,7 +691,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
             int kg = t * 64 + key;
             kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
             const kr_bf16* kp = kbase + (int64_t)kg * HD + c * 8;
-            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;
+            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;   // the block in MEMORY order (see vt_lds_piece)
             treg[p] = ld8(idx < K_CH ? kp : vp);
         }
     };
@@ -691,8 +701,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
             int idx = p * NTHR + tid;
             idx = idx < T_CH ? idx : T_CH - 1;
             const int key = idx / C::KCH, c = idx - key * C::KCH;
-            const int j = idx - K_CH;
-            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + (j >> 3) * C::VROW + (j & 7) * 16;
+            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + vt_lds_piece<HD>(idx - K_CH, C::VROW);
             const u32x4 w = __builtin_bit_cast(u32x4, treg[p]);
             u32x2* dstp = reinterpret_cast<u32x2*>(img + off);
             dstp[0] = (u32x2){w[0], w[1]};
@@ -981,7 +990,7 @@ __global__ void __launch_bounds__(256) decode_qkv_prep_kernel(const kr_bf16* __r
     const kr_bf16* vrow = row + (heads + kv_heads) * hd;
     for (int e = threadIdx.x; e < kv_heads * hd; e += blockDim.x) {
         const int h = e / hd, d = e - h * hd;
-        vtcache[(((kv_base + h) * (s_max >> 6) + (pos >> 6)) * hd + d) * 64 + (pos & 63)] = vrow[e];
+        vtcache[((kv_base + h) * (s_max >> 6) + (pos >> 6)) * (hd * 64) + kr_vt_off(d, pos & 63, hd)] = vrow[e];
     }
 }
 
@@ -1040,9 +1049,9 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const kr_bf16* __restr
             }
             // V^T fragments: row d = dt*16 + fr, keys key0 + 8fg .. +7
             bf16x8 vf[DT];
-            const kr_bf16* vp = vc + (int64_t)blk * (HD * 64) + hf * 32 + fg * 8;
+            const kr_bf16* vp = vc + (int64_t)blk * (HD * 64) + hf * (HD * 32) + fg * 8;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vf[dt] = ld8_nt(vp + (dt * 16 + fr) * 64);
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = ld8_nt(vp + (dt * 16 + fr) * 32);
 
             f32x4 s[2];
 #pragma unroll
@@ -1129,7 +1138,7 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const kr_bf16* __restric
         const int sq = tok_seq[tok], pos = tok_pos[tok];
         const int64_t base = ((int64_t)layer * batch + sq) * kv_heads + h;
         kcache[(base * s_max + pos) * hd + d] = k[tok * row_stride + h * hd + d];
-        vtcache[((base * (s_max >> 6) + (pos >> 6)) * hd + d) * 64 + (pos & 63)] = v[tok * row_stride + h * hd + d];
+        vtcache[(base * (s_max >> 6) + (pos >> 6)) * (hd * 64) + kr_vt_off(d, pos & 63, hd)] = v[tok * row_stride + h * hd + d];
     }
 }
 

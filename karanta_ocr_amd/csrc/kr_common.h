@@ -87,6 +87,13 @@ __host__ __device__ __forceinline__ int64_t kr_xp_byte_offset(int b, int k) {
     return (int64_t)(k >> 6) * 4096 + (b >> 4) * 2048 + ((k >> 5) & 1) * 1024 + ((((k >> 3) & 3) * 16 + (b & 15)) * 16) + (k & 7) * 2;
 }
 
+// ---------------------------------------------------------------- V^T blocks of the KV cache / the ViT's V^T buffer
+// A block holds 64 keys of one head, transposed, as TWO CONTIGUOUS 32-KEY HALVES: [2][HD channels][32 keys] (rounds 1-3:
+// [HD][64]).  The decode attention reads a 32-key unit per wave: with [HD][64] that was one half of every 128-byte line of the
+// block (16 rows x 64 B per wave-instruction), which streams at 4.0 TB/s where whole lines reach 6.5 (profiles/r04_halfline_read.txt);
+// with the halves contiguous a unit is 8 KiB (hd 128) of whole lines.  Element offset of (channel d, key 0..63) inside a block:
+__host__ __device__ __forceinline__ int kr_vt_off(int d, int key, int hd) { return ((key >> 5) * hd + d) * 32 + (key & 31); }
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

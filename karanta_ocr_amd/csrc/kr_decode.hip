@@ -400,11 +400,11 @@ __global__ void __launch_bounds__(WAVES * 64) dec_linear_kernel(const DecLinArgs
             *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
         } else {
             const int kvh = hh - a.heads - a.kv_heads;
-            kr_bf16* vt = a.vtcache + ((((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * 128) * 64 + (pos & 63);
+            kr_bf16* vt = a.vtcache + (((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * (128 * 64) + kr_vt_off(0, pos & 63, 128);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
-                vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+                vt[(i0 + j) * 32] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
+                vt[(64 + i0 + j) * 32] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
             }
         }
         return;
@@ -1449,11 +1449,11 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
                 *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
             } else {
                 const int kvh = hh - a.heads - a.kv_heads;
-                kr_bf16* vt = a.vtcache + ((((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos[mt] >> 6)) * 128) * 64 + (pos[mt] & 63);
+                kr_bf16* vt = a.vtcache + (((int64_t)b * a.kv_heads + kvh) * (a.s_max >> 6) + (pos[mt] >> 6)) * (128 * 64) + kr_vt_off(0, pos[mt] & 63, 128);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
-                    vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+                    vt[(i0 + j) * 32] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
+                    vt[(64 + i0 + j) * 32] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
                 }
             }
             return;
@@ -1816,9 +1816,11 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
 #pragma unroll
             for (int i = 0; i < 4; ++i) kk[kt][i] = KR_ATTN_DEC_LD(kp + i * 32);
         }
-        const kr_bf16* vp = vc + (int64_t)(u >> 1) * (HD * 64) + (u & 1) * 32 + fg * 8;
+        // the unit's half of its V^T block is contiguous ([2][HD][32]: kr_common.h): 16 channel rows x 64 B per instruction = 1 KiB of
+        // whole lines (rounds 1-3: [HD][64], half of every line — 4.0 against 6.5 TB/s for this shape, profiles/r04_halfline_read.txt)
+        const kr_bf16* vp = vc + (int64_t)(u >> 1) * (HD * 64) + (u & 1) * (HD * 32) + fg * 8;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vv[dt] = KR_ATTN_DEC_LD(vp + (dt * 16 + fr) * 64);
+        for (int dt = 0; dt < DT; ++dt) vv[dt] = KR_ATTN_DEC_LD(vp + (dt * 16 + fr) * 32);
     };
     int u = part;
     if (u < nu) load_unit(u, kf, vf);

@@ -258,11 +258,11 @@ __global__ void __launch_bounds__(WAVES * 64) dec32_kernel(const char* hxp, cons
             *reinterpret_cast<bf16x4*>(dst + 64 + i0) = o1;
         } else {
             const int kvh = hh - a.heads - a.kv_heads;
-            kr_bf16* vt = a.vtcache + ((((int64_t)eb * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * 128) * 64 + (pos & 63);
+            kr_bf16* vt = a.vtcache + (((int64_t)eb * a.kv_heads + kvh) * (a.s_max >> 6) + (pos >> 6)) * (128 * 64) + kr_vt_off(0, pos & 63, 128);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                vt[(i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
-                vt[(64 + i0 + j) * 64] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
+                vt[(i0 + j) * 32] = __builtin_bit_cast(kr_bf16, f2bf(lo[j]));
+                vt[(64 + i0 + j) * 32] = __builtin_bit_cast(kr_bf16, f2bf(hi[j]));
             }
         }
     } else {

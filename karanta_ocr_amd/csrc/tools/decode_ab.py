@@ -235,8 +235,9 @@ def chains(a, engines, reset):
                 eng._dec32(DEC_ROPE_KV, eng.d_h, w.view(p + "qkv.w"), B, 8, bias=w.view(p + "qkv.b"), kc=kc, vc=vc, **eng._w8kw(p + "qkv.w"))
             elif kind == "merge32":
                 L.kr_attn_decode_merge32(ptr(eng.d_ws), ptr(eng.d_o), B, H, hd, eng.n_split, eng.s)
-            elif kind == "o32":
-                eng._dec32(DEC_PLAIN, eng.d_o, w.view(p + "o.w"), B, eng.o_waves, out=eng.d_x, res=eng.d_x, **eng._w8kw(p + "o.w"))
+            elif kind in ("o32", "o32t1", "o32t2"):
+                eng._dec32(DEC_PLAIN, eng.d_o, w.view(p + "o.w"), B, eng.o_waves, out=eng.d_x, res=eng.d_x,
+                           tiles_per_wg={"o32": 0, "o32t1": 1, "o32t2": 2}[kind], **eng._w8kw(p + "o.w"))
             elif kind == "gateupxp":
                 eng._dec_wide(DEC_SILU8 | DEC_OUT_XP, eng.d_x, w.view(p + "gate_up.w"), B, out=eng.d_act, norm_w=w.view(p + "ln2.w"),
                               **eng._w8kw(p + "gate_up.w"))

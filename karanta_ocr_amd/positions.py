@@ -218,3 +218,22 @@ def prefill_attn_plan(prompt_lens: Sequence[int], slots: Sequence[int], kv_heads
     k_row0 = [int(sl) * kv_heads * s_max for sl in slots]
     vt0 = [int(sl) * kv_heads * (s_max // 64) for sl in slots]
     return make_attn_plan(prompt_lens, k_row0, vt0, causal=True)
+
+
+# ----------------------------------------------------------------------------- V^T block layout (host view, tests and tools)
+def vt_blocks(v_rows: np.ndarray) -> np.ndarray:
+    """V rows ``[..., S, hd]`` (S a multiple of 64) -> the V^T block layout of the KV cache / the ViT's V^T buffer, shaped
+    ``[..., S/64, hd, 64]`` as the engine's tensors are: a block holds 64 keys of one head, transposed, as TWO CONTIGUOUS
+    32-KEY HALVES ``[2][hd][32]`` (csrc/kr_common.h, kr_vt_off) — a decode-attention wave reads one half as whole cache lines."""
+    v_rows = np.asarray(v_rows)
+    *lead, S, hd = v_rows.shape
+    a = np.swapaxes(v_rows.reshape(*lead, S // 64, 2, 32, hd), -1, -2)
+    return np.ascontiguousarray(a).reshape(*lead, S // 64, hd, 64)
+
+
+def vt_rows(vt: np.ndarray) -> np.ndarray:
+    """Inverse of :func:`vt_blocks`: ``[..., nb, hd, 64]``-shaped block storage -> V rows ``[..., nb * 64, hd]``."""
+    vt = np.asarray(vt)
+    *lead, nb, hd, _ = vt.shape
+    a = np.swapaxes(vt.reshape(*lead, nb, 2, hd, 32), -1, -2)
+    return np.ascontiguousarray(a).reshape(*lead, nb * 64, hd)

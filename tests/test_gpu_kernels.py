@@ -617,13 +617,13 @@ def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256, 
         if as_cache:
             gk = host(k_out)[s_i, :, :ln]
             gvt = host(vt_out)[s_i]  # [KVH, blocks, hd, 64]
-            gv = gvt.transpose(0, 1, 3, 2).reshape(KVH, -1, hd)[:, :ln]
-            assert not host(vt_out)[s_i].transpose(0, 1, 3, 2).reshape(KVH, -1, hd)[:, ln:((ln + 63) // 64) * 64].any()
+            gv = POS.vt_rows(gvt)[:, :ln]
+            assert not POS.vt_rows(host(vt_out)[s_i])[:, ln:((ln + 63) // 64) * 64].any()
         else:
             gk = host(k_out)[:, sl]
             b0 = int(plan.qblk[[i for i in range(len(plan.qblk)) if plan.qblk[i, 0] == off][0], 3])
             nb = (ln + 63) // 64
-            gv = host(vt_out)[:, b0:b0 + nb].transpose(0, 1, 3, 2).reshape(KVH, -1, hd)
+            gv = POS.vt_rows(host(vt_out)[:, b0:b0 + nb])
             assert not gv[:, ln:].any(), "V^T padding must be zero"
             gv = gv[:, :ln]
         assert_close_bf16(gk, kr[sl].transpose(1, 0, 2), abs_=1e-3, what="prep k")
@@ -678,10 +678,8 @@ def test_attention_online_softmax_rescale_branch(L):
     k[0, 250] = bf16_round(q[0, 17] * 12)  # spike in tile 3 for query 17
     k[0, 3] = bf16_round(q[0, 200] * 12)   # and an early spike for a query of the second q-block
     qd, kd = dev_bf16(q), dev_bf16(k)
-    vt = np.zeros((H, 5, hd, 64), np.float32)
-    vt.reshape(H, 5, hd, 64)
     vpad = np.concatenate([v, np.zeros((H, 320 - n, hd), np.float32)], 1)
-    vt = vpad.reshape(H, 5, 64, hd).transpose(0, 1, 3, 2)
+    vt = POS.vt_blocks(vpad)                      # [H, 5 blocks, hd, 64]-shaped storage of [2][hd][32] halves
     plan = POS.make_attn_plan([n], [0], [0], False)
     o = torch.zeros(n, hd, dtype=torch.bfloat16, device=DEV)
     t_ = lambda a: torch.from_numpy(a).to(DEV)
@@ -709,7 +707,7 @@ def test_decode_prep_and_attention(L, H, KVH, ctxs):
     for b, c in enumerate(ctxs):
         kc[b, :, :c] = rnd(rng, KVH, c, hd)
         vc[b, :, :c] = rnd(rng, KVH, c, hd)
-    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    vt = POS.vt_blocks(vc)
     kc_d, vt_d = dev_bf16(kc), dev_bf16(vt)
     qkv = rnd(rng, B, (H + 2 * KVH) * hd)
     delta = np.asarray([-3, 0, -1190][:B], np.int32)
@@ -737,7 +735,7 @@ def test_decode_prep_and_attention(L, H, KVH, ctxs):
         kr = bf16_round(k[b] * cos + O.rotate_half(k[b]) * sin)
         assert_close_bf16(got_q[b], qr, abs_=2e-2, what="decode q rope")   # cos/sin may round differently by 1 bf16 ulp
         assert_close_bf16(got_k[b, :, c], kr, abs_=2e-2, what="decode k append")
-        gv = got_vt[b].transpose(0, 1, 3, 2).reshape(KVH, s_max, hd)
+        gv = POS.vt_rows(got_vt[b])
         np.testing.assert_array_equal(gv[:, c], v[b])
         np.testing.assert_array_equal(gv[:, :c], vc[b, :, :c])           # earlier columns untouched
         kk = np.concatenate([kc[b, :, :c], got_k[b, :, c:c + 1]], 1)
@@ -909,8 +907,8 @@ def test_linear_decode_rope_kv(L, H, KVH, ksplit, waves):
     kr = k * cos[:, None] + O.rotate_half(k) * sin[:, None]
     assert_close_bf16(host(q_d), qr, abs_=3e-2, what="fused q")
     got_k, got_vt = host(kc_d), host(vt_d)
-    gv = got_vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd)
-    ref_v_all = vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd).copy()
+    gv = POS.vt_rows(got_vt)
+    ref_v_all = POS.vt_rows(vt).copy()
     ref_k_all = kc.copy()
     for b, c in enumerate(ctxs):
         assert_close_bf16(got_k[b, :, c], kr[b], abs_=3e-2, what="fused k append")
@@ -1345,8 +1343,8 @@ def test_linear_narrow_rope_kv(L, H, KVH, K, parts, B):
     kr = k * cos[:, None] + O.rotate_half(k) * sin[:, None]
     assert_close_bf16(host(q_d), qr, abs_=3e-2, what="narrow fused q")
     got_k, got_vt = host(kc_d), host(vt_d)
-    gv = got_vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd)
-    ref_v_all = vt.transpose(0, 1, 2, 4, 3).reshape(B, KVH, s_max, hd).copy()
+    gv = POS.vt_rows(got_vt)
+    ref_v_all = POS.vt_rows(vt).copy()
     ref_k_all = kc.copy()
     for b, c in enumerate(ctxs):
         assert_close_bf16(got_k[b, :, c], kr[b], abs_=3e-2, what="narrow fused k append")
@@ -1831,7 +1829,7 @@ def test_attn_partials_merged_by_o_proj_prologue(L, H, KVH, n_split):
     for b, c in enumerate(ctxs):
         kc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
         vc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
-    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    vt = POS.vt_blocks(vc)
     q = rnd(rng, B, H, hd)
     Wo, X = rnd(rng, d, H * hd, scale=(H * hd) ** -0.5), rnd(rng, B, d)
     kc_d, vt_d, q_d, Wd, Xd = dev_bf16(kc), dev_bf16(vt), dev_bf16(q), dev_bf16(pack_w16x64(Wo)), dev_bf16(X)
@@ -1861,7 +1859,7 @@ def test_attn_decode_partials_then_merge_launch(L, H, KVH, n_split, config5):
     for b, c in enumerate(ctxs):
         kc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
         vc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
-    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    vt = POS.vt_blocks(vc)
     q = rnd(rng, B, H, hd)
     kc_d, vt_d, q_d = dev_bf16(kc), dev_bf16(vt), dev_bf16(q)
     ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
@@ -1888,7 +1886,7 @@ def test_attn_decode_fused(L, H, KVH, n_split, long_ctx):
     for b, c in enumerate(ctxs):
         kc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
         vc[b, :, :c + 1] = rnd(rng, KVH, c + 1, hd)
-    vt = vc.reshape(B, KVH, s_max // 64, 64, hd).transpose(0, 1, 2, 4, 3)
+    vt = POS.vt_blocks(vc)
     q = rnd(rng, B, H, hd)
     kc_d, vt_d, q_d = dev_bf16(kc), dev_bf16(vt), dev_bf16(q)
     ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
