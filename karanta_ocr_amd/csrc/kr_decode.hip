@@ -2140,7 +2140,21 @@ __global__ void __launch_bounds__(256) sample_greedy_kernel(const float* __restr
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < n_part; i += 256) better(bv, bi, amax_val[(int64_t)b * n_part + i], amax_idx[(int64_t)b * n_part + i]);
+    // eight partials per thread requested at once (clamped indices, no branch around the loads): the lm_head leaves up to 2048
+    // partials per row, and one load pair per loop iteration was eight dependent L2 round trips in a 6 us launch
+    for (int i0 = tid; i0 < n_part; i0 += 256 * 8) {
+        float v[8];
+        int ix[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 256, n_part - 1);
+            v[u] = amax_val[(int64_t)b * n_part + i];
+            ix[u] = amax_idx[(int64_t)b * n_part + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 256 < n_part) better(bv, bi, v[u], ix[u]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o, 64);
@@ -2481,20 +2495,31 @@ namespace {
 // One wave per row, lane l owns the 8-element chunks l, l + 64, ...: exactly the summation structure of the narrow NORM
 // kernel's prologue (dec_narrow_kernel, section 3), so the rows it writes are bit-identical to the ones that kernel
 // stages — a page's tokens stay independent of the batch it decodes in.
-template <int RL>
+// NP = number of slabs as a template constant (0, 1, 2: every slab load is requested up front, next to x and the norm weight —
+// with a run-time count the loads sat inside a loop over the row's pieces, one memory round trip per piece: 5.8 us per launch at
+// K = 3584, r4) or -1 for any count (the general form, slab loads per piece).
+template <int RL, int NP>
 __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ parts,
                                                           int n_part, int part_rows, kr_bf16* __restrict__ x_out, int64_t ldxo,
                                                           const kr_bf16* __restrict__ norm_w, float eps, kr_bf16* __restrict__ h,
                                                           int64_t ldh, int M, int K, int h_xp) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6), kc = K >> 3;
     if (b >= M) return;
+    constexpr int NPR = NP > 0 ? NP : 1;
     bf16x8 xv[RL], nw[RL];
+    f32x4 pv[NPR][RL][2];
 #pragma unroll
     for (int i = 0; i < RL; ++i) {
-        const int c = lane + i * 64;
-        if (c < kc) {
-            xv[i] = ld8(x + (int64_t)b * ldx + c * 8);
-            nw[i] = ld8(norm_w + c * 8);
+        const int c = min(lane + i * 64, kc - 1);        // clamped, not branched: the loads of a masked piece are discarded
+        xv[i] = ld8(x + (int64_t)b * ldx + c * 8);
+        nw[i] = ld8(norm_w + c * 8);
+        if constexpr (NP > 0) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const float* pp = parts + ((int64_t)k * part_rows + b) * K + c * 8;
+                pv[k][i][0] = *reinterpret_cast<const f32x4*>(pp);
+                pv[k][i][1] = *reinterpret_cast<const f32x4*>(pp + 4);
+            }
         }
     }
     float ss = 0.f;
@@ -2505,16 +2530,27 @@ __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restr
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = bf2f(xv[i][j]);
-            for (int k = 0; k < n_part; ++k) {
-                const float* pp = parts + ((int64_t)k * part_rows + b) * K + c * 8;
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+            if constexpr (NP > 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] += p0[j];
-                    v[4 + j] += p1[j];
+                for (int k = 0; k < NP; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] += pv[k][i][0][j];
+                        v[4 + j] += pv[k][i][1][j];
+                    }
+                }
+            } else if constexpr (NP < 0) {
+                for (int k = 0; k < n_part; ++k) {
+                    const float* pp = parts + ((int64_t)k * part_rows + b) * K + c * 8;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] += p0[j];
+                        v[4 + j] += p1[j];
+                    }
                 }
             }
-            if (n_part > 0) {
+            if (NP != 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[i][j] = f2bf(v[j]);
                 *reinterpret_cast<bf16x8*>(x_out + (int64_t)b * ldxo + c * 8) = xv[i];
@@ -2538,6 +2574,17 @@ __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restr
     }
 }
 
+template <int RL>
+void launch_resnorm(int blocks, kr_stream s, const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int pr, kr_bf16* x_out,
+                    int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, int h_xp) {
+#define KR_RESNORM(NP) dec_resnorm_kernel<RL, NP><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp)
+    if (n_part_in == 0) KR_RESNORM(0);
+    else if (n_part_in == 1) KR_RESNORM(1);
+    else if (n_part_in == 2 && RL <= 4) KR_RESNORM(2);
+    else KR_RESNORM(-1);
+#undef KR_RESNORM
+}
+
 int resnorm_impl(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out, int64_t ldxo,
                  const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, int h_xp, kr_stream s) {
     KR_CHECK_ARG(x && norm_w && h, "kr_decode_resnorm: null pointer");
@@ -2548,9 +2595,10 @@ int resnorm_impl(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part
                  "kr_decode_resnorm: partial sums need a separate x_out");
     KR_CHECK_ARG(n_part_in == 0 || part_rows == 0 || part_rows >= M, "kr_decode_resnorm: part_rows %d < M %d", part_rows, M);
     const int pr = part_rows > 0 ? part_rows : M, blocks = (M + 3) / 4;
-    if (K <= 1536) dec_resnorm_kernel<3><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
-    else if (K <= 2048) dec_resnorm_kernel<4><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
-    else dec_resnorm_kernel<8><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    if (K <= 1536) launch_resnorm<3>(blocks, s, x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    else if (K <= 2048) launch_resnorm<4>(blocks, s, x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    else if (K <= 3584) launch_resnorm<7>(blocks, s, x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
+    else launch_resnorm<8>(blocks, s, x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp);
     KR_CHECK_LAUNCH();
     return KR_OK;
 }
