@@ -266,6 +266,7 @@ def main(argv=None):
     [t.start() for t in ts]
     [t.join() for t in ts]
     wall = time.perf_counter() - t0
+    sched = srv.scheduler_stats()                         # (includes the warm-up request's admission and steps)
     S.unregister_local_server(port)
     srv.close()
     la = np.sort(np.asarray(lat))
@@ -281,7 +282,7 @@ def main(argv=None):
         "pages_per_s": round(args.pages / wall, 3), "tokens_per_s": round(sum(toks) / wall, 1), "wall_s": round(wall, 2),
         "latency_s": {"p50": pct(0.50), "p95": pct(0.95), "p99": pct(0.99), "max": round(float(la[-1]), 3)},
         "completion_tokens": int(sum(toks)), "expected_tokens": int(sum(limits)) if not args.guided else None,
-        "errors": errors[:5], "n_errors": len(errors),
+        "scheduler": sched, "errors": errors[:5], "n_errors": len(errors),
     }), flush=True)
     eng.close()
     return 1 if errors else 0

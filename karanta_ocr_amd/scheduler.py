@@ -12,6 +12,7 @@ retire`, and any object with those six methods (the CPU tests use a fake) can st
 from __future__ import annotations
 
 import collections
+import time
 from dataclasses import dataclass
 from typing import Any, Deque, Dict, Iterable, List, Optional, Sequence
 
@@ -66,6 +67,10 @@ class SlotScheduler:
         self.admit_min, self.admit_max_wait = max(1, int(admit_min)), max(0, int(admit_max_wait))
         self._held = 0                               # scheduler steps the oldest admissible request has been held back
         self.steps = 0                               # decode steps run
+        # host wall time by phase (seconds): admission launches, decode-chunk launches, the wait for the GPU in _harvest
+        self.phase_s = {"admit": 0.0, "decode_launch": 0.0, "harvest": 0.0}
+        self.admissions = 0                          # admission rounds that carried pages
+        self.pages_admitted = 0
         self.slot_steps_busy = 0                     # sum over steps of occupied slots (utilisation numerator)
         # a slot may run up to chunk - 1 steps past its limit before the host looks: size the history for that
         # sampling: pages may carry temperature > 0 (the decode graph then includes the Gumbel-max pass)
@@ -97,10 +102,16 @@ class SlotScheduler:
 
     def step(self) -> List[SlotResult]:
         if not self.overlap:
+            t0 = time.perf_counter()
             done: List[SlotResult] = self._admit()
+            t1 = time.perf_counter()
+            self.phase_s["admit"] += t1 - t0
             if self.active:
                 self._decode_chunk()
+                t2 = time.perf_counter()
                 done += self._harvest()
+                self.phase_s["decode_launch"] += t2 - t1
+                self.phase_s["harvest"] += time.perf_counter() - t2
             return done
         # overlapped: finish an admission that is through, queue the decode chunk, THEN spend host time launching the
         # next admission (the GPU has both to run), then look at the finished flags
@@ -208,6 +219,8 @@ class SlotScheduler:
             for r, j, n in zip(batch, slots, lens):
                 self.active[j] = r
                 self.prompt_len[j] = int(n)
+            self.admissions += 1
+            self.pages_admitted += len(batch)
         return failed
 
     def _budget(self, r: SlotRequest) -> int:

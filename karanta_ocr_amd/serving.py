@@ -380,7 +380,17 @@ class LocalServer:
         up = max(1e-9, time.time() - self._t_start)
         return 200, {"pages_done": self.pages_done, "uptime_s": round(up, 3), "pages_per_s": round(self.pages_done / up, 4),
                      "running": self._running, "waiting": self._q.qsize(),
-                     "latency_s": {"p50": pct(0.50), "p95": pct(0.95), "p99": pct(0.99), "n": len(lat)}}
+                     "latency_s": {"p50": pct(0.50), "p95": pct(0.95), "p99": pct(0.99), "n": len(lat)},
+                     "scheduler": self.scheduler_stats()}
+
+    def scheduler_stats(self) -> Optional[dict]:
+        """Continuous mode: where the scheduler thread's wall time went and how full the decode slots were."""
+        sch = getattr(self, "_sch", None)
+        if sch is None:
+            return None
+        return {"decode_steps": sch.steps, "slot_occupancy": round(sch.slot_steps_busy / max(1, sch.steps * sch.n_slots), 4),
+                "admissions": sch.admissions, "pages_admitted": sch.pages_admitted,
+                "host_phase_s": {k: round(v, 3) for k, v in sch.phase_s.items()}}
 
     def models(self) -> Tuple[int, dict]:
         return 200, {"object": "list", "data": [{"id": self.name, "object": "model", "owned_by": "karanta"}]}
@@ -536,6 +546,7 @@ class LocalServer:
                                 admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions)
         except Exception as e:  # cannot enter slot mode: every request gets a 500
             sch, boot_error = None, f"{type(e).__name__}: {e}"
+        self._sch = sch
         last = (-1, -1)
         while not self._stop:
             # block only when there is nothing to decode; otherwise take what has arrived and keep stepping
@@ -574,6 +585,7 @@ class LocalServer:
                                         admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions)
                 except Exception as e2:
                     sch, boot_error = None, f"{type(e2).__name__}: {e2}"
+                self._sch = sch
                 continue
             self._running = sch.running
             now = (sch.running, len(sch.waiting) + self._q.qsize())
