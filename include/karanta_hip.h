@@ -39,7 +39,7 @@ typedef uint16_t kr_bf16;
 /* kr_version() of the library this header describes: major * 100 + minor.  The major changes with every incompatible
  * change of a signature or struct below (r4: kr_narrow_opts argument of round 3, packed 17..32-row family); a caller built
  * against major X must refuse a library whose kr_version() / 100 != X. */
-#define KR_ABI_VERSION 400
+#define KR_ABI_VERSION 402
 
 #define KR_OK 0
 #define KR_ERR_ARG (-1)    /* unsupported shape / null pointer */
@@ -401,7 +401,7 @@ int kr_pack_rows32(const kr_bf16* x, int64_t ldx, int M, int K, kr_bf16* xp, kr_
  * and `ksplit` arguments) — the same chunk ranges accumulated from zero in ascending k, folded in the same order — so row b
  * of the result has the bits kr_linear_decode_narrow gives for that row alone: a page's tokens do not depend on its batch.
  * 8-wave workgroups; a 16-wave partition runs as two ranges per wave.  tiles_per_wg: 0 = automatic (two weight tiles share
- * one ring of x fragments where that leaves >= 192 workgroups), 1, 2.  No norm prologue: x is kr_decode_resnorm32's output. */
+ * one ring of x fragments where that leaves >= 192 workgroups), 1, 2 (4 with group_split).  No norm prologue: x is kr_decode_resnorm32's output. */
 typedef struct kr_dec32 {
     const kr_bf16* xp;            /* packed activations, K * 64 bytes */
     const void* w_packed;         /* weights.pack_w16x32 (bf16) or pack_w16x64_fp8 (with w_scale) */
@@ -416,6 +416,12 @@ typedef struct kr_dec32 {
     int32_t waves_ref, ksplit;    /* the <= 16-row launch's K partition */
     int32_t atomic_out;           /* ksplit == 2: both K ranges ADD into out_f32 (zeroed by an earlier launch) */
     int32_t tiles_per_wg;
+    int32_t group_split;          /* atomic_out, ksplit 2, bf16 weights: each K range's atoms in TWO workgroups (first / second half
+                                   * of the partition), each adding its half's fold into slab [ks] of out_f32 = [2][M][ldc]: the slab
+                                   * holds (half 0) + (half 1) = the narrow launch's fold of that range, and the consumer adds
+                                   * x + (slab 0 + slab 1) (kr_decode_resnorm32, sum_slabs_first) = x + the narrow launch's one slab.
+                                   * Twice the weight tiles per workgroup at the same number of workgroups: half the x bytes */
+    int32_t reserved0;
     float* zero_ptr;              /* this launch also zeroes [zero_ptr, zero_ptr + zero_bytes) (16-byte multiples) */
     uint64_t zero_bytes;
     /* KR_DEC_ROPE_KV (as kr_linear_decode): */
@@ -424,9 +430,11 @@ typedef struct kr_dec32 {
 } kr_dec32;
 int kr_linear_decode32(int mode, const kr_dec32* args, kr_stream s);
 
-/* kr_decode_resnorm with h written in the packed layout (h_xp: K * 64 bytes); x_out stays row-major. */
+/* kr_decode_resnorm with h written in the packed layout (h_xp: K * 64 bytes); x_out stays row-major.  sum_slabs_first
+ * (n_part_in == 2): x + (slab 0 + slab 1) instead of (x + slab 0) + slab 1 — the slabs of a group_split down_proj. */
 int kr_decode_resnorm32(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
-                        int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h_xp, int M, int K, kr_stream s);
+                        int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h_xp, int M, int K, int sum_slabs_first,
+                        kr_stream s);
 
 /* n fp8 e4m3fn codes -> bf16 through the hardware conversion the kernels use (test hook: pins the number format). */
 int kr_fp8_to_bf16(const uint8_t* src, kr_bf16* dst, int64_t n, kr_stream s);
@@ -442,6 +450,13 @@ int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16*
                          const int32_t* ctx_len, kr_bf16* out, float* workspace, int32_t* counters,
                          int batch, int heads, int kv_heads, int hd, int s_max, int n_split,
                          float scale, kr_stream s);
+/* The serving form: kr_attn_decode_fused(out = NULL) for a batch of decode SLOTS — the workgroups of a slot whose `finished` flag
+ * is set (EOS seen by kr_sample_greedy, or retired by the host: an idle slot of the continuous server,
+ * bulk_processing/workers/inference_worker.py:331-339 keeps the slots filled one request at a time) return at once and leave its
+ * partials as they were; nothing downstream consumes a finished row.  Live rows: the same partials, bit for bit. */
+int kr_attn_decode_slots(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
+                         const int32_t* finished, float* workspace, int batch, int heads, int kv_heads, int hd, int s_max,
+                         int n_split, float scale, kr_stream s);
 
 /* Merge of the partials kr_attn_decode_fused leaves with out == NULL into bf16 out [batch, heads*hd]
  * (one small launch; the alternative to merging inside the consumer's prologue). */

@@ -47,7 +47,7 @@ SIGNATURES = {
     "kr_rmsnorm": [c_p, i64, c_p, c_p, i64, i32, f32, c_p],
     "kr_gemm_bf16": [c_p, i64, c_p, c_p, c_p, i64, c_p, i64, i64, i32, i32, i32, i32, c_p],
     "kr_decode_resnorm": [c_p, i64, c_p, i32, i32, c_p, i64, c_p, f32, c_p, i64, i32, i32, c_p],
-    "kr_decode_resnorm32": [c_p, i64, c_p, i32, i32, c_p, i64, c_p, f32, c_p, i32, i32, c_p],
+    "kr_decode_resnorm32": [c_p, i64, c_p, i32, i32, c_p, i64, c_p, f32, c_p, i32, i32, i32, c_p],
     "kr_pack_rows32": [c_p, i64, i32, i32, c_p, c_p],
     "kr_linear_decode32": [i32, c_p, c_p],
     "kr_attn_decode_merge32": [c_p, c_p, i32, i32, i32, i32, c_p],
@@ -85,6 +85,7 @@ SIGNATURES = {
     "kr_linear_decode_narrow": [i32, c_p, i64, c_p, i32, c_p, i64, c_p, c_p, c_p, f32, c_p, i64, c_p, c_p, i64,
                                 i32, i32, i32, i32, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p],
     "kr_attn_decode_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
+    "kr_attn_decode_slots": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, f32, c_p],
     "kr_attn_decode_merge": [c_p, c_p, i32, i32, i32, i32, c_p],
     "kr_sample_greedy": [c_p, c_p, i32, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, i32, c_p],
     "kr_comm_unique_id": [c_p],
@@ -129,7 +130,7 @@ class Dec32(C.Structure):
     _fields_ = [("xp", c_p), ("w_packed", c_p), ("w_scale", c_p), ("bias", c_p), ("residual", c_p), ("ldr", C.c_int64),
                 ("out", c_p), ("out_f32", c_p), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("waves_ref", C.c_int32), ("ksplit", C.c_int32), ("atomic_out", C.c_int32), ("tiles_per_wg", C.c_int32),
-                ("zero_ptr", c_p), ("zero_bytes", C.c_uint64),
+                ("group_split", C.c_int32), ("reserved0", C.c_int32), ("zero_ptr", c_p), ("zero_bytes", C.c_uint64),
                 ("cs_table", c_p), ("cs_stride", C.c_int32), ("prompt_len", c_p), ("ctx_len", c_p),
                 ("q_out", c_p), ("kcache", c_p), ("vtcache", c_p), ("heads", C.c_int32), ("kv_heads", C.c_int32), ("s_max", C.c_int32)]
 

@@ -189,6 +189,9 @@ def main(argv=None):
     ap.add_argument("--overlap-cus", type=int, default=None,
                     help="overlap admissions with decoding: ViT + prefill on a stream restricted to this many CUs "
                          "(kr_stream_create_cu_mask; 0 = an ordinary second stream; unset = admissions interrupt the decode graph)")
+    ap.add_argument("--launch-ahead", action="store_true",
+                    help="queue the next decode chunk before waiting for the previous chunk's flags (SlotScheduler(launch_ahead=True); "
+                         "measured: no gain on this workload, profiles/r04_corpus_launch_ahead.txt)")
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU front end")
     ap.add_argument("--guided", action="store_true", help="every request carries the pipeline's guided_regex")
     ap.add_argument("--gpus", type=int, default=None,
@@ -229,7 +232,7 @@ def main(argv=None):
     eng.load_weights(random_weights(cfg, 0, as_bits=True))
     srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=True, max_tokens_cap=args.t_max, chunk=args.chunk,
                         honor_temperature=False, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait,
-                        overlap_admissions=args.overlap_cus is not None)
+                        overlap_admissions=args.overlap_cus is not None, launch_ahead=args.launch_ahead)
     port = 8791
     S.register_local_server(port, srv)
     guided = GUIDED
@@ -276,6 +279,7 @@ def main(argv=None):
                     f"VLLMClient.generate -> LocalServer(continuous), {args.workers} worker threads, {B} decode slots, "
                     f"max_tokens U[{args.t_min},{args.t_max}] (mean {np.mean(limits):.0f}), prompt {P} tokens, "
                     f"admit_min {args.admit_min} (max wait {args.admit_max_wait} x {args.chunk} steps), "
+                    f"{'chunks queued one ahead, ' if args.launch_ahead and args.overlap_cus is None else ''}"
                     f"{'admissions interrupt the decode graph' if args.overlap_cus is None else 'admissions overlapped on ' + (str(args.overlap_cus) + ' CUs' if args.overlap_cus else 'an unmasked second stream')}, "
                     f"{'host PIL' if args.host_images else 'GPU'} image front end, {'guided_regex' if args.guided else 'greedy'}, "
                     f"random-init weights",

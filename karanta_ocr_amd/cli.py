@@ -166,7 +166,9 @@ def make_server(args, log=print):
     max_prompt_tokens, max_patches = admission_budget(args, cfg, max_pixels)
     log(f"admission budget: {max_prompt_tokens} prompt tokens / {max_patches} image patches per ViT + prefill pass, "
         f"{args.max_num_seqs} decode slots of {args.max_model_len} tokens")
-    eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 63) // 64 * 64,
+    # cache rows per slot: the model length + the steps a slot may run past its limit before the scheduler looks (2 chunks of 8
+    # with launch-ahead) + the parking row
+    eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 17 + 63) // 64 * 64,
                  max_patches=max_patches, max_prompt_tokens=max_prompt_tokens,
                  weight_dtype=weight_dtype, fp8_activations=bool(getattr(args, "fp8_activations", False)) or None)
     # one server: read the checkpoint.  A launch.py group: rank 0 reads it ONCE, the arena goes to the other GPUs over

@@ -576,6 +576,263 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
         }
 }
 
+// =====================================================================================
+// 4 waves x 64 queries: ONE wave per SIMD with the whole register file (VERDICT r3 next #4b; the guide's "4-wave, one-wave-per-SIMD"
+// attention structure, cdna_hip_programming.md)
+// =====================================================================================
+// A workgroup is still 256 queries of one head over the same two-image K / V^T ring, but its 4 waves own 64 queries each (two
+// 32-query blocks): the K and V^T fragments a wave reads from LDS feed TWO MFMA chains (half the fragment reads per MFMA), and the
+// overlap of softmax and matrix work has to come from inside the wave — QK^T of block 1 and PV of block 0 are independent of
+// block 0's / block 1's exponentials, in one basic block for the scheduler to interleave — instead of from a second wave on the
+// SIMD.  Same arithmetic per query as attn_varlen_kernel (PRESCALE, ONES row, lazy reference): bit-identical outputs.
+template <int HD, bool CAUSAL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) attn_varlen_q64_kernel(
+    const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ k, const kr_bf16* __restrict__ vt, kr_bf16* __restrict__ out,
+    const int32_t* __restrict__ qblk, const int32_t* __restrict__ qblk_len, int64_t nq_total, int q_heads, int group,
+    int64_t k_head_stride, int64_t vt_head_stride, float scale_log2e) {
+    using C = AttnCfg<HD>;
+    constexpr int NTHR = 256, QB = 2;
+    constexpr int K_CH = 64 * C::KCH, V_CH = HD * 8, T_CH = K_CH + V_CH, PASSES = (T_CH + NTHR - 1) / NTHR;
+    constexpr int K_BYTES = 64 * C::KROW, V_BYTES = C::DT * 32 * C::VROW, IMG = K_BYTES + V_BYTES;
+    __shared__ __attribute__((aligned(16))) char img_s[2 * IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int bi = blockIdx.x / q_heads, head = blockIdx.x - bi * q_heads, kvh = head / group;
+    const int64_t q_row0 = qblk[4 * bi + 0];
+    const int n_q = qblk[4 * bi + 1];
+    const int64_t k_row0 = (int64_t)qblk[4 * bi + 2];
+    const int64_t vt_blk0 = (int64_t)qblk[4 * bi + 3];
+    const int kv_len_seg = qblk_len[2 * bi + 0];
+    const int q_pos0 = qblk_len[2 * bi + 1];
+    int kv_len = kv_len_seg;
+    if (CAUSAL) kv_len = min(kv_len, q_pos0 + n_q);
+    const int n_tiles = (kv_len + 63) >> 6;
+    constexpr bool ONES = C::DT * 32 > HD;
+    if (ONES) {
+        for (int e = tid; e < (C::DT * 32 - HD) * C::VROW / 8; e += NTHR) {
+            const unsigned v = e < 16 ? 0x3F803F80u : 0u;
+            reinterpret_cast<u32x2*>(img_s + K_BYTES + HD * C::VROW)[e] = (u32x2){v, v};
+            reinterpret_cast<u32x2*>(img_s + IMG + K_BYTES + HD * C::VROW)[e] = (u32x2){v, v};
+        }
+    }
+    constexpr bool PRESCALE = (HD == 80) && KR_ATTN_PRESCALE;
+    int ql[QB];
+    bool q_valid[QB];
+    bf16x8 qf[QB][C::KS];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        ql[b] = wave * 64 + b * 32 + lq;
+        q_valid[b] = ql[b] < n_q;
+        if (!q_valid[b]) ql[b] = n_q - 1;
+        const kr_bf16* qp = q + ((int64_t)head * nq_total + q_row0 + ql[b]) * HD + lh * 8;
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) qf[b][s] = ld8(qp + s * 16);
+        if (PRESCALE) {
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[b][s][j] = f2bf(bf2f(qf[b][s][j]) * scale_log2e);
+        }
+    }
+    float m_run[QB], l_run[QB];
+    f32x16 o[QB][C::DT], cinit[QB];   // cinit: -m_ref of the block's queries in every register (zero without PRESCALE)
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        m_run[b] = PRESCALE ? 0.f : -1e30f;
+        l_run[b] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[b][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][t][r] = 0.f;
+    }
+    const kr_bf16* kbase = k + (int64_t)kvh * k_head_stride + k_row0 * HD;
+    const kr_bf16* vbase = vt + (int64_t)kvh * vt_head_stride + vt_blk0 * (int64_t)(HD * 64);
+    bf16x8 treg[PASSES];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int idx = p * NTHR + tid;
+            idx = idx < T_CH ? idx : T_CH - 1;
+            const int key = idx / C::KCH, c = idx - key * C::KCH;
+            int kg = t * 64 + key;
+            kg = kg < kv_len_seg ? kg : kv_len_seg - 1;
+            const kr_bf16* kp = kbase + (int64_t)kg * HD + c * 8;
+            const kr_bf16* vp = vbase + (int64_t)t * (HD * 64) + (idx - K_CH) * 8;
+            treg[p] = ld8(idx < K_CH ? kp : vp);
+        }
+    };
+    auto store_tile = [&](char* img) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int idx = p * NTHR + tid;
+            idx = idx < T_CH ? idx : T_CH - 1;
+            const int key = idx / C::KCH, c = idx - key * C::KCH;
+            const int off = idx < K_CH ? k_lds_off<HD>(key, c) : K_BYTES + vt_lds_piece<HD>(idx - K_CH, C::VROW);
+            const u32x4 w = __builtin_bit_cast(u32x4, treg[p]);
+            u32x2* dstp = reinterpret_cast<u32x2*>(img + off);
+            dstp[0] = (u32x2){w[0], w[1]};
+            dstp[1] = (u32x2){w[2], w[3]};
+        }
+    };
+    if (n_tiles > 0) {
+        load_tile(0);
+        store_tile(img_s);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        load_tile(n_tiles > 1 ? 1 : 0);
+        __syncthreads();
+        for (int t = 0; t < n_tiles; ++t) {
+            const char* k_s = img_s + (t & 1) * IMG;
+            const char* v_s = k_s + K_BYTES;
+            if (!CAUSAL || t * 64 <= q_pos0 + wave * 64 + 63) {
+                bf16x8 kf[2][C::KS];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int ks = 0; ks < C::KS; ++ks)
+                        kf[sub][ks] = *reinterpret_cast<const bf16x8*>(k_s + k_lds_off<HD>(sub * 32 + lq, 2 * ks + lh));
+                f32x16 s[QB][2];
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        // the chain starts from the block's persistent -m_ref tuple (PRESCALE) / from zero: no per-tile register fill
+                        s[b][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][0], qf[b][0], cinit[b], 0, 0, 0);
+#pragma unroll
+                        for (int ks = 1; ks < C::KS; ++ks)
+                            s[b][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[b][ks], s[b][sub], 0, 0, 0);
+                    }
+                // V^T fragments: read once, used by both query blocks
+                bf16x8 vf[C::DT][4];
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const char* vrow = v_s + (dt * 32 + lq) * C::VROW;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int kb = f * 16 + 4 * lh;
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + kb * 2);
+                        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (kb + 8) * 2);
+                        vf[dt][f] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+                    }
+                }
+                bf16x8 pf[QB][2][2];
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    const int qpos = q_pos0 + wave * 64 + b * 32 + lq;
+                    bool need_mask = t * 64 + 64 > kv_len_seg;
+                    if (CAUSAL) need_mask |= t * 64 + 63 > q_pos0 + wave * 64 + b * 32;
+                    if (need_mask) {
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                const bool ok = key < kv_len_seg && (!CAUSAL || key <= qpos);
+                                s[b][sub][r] = ok ? s[b][sub][r] : -INFINITY;
+                            }
+                    }
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][sub][r]);
+                    {
+                        const unsigned mb = __builtin_bit_cast(unsigned, mx);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+                    }
+                    if (!PRESCALE) mx *= scale_log2e;
+                    if (PRESCALE) {
+                        const bool first = t == 0;
+                        if (first || __any(mx > 8.0f)) {
+                            const float d = first ? (mx > -INFINITY ? mx : 0.f) : fmaxf(mx, 0.f);
+                            m_run[b] += d;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) cinit[b][r] = -m_run[b];
+#pragma unroll
+                            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) s[b][sub][r] -= d;
+                            if (!first) {
+                                const float alpha = __builtin_amdgcn_exp2f(-d);
+                                l_run[b] *= alpha;
+#pragma unroll
+                                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) o[b][dt][r] *= alpha;
+                            }
+                        }
+                    } else {
+                        const float m_new = fmaxf(m_run[b], mx);
+                        if (__any(m_new - m_run[b] > 8.0f)) {
+                            const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+                            m_run[b] = m_new;
+                            l_run[b] *= alpha;
+#pragma unroll
+                            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[b][dt][r] *= alpha;
+                        }
+                    }
+                    float psum = 0.f;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int h8 = 0; h8 < 2; ++h8) {
+                            f32x8 pv;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                pv[j] = PRESCALE ? __builtin_amdgcn_exp2f(s[b][sub][h8 * 8 + j])
+                                                 : __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][sub][h8 * 8 + j], scale_log2e, -m_run[b]));
+                                if (!ONES) psum += pv[j];
+                            }
+                            pf[b][sub][h8] = __builtin_convertvector(pv, bf16x8);
+                        }
+                    l_run[b] += psum;
+                }
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int ss = 0; ss < 2; ++ss)
+                                o[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][sub * 2 + ss], pf[b][sub][ss], o[b][dt], 0, 0, 0);
+            }
+            store_tile(img_s + ((t + 1) & 1) * IMG);
+            __syncthreads();
+            load_tile(t + 2 < n_tiles ? t + 2 : n_tiles - 1);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        float l_tot;
+        if (ONES) {
+            l_tot = __shfl(o[b][HD / 32][8], lq, 64);
+        } else {
+            l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        }
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (q_valid[b]) {
+            kr_bf16* op = out + (q_row0 + ql[b]) * ((int64_t)q_heads * HD) + (int64_t)head * HD;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = dt * 32 + 8 * i + 4 * lh;
+                    if (d < HD) {
+                        bf16x4 ov;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ov[j] = f2bf(o[b][dt][4 * i + j] * inv);
+                        *reinterpret_cast<bf16x4*>(op + d) = ov;
+                    }
+                }
+        }
+    }
+}
+
 #ifdef KR_ATTN_PIPE_EXPERIMENT
 // =====================================================================================
 // EXPERIMENT (r3, measured, NOT adopted; built only with -DKR_ATTN_PIPE_EXPERIMENT via tools/build_variant.py):
@@ -1226,7 +1483,17 @@ static int attn_varlen_impl(const kr_bf16* q, const kr_bf16* k, const kr_bf16* v
     attn_varlen_kernel<HD_, C_, NW_><<<grid, NW_ * 64, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total, q_heads, group, \
                                                                       k_head_stride, vt_head_stride, sl)
 #endif
-#define KR_LAUNCH_ATTN_Q(HD_, C_) do { if (q_block == 256) KR_LAUNCH_ATTN(HD_, C_, 8); else KR_LAUNCH_ATTN(HD_, C_, 4); } while (0)
+    static const int q64_default = [] { const char* e = getenv("KARANTA_ATTN_Q64"); return e ? atoi(e) : 0; }();
+    const char* q64e = getenv("KARANTA_ATTN_Q64_NOW");   // tools/attn_microbench.py: same-process A/B
+    const bool q64 = q_block == 256 && (q64e ? atoi(q64e) != 0 : q64_default != 0);
+#define KR_LAUNCH_ATTN_Q(HD_, C_)                                                                                          \
+    do {                                                                                                                   \
+        if (q64 && HD_ == 80) /* hd 128: two query blocks' accumulators do not fit 512 registers (spills) */               \
+            attn_varlen_q64_kernel<80, C_><<<grid, 256, 0, kr_hs(s)>>>(q, k, vt, out, qblk, qblk_len, nq_total, q_heads, group,  \
+                                                                       k_head_stride, vt_head_stride, sl);                 \
+        else if (q_block == 256) KR_LAUNCH_ATTN(HD_, C_, 8);                                                               \
+        else KR_LAUNCH_ATTN(HD_, C_, 4);                                                                                   \
+    } while (0)
     if (hd == 80) {
         if (causal) KR_LAUNCH_ATTN_Q(80, true); else KR_LAUNCH_ATTN_Q(80, false);
     } else {

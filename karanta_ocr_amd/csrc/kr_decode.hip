@@ -1506,13 +1506,23 @@ __global__ void __launch_bounds__(WAVES * 64) dec_narrow_kernel(const kr_bf16* h
             f32x4 sum[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // THE fold of this K range, for every batch size (kr_decode32.hip reproduces it): the waves' sums in wave order
+                // inside each HALF of the waves, then the two halves added — so that a 17..32-row launch may give the two halves
+                // to two workgroups (each folds its own, both add into the slab: two addends, order-free) and still produce these
+                // bits (r4; rounds 1-3: one left fold over all waves)
+                f32x4 half[2];
 #pragma unroll
-                for (int w = 0; w < WAVES; ++w) {
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
+                for (int hfi = 0; hfi < 2; ++hfi) {
+                    half[hfi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sum[t][j] += p[j];
+                    for (int w = hfi * (WAVES / 2); w < (hfi + 1) * (WAVES / 2); ++w) {
+                        const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) half[hfi][j] += p[j];
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[t][j] = half[0][j] + half[1][j];
             }
             epilogue(mt, sum);
         }
@@ -1770,7 +1780,8 @@ int launch_oproj_heads(const float* ws, const void* wp, const float* w_scale, fl
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16* __restrict__ q, const kr_bf16* __restrict__ kcache,
                                                                   const kr_bf16* __restrict__ vtcache,
-                                                                  const int32_t* __restrict__ ctx_len, int heads, int kv_heads,
+                                                                  const int32_t* __restrict__ ctx_len,
+                                                                  const int32_t* __restrict__ finished, int heads, int kv_heads,
                                                                   int group, int n_split, int s_max, float scale_log2e,
                                                                   kr_bf16* __restrict__ out, float* __restrict__ ws,
                                                                   int* __restrict__ counters, int ws_bytes) {
@@ -1787,6 +1798,9 @@ __global__ void __launch_bounds__(WAVES * 64) attn_decode2_kernel(const kr_bf16*
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int n_part = n_split * WAVES, part = split * WAVES + wave;
     const int ctx = ctx_len[b] + 1;
+    // a sequence that has finished (EOS flag set by the sampling launch, or retired by the host): nothing downstream reads its rows
+    // any more — its workgroups leave without touching its cache (a server's idle slots: ~18 % of the rows in the corpus run)
+    if (finished != nullptr && finished[b] != 0) return;
 
     const int g = fr < group ? fr : 0;
     // MFMA k-step i pairs K[key][32i + 8fg + j] with Q[g][32i + 8fg + j]: per load instruction the
@@ -2450,9 +2464,9 @@ extern "C" int kr_linear_decode_narrow_fp8(int mode, const kr_bf16* x, int64_t l
                        heads, kv_heads, s_max, opts, s);
 }
 
-extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
-                                    kr_bf16* out, float* workspace, int32_t* counters, int batch, int heads, int kv_heads,
-                                    int hd, int s_max, int n_split, float scale, kr_stream s) {
+static int attn_decode_impl(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
+                            const int32_t* finished, kr_bf16* out, float* workspace, int32_t* counters, int batch, int heads,
+                            int kv_heads, int hd, int s_max, int n_split, float scale, kr_stream s) {
     KR_CHECK_ARG(q && kcache && vtcache && ctx_len && (out || workspace), "kr_attn_decode_fused: null pointer");
     KR_CHECK_ARG(hd == 128, "kr_attn_decode_fused: hd=%d (only 128)", hd);
     KR_CHECK_ARG(heads % kv_heads == 0 && heads / kv_heads <= 16, "kr_attn_decode_fused: GQA group must be <= 16");
@@ -2477,16 +2491,29 @@ extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, con
     const float sl2 = scale * 1.4426950408889634f;
     const int group = heads / kv_heads;
     if (waves == 8)
-        attn_decode2_kernel<8><<<grid, 512, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
+        attn_decode2_kernel<8><<<grid, 512, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, finished, heads, kv_heads, group, n_split, s_max, sl2, out,
                                                            workspace, counters, (int)ws_bytes);
     else if (waves == 4)
-        attn_decode2_kernel<4><<<grid, 256, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
+        attn_decode2_kernel<4><<<grid, 256, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, finished, heads, kv_heads, group, n_split, s_max, sl2, out,
                                                            workspace, counters, (int)ws_bytes);
     else
-        attn_decode2_kernel<2><<<grid, 128, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, heads, kv_heads, group, n_split, s_max, sl2, out,
+        attn_decode2_kernel<2><<<grid, 128, 0, kr_hs(s)>>>(q, kcache, vtcache, ctx_len, finished, heads, kv_heads, group, n_split, s_max, sl2, out,
                                                            workspace, counters, (int)ws_bytes);
     KR_CHECK_LAUNCH();
     return KR_OK;
+}
+
+extern "C" int kr_attn_decode_fused(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
+                                    kr_bf16* out, float* workspace, int32_t* counters, int batch, int heads, int kv_heads,
+                                    int hd, int s_max, int n_split, float scale, kr_stream s) {
+    return attn_decode_impl(q, kcache, vtcache, ctx_len, nullptr, out, workspace, counters, batch, heads, kv_heads, hd, s_max, n_split, scale, s);
+}
+
+extern "C" int kr_attn_decode_slots(const kr_bf16* q, const kr_bf16* kcache, const kr_bf16* vtcache, const int32_t* ctx_len,
+                                    const int32_t* finished, float* workspace, int batch, int heads, int kv_heads, int hd, int s_max,
+                                    int n_split, float scale, kr_stream s) {
+    KR_CHECK_ARG(finished && workspace, "kr_attn_decode_slots: null pointer");
+    return attn_decode_impl(q, kcache, vtcache, ctx_len, finished, nullptr, workspace, nullptr, batch, heads, kv_heads, hd, s_max, n_split, scale, s);
 }
 
 // ---- residual sum + RMSNorm ONCE per batch (decode batches above 16 rows)
@@ -2530,7 +2557,24 @@ __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restr
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = bf2f(xv[i][j]);
-            if constexpr (NP > 0) {
+            if constexpr (NP == 2) {
+                if (h_xp & 2) {   // the two slabs are the two K ranges of a group-split down_proj: x + (s0 + s1), the <= 16-row sum
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] += pv[0][i][0][j] + pv[1][i][0][j];
+                        v[4 + j] += pv[0][i][1][j] + pv[1][i][1][j];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] += pv[k][i][0][j];
+                            v[4 + j] += pv[k][i][1][j];
+                        }
+                    }
+                }
+            } else if constexpr (NP > 0) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
 #pragma unroll
@@ -2568,7 +2612,7 @@ __global__ void __launch_bounds__(256) dec_resnorm_kernel(const kr_bf16* __restr
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(nw[i][j]) * bfround(bf2f(xv[i][j]) * rs));
-            if (h_xp) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(h) + kr_xp_byte_offset(b, c * 8)) = o;
+            if (h_xp & 1) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(h) + kr_xp_byte_offset(b, c * 8)) = o;
             else *reinterpret_cast<bf16x8*>(h + (int64_t)b * ldh + c * 8) = o;
         }
     }
@@ -2580,7 +2624,7 @@ void launch_resnorm(int blocks, kr_stream s, const kr_bf16* x, int64_t ldx, cons
 #define KR_RESNORM(NP) dec_resnorm_kernel<RL, NP><<<blocks, 256, 0, kr_hs(s)>>>(x, ldx, part_in, n_part_in, pr, x_out, ldxo, norm_w, norm_eps, h, ldh, M, K, h_xp)
     if (n_part_in == 0) KR_RESNORM(0);
     else if (n_part_in == 1) KR_RESNORM(1);
-    else if (n_part_in == 2 && RL <= 4) KR_RESNORM(2);
+    else if (n_part_in == 2 && (RL <= 4 || (h_xp & 2))) KR_RESNORM(2);
     else KR_RESNORM(-1);
 #undef KR_RESNORM
 }
@@ -2589,8 +2633,9 @@ int resnorm_impl(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part
                  const kr_bf16* norm_w, float norm_eps, kr_bf16* h, int64_t ldh, int M, int K, int h_xp, kr_stream s) {
     KR_CHECK_ARG(x && norm_w && h, "kr_decode_resnorm: null pointer");
     KR_CHECK_ARG(M >= 1 && M <= 32 && K > 0 && K % 8 == 0 && K <= 4096, "kr_decode_resnorm: M=%d K=%d (M <= 32, K %% 8, K <= 4096)", M, K);
-    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && (h_xp ? (K % 64 == 0 && ((uintptr_t)h & 15) == 0) : (ldh >= K && (ldh & 7) == 0)),
+    KR_CHECK_ARG(ldx >= K && (ldx & 7) == 0 && ((h_xp & 1) ? (K % 64 == 0 && ((uintptr_t)h & 15) == 0) : (ldh >= K && (ldh & 7) == 0)),
                  "kr_decode_resnorm: ldx / ldh");
+    KR_CHECK_ARG(!(h_xp & 2) || n_part_in == 2, "kr_decode_resnorm32: sum_slabs_first takes exactly two slabs");
     KR_CHECK_ARG(n_part_in >= 0 && n_part_in <= 8 && (n_part_in == 0 || (part_in && x_out && x_out != x && ldxo >= K && (ldxo & 7) == 0)),
                  "kr_decode_resnorm: partial sums need a separate x_out");
     KR_CHECK_ARG(n_part_in == 0 || part_rows == 0 || part_rows >= M, "kr_decode_resnorm: part_rows %d < M %d", part_rows, M);
@@ -2610,8 +2655,9 @@ extern "C" int kr_decode_resnorm(const kr_bf16* x, int64_t ldx, const float* par
 }
 
 extern "C" int kr_decode_resnorm32(const kr_bf16* x, int64_t ldx, const float* part_in, int n_part_in, int part_rows, kr_bf16* x_out,
-                                   int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h_xp, int M, int K, kr_stream s) {
-    return resnorm_impl(x, ldx, part_in, n_part_in, part_rows, x_out, ldxo, norm_w, norm_eps, h_xp, 0, M, K, 1, s);
+                                   int64_t ldxo, const kr_bf16* norm_w, float norm_eps, kr_bf16* h_xp, int M, int K, int sum_slabs_first,
+                                   kr_stream s) {
+    return resnorm_impl(x, ldx, part_in, n_part_in, part_rows, x_out, ldxo, norm_w, norm_eps, h_xp, 0, M, K, 1 | (sum_slabs_first ? 2 : 0), s);
 }
 
 static int merge_impl(const float* workspace, kr_bf16* out, int batch, int heads, int hd, int n_split, int xp, kr_stream s) {

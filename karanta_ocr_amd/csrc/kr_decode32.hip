@@ -73,21 +73,27 @@ struct D32Args {
 
 // WAVES physical waves, each owning VW consecutive atoms of the WAVES * VW the reference partition has; U = ring depth in
 // chunks (x fragments and weights of a chunk travel together); NT weight tiles per workgroup.
-template <int NT, int EPI, int WAVES, int VW, int U, bool W8>
+// GS ("group split", atomic split-K slabs only): the workgroup owns ONE HALF of a K range's atoms — blockIdx.y = 2 * ks + half —
+// folds them in wave order and adds the half's sum into slab ks, which the other half's workgroup adds into as well: two
+// addends per slab element, so the slab holds (first half) + (second half) = the narrow kernel's fold whichever arrives
+// first.  Half the x bytes per weight byte at the same number of workgroups (NT doubles).
+template <int NT, int EPI, int WAVES, int VW, int U, bool W8, bool GS = false>
 __global__ void __launch_bounds__(WAVES * 64) dec32_kernel(const char* hxp, const char* hwp, int hM, int hN, int hK, int hcpb,
                                                            const D32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WC = WCh<W8>;
-    constexpr int WREF = WAVES * VW;
+    constexpr int WLOC = WAVES * VW;                 // atoms of this workgroup
+    constexpr int WREF = GS ? 2 * WLOC : WLOC;       // atoms of the reference partition of one K range
+    static_assert(!GS || EPI == D32_PARTIAL, "group split feeds atomic slabs");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int g = blockIdx.x, ks = blockIdx.y;
+    const int g = blockIdx.x, ks = GS ? (int)blockIdx.y >> 1 : (int)blockIdx.y, a0 = GS ? ((int)blockIdx.y & 1) * WLOC : 0;
     const int M = hM, nchunks = hK >> 6, ntiles = hN >> 4;
     const int cb0 = min(ks * hcpb, nchunks), cb1 = min(cb0 + hcpb, nchunks), nblk = cb1 - cb0;
     int ab[VW + 1];   // atom boundaries of this wave (the narrow kernel's c0 / c1 with WAVES = WREF)
 #pragma unroll
-    for (int v = 0; v <= VW; ++v) ab[v] = cb0 + ((wave * VW + v) * nblk) / WREF;
+    for (int v = 0; v <= VW; ++v) ab[v] = cb0 + ((a0 + wave * VW + v) * nblk) / WREF;
     const int c0 = ab[0], c1 = ab[VW];
 
     int tile[NT];
@@ -214,21 +220,49 @@ __global__ void __launch_bounds__(WAVES * 64) dec32_kernel(const char* hxp, cons
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                *reinterpret_cast<f32x4*>(red + ((((mt * WREF) + wave * VW + v) * NT + t) * 64 + lane) * 4) = acc[v][mt][t];
+                *reinterpret_cast<f32x4*>(red + ((((mt * WLOC) + wave * VW + v) * NT + t) * 64 + lane) * 4) = acc[v][mt][t];
     __syncthreads();
+    if constexpr (GS) {   // roles (column tile, weight tile) dealt over the waves; every role: fold of this half, add into slab ks
+        for (int role = wave; role < MT * NT; role += WAVES) {
+            const int rmt = role & 1, rt = role >> 1, rb = fr + 16 * rmt;
+            f32x4 sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WLOC; ++w) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((((rmt * WLOC) + w) * NT + rt) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm[j] += p[j];
+            }
+            if (rb < M && tile[rt] < ntiles) {
+                float* dst = a.out_f32 + ((int64_t)ks * M + rb) * a.ldc + tile[rt] * 16 + fg * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sm[j]);
+            }
+        }
+        return;
+    }
+    static_assert(GS || (EPI == D32_ROPE_KV ? MT : MT * NT) <= WAVES, "one epilogue role per wave");
     if (wave >= EW) return;
     constexpr int ET = EPI == D32_ROPE_KV ? NT : 1;   // tiles this epilogue wave folds
     f32x4 sum[ET];
 #pragma unroll
     for (int e = 0; e < ET; ++e) {
         const int t = EPI == D32_ROPE_KV ? e : et;
-        sum[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the narrow kernel's fold: wave order inside each half of the atoms, then the two halves added (GS: this workgroup's
+        // atoms ARE one half; the slab add is the second level)
+        constexpr int NH = GS ? 1 : 2;
+        f32x4 half[NH];
 #pragma unroll
-        for (int w = 0; w < WREF; ++w) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((((emt * WREF) + w) * NT + t) * 64 + lane) * 4);
+        for (int hfi = 0; hfi < NH; ++hfi) {
+            half[hfi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum[e][j] += p[j];
+            for (int w = hfi * (WLOC / NH); w < (hfi + 1) * (WLOC / NH); ++w) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(red + ((((emt * WLOC) + w) * NT + t) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) half[hfi][j] += p[j];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[e][j] = GS ? half[0][j] : half[0][j] + half[NH - 1][j];
         if (a.w_scale) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(a.w_scale + min(tile[t], ntiles - 1) * 16 + fg * 4);
 #pragma unroll
@@ -334,6 +368,19 @@ int launch32_u(const kr_dec32& q, const D32Args& a, int groups, kr_stream s) {
     }
 }
 
+// group split: grid.y = 2 * ksplit (K range, half of its atoms); bf16 weights (a row scale would have to multiply the SUM of
+// the two halves).  8-atom partitions run 4-wave workgroups with NT tiles, 16-atom partitions 8-wave workgroups.
+template <int NT, int WAVES, int U>
+int launch32_gs(const kr_dec32& q, const D32Args& a, int groups, kr_stream s) {
+    const int nchunks = q.K >> 6, cpb = (nchunks + q.ksplit - 1) / q.ksplit;
+    const size_t lds = (size_t)MT * WAVES * NT * 1024;
+    auto fn = &dec32_kernel<NT, D32_PARTIAL, WAVES, 1, U, false, true>;
+    fn<<<dim3(groups, 2 * q.ksplit), WAVES * 64, lds, kr_hs(s)>>>(reinterpret_cast<const char*>(q.xp), reinterpret_cast<const char*>(q.w_packed),
+                                                                  q.M, q.N, q.K, cpb, a);
+    KR_CHECK_LAUNCH();
+    return KR_OK;
+}
+
 template <int NT, int EPI, bool W8>
 int launch32_w(const kr_dec32& q, const D32Args& a, int groups, kr_stream s) {
     // physical waves: 8; a 16-atom reference partition runs as two atoms per wave
@@ -376,7 +423,9 @@ extern "C" int kr_linear_decode32(int mode, const kr_dec32* qp, kr_stream s) {
     KR_CHECK_ARG(q.ksplit >= 1 && q.ksplit <= 8 && q.ksplit <= (q.K >> 6), "kr_linear_decode32: ksplit=%d", q.ksplit);
     KR_CHECK_ARG((q.zero_ptr || q.zero_bytes == 0) && ((uintptr_t)q.zero_ptr & 15) == 0 && (q.zero_bytes & 15) == 0 && q.zero_bytes < (1u << 30),
                  "kr_linear_decode32: zero range");
-    KR_CHECK_ARG(q.tiles_per_wg >= 0 && q.tiles_per_wg <= 2, "kr_linear_decode32: tiles_per_wg=%d (0 = automatic, 1, 2)", q.tiles_per_wg);
+    KR_CHECK_ARG(q.tiles_per_wg >= 0 && (q.tiles_per_wg <= 2 || (q.group_split && q.tiles_per_wg == 4)),
+                 "kr_linear_decode32: tiles_per_wg=%d (0 = automatic, 1, 2; 4 with group_split)", q.tiles_per_wg);
+    KR_CHECK_ARG(!q.group_split || (mode == D32_PLAIN && q.ksplit == 2), "kr_linear_decode32: group_split is for PLAIN, ksplit 2");
     D32Args a{};
     a.w_scale = q.w_scale; a.bias = q.bias; a.residual = q.residual; a.ldr = q.ldr;
     a.out = q.out; a.out_f32 = q.out_f32; a.ldc = q.ldc; a.ksplit = q.ksplit; a.part_atomic = q.atomic_out ? 1 : 0;
@@ -393,6 +442,18 @@ extern "C" int kr_linear_decode32(int mode, const kr_dec32* qp, kr_stream s) {
             if (q.ksplit > 1) {
                 KR_CHECK_ARG(q.out_f32 && !q.out && !q.bias && !q.residual, "kr_linear_decode32: split-K writes f32 slabs only (no bias / residual)");
                 KR_CHECK_ARG(!a.part_atomic || q.ksplit == 2, "kr_linear_decode32: atomic_out is for ksplit 2 (order-free sum)");
+                if (q.group_split) {
+                    KR_CHECK_ARG(a.part_atomic && !q.w_scale, "kr_linear_decode32: group_split needs atomic_out and bf16 weights");
+                    const int cpb = ((q.K >> 6) + q.ksplit - 1) / q.ksplit, share = (cpb + q.waves_ref - 1) / q.waves_ref;
+                    const int tw = q.tiles_per_wg ? q.tiles_per_wg : (q.waves_ref == 8 ? 4 : 2);
+                    KR_CHECK_ARG(ntiles % tw == 0 && (tw == 2 || tw == 4), "kr_linear_decode32: group_split tiles_per_wg=%d over %d tiles", tw, ntiles);
+                    if (q.waves_ref == 8) {
+                        if (tw == 4) return launch32_gs<4, 4, 4>(q, a, ntiles / 4, s);
+                        return share <= 5 ? launch32_gs<2, 4, 5>(q, a, ntiles / 2, s) : launch32_gs<2, 4, 8>(q, a, ntiles / 2, s);
+                    }
+                    if (tw == 4) return launch32_gs<4, 8, 3>(q, a, ntiles / 4, s);
+                    return share <= 3 ? launch32_gs<2, 8, 3>(q, a, ntiles / 2, s) : launch32_gs<2, 8, 5>(q, a, ntiles / 2, s);
+                }
                 return nt2 ? launch32_q<2, D32_PARTIAL>(q, a, (ntiles + 1) / 2, s) : launch32_q<1, D32_PARTIAL>(q, a, ntiles, s);
             }
             KR_CHECK_ARG(q.out || q.out_f32, "kr_linear_decode32: PLAIN output");

@@ -109,8 +109,13 @@ if __name__ == "__main__":
                                               "prefill 8 x 1394, 12/2 heads x 128 causal": ([1394] * 8, 12, 2, 128, True),
                                               "vit 1 x 19276": ([19276], 16, 16, 80, False)}.items():
         outs = {}
-        for qb in (128, 256):
-            ms, tf, o = run(lens, H, KVH, hd, causal, qb)
+        for qb in (128, 256, "256 (4 waves x 64 queries)"):
+            # r4: the one-wave-per-SIMD form of the 256-query workgroup (hd 80 only; KARANTA_ATTN_Q64_NOW is read per call)
+            os.environ["KARANTA_ATTN_Q64_NOW"] = "1" if isinstance(qb, str) else "0"
+            if isinstance(qb, str) and hd != 80:
+                continue
+            ms, tf, o = run(lens, H, KVH, hd, causal, 256 if isinstance(qb, str) else qb)
             outs[qb] = o
             print(f"{name:45s} q_block {qb}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s", flush=True)
-        print("    max |diff| between the two block sizes:", float((outs[128].float() - outs[256].float()).abs().max()), flush=True)
+        os.environ["KARANTA_ATTN_Q64_NOW"] = "0"
+        print("    max |diff| between the block sizes:", max(float((outs[128].float() - o.float()).abs().max()) for o in outs.values()), flush=True)

@@ -49,7 +49,7 @@ def main():
                     help="instead of whole steps: time ONE kind of launch as a chain over the layers' weights (graph of reps x "
                          "layers launches; the per-launch figure includes the dependent-launch gap): comma-separated list of "
                          "qkv,qkv0,attn,merge,o,oheads,gateup,gateup32,down,merge+o; the 17..32-row packed family: resnorm32,qkv32,"
-                         "merge32,o32,gateupxp,down32,down32t1,down32t2; round 3's > 16-row forms: resnorm,qkvd")
+                         "merge32,o32,gateupxp,down32,down32t1,down32t2,down32a,down32gs,down32gs2,down32gs4; round 3's > 16-row forms: resnorm,qkvd")
     ap.add_argument("--cus", default=None,
                     help="comma-separated CU counts: replay each variant's graph on a stream masked to the first N compute units "
                          "(kr_stream_create_cu_mask) — what a decode step keeps when part of the chip is given to something else")
@@ -226,7 +226,7 @@ def chains(a, engines, reset):
                 args = (ptr(eng.d_x), eng.d_x.stride(0), ptr(eng.d_part[:1]), 1, B, ptr(eng.d_x2), eng.d_x2.stride(0), ptr(w.view(p + "ln1.w")),
                         t.rms_norm_eps, ptr(eng.d_h))
                 if kind == "resnorm32":
-                    L.kr_decode_resnorm32(*args, B, t.hidden_size, eng.s)
+                    L.kr_decode_resnorm32(*args, B, t.hidden_size, 0, eng.s)
                 else:
                     L.kr_decode_resnorm(*args, eng.d_h.stride(0), B, t.hidden_size, eng.s)
             elif kind == "qkvd":
@@ -244,6 +244,12 @@ def chains(a, engines, reset):
             elif kind in ("down32", "down32t1", "down32t2"):
                 eng._dec32(DEC_PLAIN, eng.d_act, w.view(p + "down.w"), B, eng.down_waves_small, ksplit=2, out_f32=eng.d_part,
                            tiles_per_wg={"down32": 0, "down32t1": 1, "down32t2": 2}[kind], **eng._w8kw(p + "down.w"))
+            elif kind in ("down32a", "down32gs", "down32gs2", "down32gs4"):   # atomic slab(s): the product form / group split
+                gs = kind != "down32a"
+                acc = eng.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)
+                eng._dec32(DEC_PLAIN, eng.d_act, w.view(p + "down.w"), B, eng.down_waves_small, ksplit=2, out_f32=acc if gs else acc[0],
+                           atomic_out=True, group_split=gs, tiles_per_wg={"down32a": 0, "down32gs": 0, "down32gs2": 2, "down32gs4": 4}[kind],
+                           **({} if gs else eng._w8kw(p + "down.w")))
             elif kind == "attn":
                 L.kr_attn_decode_fused(ptr(eng.d_q), kc, vc, ptr(eng.d_ctx), 0, ptr(eng.d_ws), 0, B, H, KVH, hd, eng.s_max, eng.n_split,
                                        hd ** -0.5, eng.s)

@@ -1,7 +1,7 @@
 """How busy was the GPU?  Union of the kernel intervals of a rocprofv3 --kernel-trace CSV against the span they cover, and
 where the idle time sits: gaps by size class, and for the long gaps which kernel ended before / started after them.
 
-    python gpu_busy.py KERNEL_TRACE.csv [--skip-first-s S] [--long-us 200]
+    python gpu_busy.py KERNEL_TRACE.csv [--skip-first-s S | --last-s S] [--long-us 200]
 
 Used on the corpus run (bench_corpus under rocprofv3): pages/s there is set by the scheduler thread keeping the one GPU
 stream fed, so the number that matters is busy / span, not any single kernel."""
@@ -10,6 +10,7 @@ import argparse, collections, csv, re
 ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--skip-first-s", type=float, default=0.0, help="drop this much of the trace's start (load, warm-up, capture)")
+ap.add_argument("--last-s", type=float, default=0.0, help="keep only this much of the trace's end (the timed region of a run)")
 ap.add_argument("--long-us", type=float, default=200.0)
 a = ap.parse_args()
 
@@ -21,6 +22,8 @@ def short(n):
 
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(a.csv)))
 t_begin = iv[0][0] + int(a.skip_first_s * 1e9)
+if a.last_s > 0:
+    t_begin = max(t_begin, max(e for _, e, _ in iv) - int(a.last_s * 1e9))
 iv = [x for x in iv if x[0] >= t_begin]
 span = (max(e for _, e, _ in iv) - iv[0][0]) / 1e3
 busy, cur_e, prev = 0.0, iv[0][0], None

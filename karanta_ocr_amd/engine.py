@@ -371,7 +371,8 @@ class Engine:
         # decode state
         self.d_x = z(B, t.hidden_size)
         self.d_x2 = z(B, t.hidden_size)  # the other residual buffer (deferred split-K ping-pong)
-        self.d_part = z(2, B, t.hidden_size, dtype=torch.float32)  # down_proj slabs of the deferred split
+        # down_proj slabs of the deferred split: [2][B][hidden]; > 16 rows with the group-split down_proj: two PAIRS (layer parity)
+        self.d_part = z(4 if B > 16 else 2, B, t.hidden_size, dtype=torch.float32)
         # ONE-slab form of the deferred split (KARANTA_ATOMIC_SLAB, default on): down_proj's two K ranges add into one f32
         # accumulator with float atomics (a + b onto zero: order-free, reproducible); two accumulators alternate by layer
         # parity, layer L's qkv launch zeroes the one layer L's down_proj adds into.  d_part doubles as the pair.
@@ -427,6 +428,7 @@ class Engine:
         # down_proj; KARANTA_DEC32=0: round 3's two-column-tile instantiations of the narrow kernel (row-major x fragments)
         # ... with kr_decode_resnorm32 + the packed qkv launch also at the widths whose fused qkv launch fits (KARANTA_RESNORM32_QKV)
         self.resnorm32_qkv = os.environ.get("KARANTA_RESNORM32_QKV", "1") == "1"
+        self.group_split_down = int(os.environ.get("KARANTA_DOWN_GS", "1"))   # 0 off, 1 at 16-atom partitions (2B widths), 2 always
         self.family32 = (self.B > 16 and self.narrow_mode and self.narrow_o and t.intermediate_size % 64 == 0 and t.q_dim % 64 == 0
                          and t.hidden_size % 64 == 0 and os.environ.get("KARANTA_DEC32", "1") == "1")
         if self.row_split and t.hidden_size != 3584:
@@ -445,6 +447,7 @@ class Engine:
         self.d_delta = z(B, dtype=torch.int32)
         self.d_tok = z(B, dtype=torch.int32)
         self.d_fin = z(B, dtype=torch.int32)
+        self._snap_ring, self._snap_next, self._snap_event, self._copy_stream = None, 0, None, None   # snapshot_slots()
         self.d_temp = z(B, dtype=torch.float32)   # per-slot sampling temperature and seed
         self.d_seed = z(B, dtype=torch.int32)
         # guided decoding: per slot the device addresses of its pattern's tables (0 = unconstrained) + its DFA state
@@ -536,7 +539,7 @@ class Engine:
             self.L.kr_linear_decode_narrow(*head, ptr(W), *tail, self.s)
 
     def _dec32(self, mode, xp, W, M, waves_ref, out=None, out_f32=None, bias=None, res=None, ksplit=1, atomic_out=False, zero=None,
-               kc=0, vc=0, w8=None, w_scale=None, tiles_per_wg=0):
+               kc=0, vc=0, w8=None, w_scale=None, tiles_per_wg=0, group_split=False):
         """kr_linear_decode32: the decode linears of a 17..32-row batch on PACKED activations (xp: kr_pack_rows32 layout, written
         by kr_decode_resnorm32 / kr_attn_decode_merge32 / the gate/up launch with DEC_OUT_XP), with the K partition of the
         <= 16-row launch of the same layer (waves_ref, ksplit): row for row the bits that launch produces."""
@@ -545,12 +548,14 @@ class Engine:
         o = out if out is not None else out_f32
         a = Dec32(ptr(xp), ptr(w8 if w8 is not None else W), ptr(w_scale), ptr(bias), ptr(res), res.stride(0) if res is not None else 0,
                   ptr(out), ptr(out_f32), o.stride(-2) if o is not None else 0, M, N, K, waves_ref, ksplit, 1 if atomic_out else 0,
-                  tiles_per_wg, ptr(zero) if zero is not None else None, zero.numel() * 4 if zero is not None else 0,
+                  tiles_per_wg, 1 if group_split else 0, 0, ptr(zero) if zero is not None else None,
+                  zero.numel() * 4 if zero is not None else 0,
                   ptr(self.d_cs), self.max_new, ptr(self.d_plen), ptr(self.d_ctx), ptr(self.d_q), kc or None, vc or None,
                   t.num_heads, t.num_kv_heads, self.s_max)
         self.L.kr_linear_decode32(mode, C.byref(a), self.s)
 
     down_waves_small = 16         # waves per down_proj workgroup at <= 16 rows (instance attribute for sweeps)
+    down_gs_tiles = 0             # weight tiles per workgroup of the group-split down_proj (0: 4 at 8-atom partitions, else 2)
     o_waves = 8                   # waves per o_proj workgroup at <= 16 rows
 
     def _down_waves(self, B: int) -> int:
@@ -1115,6 +1120,14 @@ class Engine:
         pending = False                           # down_proj's split-K sums of the previous layer waiting in d_part
         slabs = self.d_part.view(-1)[: 2 * B * t.hidden_size].view(2, B, t.hidden_size)   # as down_proj packs them
         one_slab = self.atomic_slab and self.defer_down
+        # > 16 rows, bf16 weights: down_proj's K ranges each in TWO workgroups (kr_dec32.group_split) adding into a slab per range;
+        # the pair of a layer parity replaces the one slab, and kr_decode_resnorm32 adds x + (slab 0 + slab 1): the same bits
+        # (measured, profiles/r04_down_group_split.txt: 2B / 32 rows 1.691 -> 1.678 ms per step; at the 7B width, where two tiles
+        # per workgroup already share the x fragments, 3.968 -> 3.983: there it stays off unless KARANTA_DOWN_GS=2)
+        gs = (f32 and one_slab and self.resnorm32_qkv and not self.fp8
+              and (self.group_split_down == 2 or self.group_split_down == 1 and self.down_waves_small == 16)
+              and (t.hidden_size // 16) % (4 if self.down_waves_small == 8 else 2) == 0)
+        pairs = self.d_part.view(-1)[: 4 * B * t.hidden_size].view(2, 2, B, t.hidden_size) if gs else None
         for i in range(nl):
             p = f"llm.{i}."
             kc, vc = ptr(self.kcache[i]), ptr(self.vtcache[i])     # the cache tensors are [layers, max_batch, ...]
@@ -1127,12 +1140,15 @@ class Engine:
                 # layer i - 1's qkv launch, which is complete)
                 zero = slabs[(i + 1) & 1] if (one_slab and i + 1 < nl) else None
                 pin = ((slabs[i & 1:(i & 1) + 1] if one_slab else slabs) if pending else None)
+                if gs:
+                    zero = pairs[(i + 1) & 1] if i + 1 < nl else None
+                    pin = pairs[i & 1] if pending else None
                 if B > 16 and (self.resnorm_qkv or f32 and self.resnorm32_qkv):
                     # the residual sum + RMSNorm ONCE for the batch (bit-identical rows), then ONE qkv launch over all rows
                     args = (ptr(x), x.stride(0), ptr(pin), int(pin.shape[0]) if pin is not None else 0, B, ptr(x_other),
                             x_other.stride(0), ptr(w.view(p + "ln1.w")), t.rms_norm_eps, ptr(self.d_h))
                     if f32:
-                        L.kr_decode_resnorm32(*args, B, t.hidden_size, s)
+                        L.kr_decode_resnorm32(*args, B, t.hidden_size, 1 if (gs and pin is not None) else 0, s)
                         self._dec32(DEC_ROPE_KV, self.d_h, w.view(p + "qkv.w"), B, 8, bias=w.view(p + "qkv.b"), kc=kc, vc=vc,
                                     zero=zero, **self._w8kw(p + "qkv.w"))
                     else:
@@ -1150,8 +1166,8 @@ class Engine:
                     x, x_other = x_other, x
                     pending = False
             # ---- 2. split-KV attention partials, 3. their merge
-            L.kr_attn_decode_fused(ptr(self.d_q), kc, vc, ptr(self.d_ctx), 0, ptr(self.d_ws), 0, B, H, KVH, hd, self.s_max, self.n_split,
-                                   hd ** -0.5, s)
+            L.kr_attn_decode_slots(ptr(self.d_q), kc, vc, ptr(self.d_ctx), ptr(self.d_fin), ptr(self.d_ws), B, H, KVH, hd, self.s_max,
+                                   self.n_split, hd ** -0.5, s)
             if f32:
                 L.kr_attn_decode_merge32(ptr(self.d_ws), ptr(self.d_o), B, H, hd, self.n_split, s)
             else:
@@ -1182,7 +1198,10 @@ class Engine:
             # or (last layer / widths without the deferral) down_proj + residual
             defer = self.defer_down and i + 1 < nl
             acc = slabs[(i + 1) & 1] if (defer and self.atomic_slab) else (self.d_part if defer else None)
-            if f32:
+            if f32 and gs and defer:
+                self._dec32(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, self.down_waves_small, ksplit=2, out_f32=pairs[(i + 1) & 1],
+                            atomic_out=True, group_split=True, tiles_per_wg=self.down_gs_tiles)
+            elif f32:
                 self._dec32(DEC_PLAIN, self.d_act, w.view(p + "down.w"), B, self.down_waves_small, ksplit=2 if defer else 1,
                             out_f32=acc, atomic_out=defer and self.atomic_slab, out=None if defer else x, res=None if defer else x,
                             **self._w8kw(p + "down.w"))
@@ -1437,6 +1456,7 @@ class Engine:
         if self._adm_stream is not None:
             self._adm_stream.synchronize()
         self._adm_inflight = 0
+        self._snap_event = None
         with torch.cuda.stream(self.stream):
             self.d_fin.fill_(1)
             self.d_temp.zero_()
@@ -1556,21 +1576,60 @@ class Engine:
     def poll_slots(self):
         """(finished[B], generated[B]): device EOS flags and tokens generated so far per slot (synchronises)."""
         self.stream.synchronize()
+        self._snap_event = None
         fin = self.d_fin.cpu().numpy().astype(bool)
         gen = (self.d_ctx.cpu().numpy() + 1 - self.d_plen.cpu().numpy()).astype(np.int64)
         return fin, gen
 
+    # poll_slots without draining the stream (SlotScheduler launch-ahead): the slot state as of THIS point of the engine's stream is
+    # copied to pinned host memory behind an event; the scheduler queues the next decode chunk before it waits for that event, so
+    # the GPU has work while the host harvests finished slots and prepares the next admission.
+    def snapshot_slots(self):
+        ring = self._snap_ring
+        if ring is None:
+            ring = self._snap_ring = [torch.empty(3, self.B, dtype=torch.int32).pin_memory() for _ in range(4)]
+        buf = ring[self._snap_next % len(ring)]
+        self._snap_next += 1
+        with torch.cuda.stream(self.stream):
+            buf[0].copy_(self.d_fin, non_blocking=True)
+            buf[1].copy_(self.d_ctx, non_blocking=True)
+            buf[2].copy_(self.d_plen, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return {"buf": buf, "event": ev}
+
+    def read_snapshot(self, snap):
+        """(finished[B], generated[B]) of a snapshot_slots() handle; waits for that point of the stream only.  Later slot_tokens /
+        slot_logprobs reads run on a side stream ordered after the same point (history rows are append-only)."""
+        snap["event"].synchronize()
+        a = snap["buf"].numpy()
+        fin = a[0].astype(bool)
+        gen = (a[1].astype(np.int64) + 1 - a[2])
+        self._snap_event = snap["event"]
+        return fin, gen
+
+    def _host_copy(self, t: "torch.Tensor") -> np.ndarray:
+        """Device -> host of a slot's history.  After read_snapshot(): on the copy stream, behind the snapshot's event, so that the
+        read does not wait for the decode chunk already queued on the engine's stream."""
+        if self._snap_event is None:
+            return t.cpu().numpy()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._copy_stream.wait_event(self._snap_event)
+        with torch.cuda.stream(self._copy_stream):
+            return t.cpu().numpy()
+
     def slot_tokens(self, slot: int, n: int) -> np.ndarray:
-        return self.d_hist[:n, slot].cpu().numpy().astype(np.int64)
+        return self._host_copy(self.d_hist[:n, slot]).astype(np.int64)
 
     def slot_logprobs(self, slot: int, n: int, k: int) -> Dict[str, np.ndarray]:
         """Log-probabilities of the first n generated tokens of a slot (begin_slots(logprobs=...))."""
         if self.d_lp is None or self._logprobs is None:
             raise KarantaHipError("log-probabilities were not recorded: begin_slots(logprobs=k)")
         k = min(int(k), int(self._logprobs))
-        lp = self.d_lp[:n, slot].cpu().numpy()
+        lp = self._host_copy(self.d_lp[:n, slot])
         return {"token": lp[:, 0].copy(), "top": lp[:, 1:1 + k].copy(),
-                "top_ids": self.d_lpi[:n, slot, :k].cpu().numpy().astype(np.int64)}
+                "top_ids": self._host_copy(self.d_lpi[:n, slot, :k]).astype(np.int64)}
 
     def retire(self, slot: int):
         """Host-side stop (length limit): the slot idles from the next step on."""

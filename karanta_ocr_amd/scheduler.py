@@ -45,7 +45,7 @@ class SlotScheduler:
     def __init__(self, engine, max_tokens_cap: int, chunk: int = 8, eos_token_ids: Optional[Sequence[int]] = None,
                  max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False,
                  overlap: bool = False, guided: bool = False, logprobs: Optional[int] = None, admit_min: int = 1,
-                 admit_max_wait: int = 4):
+                 admit_max_wait: int = 4, launch_ahead: bool = False):
         if max_tokens_cap < 1 or chunk < 1:
             raise ValueError("max_tokens_cap and chunk must be >= 1")
         self.engine = engine
@@ -61,6 +61,17 @@ class SlotScheduler:
         # (Engine.admit_begin / admit_ready / admit_end); one admission in flight at a time
         self.overlap = bool(overlap) and all(hasattr(engine, m) for m in ("admit_begin", "admit_ready", "admit_end"))
         self._inflight = None                        # (handle, requests, slots)
+        # launch-ahead (opt-in; engines with snapshot_slots / read_snapshot): the NEXT decode chunk is queued before the host waits for
+        # the previous chunk's slot flags, so harvesting, the server loop and the next admission's host work run while the GPU decodes.
+        # A finished slot is seen one chunk later: a slot may run up to 2 * chunk - 1 steps past its limit.  Measured on the corpus
+        # run (profiles/r04_corpus_launch_ahead.txt): 28.3-28.5 pages/s against 28.6 — the GPU is ~95 % busy without it and the later
+        # harvest costs slot occupancy (0.86 -> 0.84) — so it is OFF by default; it pays where the host is slow relative to a chunk.
+        self.launch_ahead = (bool(launch_ahead) and not self.overlap
+                             and all(hasattr(engine, m) for m in ("snapshot_slots", "read_snapshot")))
+        self.over = (2 if self.launch_ahead else 1) * int(chunk)
+        self._snap = None                            # (sequence number, handle) of the chunk whose flags are read next
+        self._snap_seq = 0                           # snapshots taken so far
+        self._adm_seq: Dict[int, int] = {}           # slot -> snapshots taken when its request was admitted
         # Admission batching: while sequences are decoding, wait until `admit_min` slots are free (and as many requests
         # wait) before interrupting the decode graph with an admission — one ViT + prefill over several pages runs its
         # GEMMs at several times the rows of a single page — but never longer than `admit_max_wait` scheduler steps.
@@ -84,7 +95,7 @@ class SlotScheduler:
             kw["guided"] = True
         if logprobs is not None:
             kw["logprobs"] = int(logprobs)
-        engine.begin_slots(self.cap + self.chunk, **kw)
+        engine.begin_slots(self.cap + self.over, **kw)
 
     # ------------------------------------------------------------------ public
     def submit(self, req: SlotRequest) -> None:
@@ -101,6 +112,8 @@ class SlotScheduler:
         return len(self.active)
 
     def step(self) -> List[SlotResult]:
+        if self.launch_ahead:
+            return self._step_ahead()
         if not self.overlap:
             t0 = time.perf_counter()
             done: List[SlotResult] = self._admit()
@@ -123,6 +136,32 @@ class SlotScheduler:
         if self.active:
             done += self._harvest()
         return done
+
+    def _step_ahead(self) -> List[SlotResult]:
+        done: List[SlotResult] = []
+        t0 = time.perf_counter()
+        if self.active:
+            if self._snap is None:                   # nothing queued yet: this chunk's flags are the first to be read
+                self._decode_chunk()
+                self._snap = self._take_snapshot()
+            self._decode_chunk()                     # the GPU's work while the host does everything below
+            nxt = self._take_snapshot()
+            t1 = time.perf_counter()
+            fin, gen = self.engine.read_snapshot(self._snap[1])
+            done += self._harvest((fin, gen), self._snap[0])
+            self._snap = nxt if self.active else None
+            t2 = time.perf_counter()
+            self.phase_s["decode_launch"] += t1 - t0
+            self.phase_s["harvest"] += t2 - t1
+            t0 = t2
+        done += self._admit()                        # queued behind the chunk that is executing
+        self.phase_s["admit"] += time.perf_counter() - t0
+        return done
+
+    def _take_snapshot(self):
+        seq = self._snap_seq
+        self._snap_seq += 1
+        return seq, self.engine.snapshot_slots()
 
     def _decode_chunk(self):
         self.engine.decode_steps(self.chunk)
@@ -183,7 +222,7 @@ class SlotScheduler:
                 # alone, as a client error; whatever is admitted with it is unaffected
                 self.waiting.popleft()
                 failed.append(self._failure(r, f"prompt ({n_tok} tokens) + max_tokens ({min(int(r.max_tokens), self.cap)}) + "
-                                               f"{self.chunk} scheduler steps exceed the sequence capacity {room}", status=400))
+                                               f"{self.over} scheduler steps exceed the sequence capacity {room}", status=400))
                 continue
             n_patch = sum(int(np.prod(g)) for g in getattr(r.page, "grids", None) or [])   # from the grids: pages may
             #                                                    carry uint8 images (GPU front end) instead of patches
@@ -219,6 +258,7 @@ class SlotScheduler:
             for r, j, n in zip(batch, slots, lens):
                 self.active[j] = r
                 self.prompt_len[j] = int(n)
+                self._adm_seq[j] = self._snap_seq    # snapshots taken from now on see this request in the slot
             self.admissions += 1
             self.pages_admitted += len(batch)
         return failed
@@ -226,7 +266,7 @@ class SlotScheduler:
     def _budget(self, r: SlotRequest) -> int:
         """Cache rows a request may write after its prompt: its token limit plus the steps a slot can run past it
         before the host looks at the flags again."""
-        return min(int(r.max_tokens), self.cap) + self.chunk
+        return min(int(r.max_tokens), self.cap) + self.over
 
     def _budget_kw(self, batch) -> dict:
         # engines that check capacity per request take the budgets (test fakes without seq_room do not)
@@ -235,10 +275,14 @@ class SlotScheduler:
     def _failure(self, r: SlotRequest, msg: str, status: int = 500) -> SlotResult:
         return SlotResult(r.tag, np.zeros(0, np.int64), "length", 0, error=msg, request=r, status=status)
 
-    def _harvest(self) -> List[SlotResult]:
-        fin, gen = self.engine.poll_slots()
+    def _harvest(self, flags=None, seq: Optional[int] = None) -> List[SlotResult]:
+        """Requests that finished.  flags / seq: a snapshot's (finished, generated) and its sequence number — slots admitted after it
+        was taken still show their previous occupant there and are skipped."""
+        fin, gen = flags if flags is not None else self.engine.poll_slots()
         out: List[SlotResult] = []
         for j in sorted(self.active):
+            if seq is not None and self._adm_seq.get(j, 0) > seq:
+                continue
             r = self.active[j]
             limit = min(int(r.max_tokens), self.cap)
             if not (fin[j] or gen[j] >= limit):

@@ -341,7 +341,7 @@ class LocalServer:
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
                  batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
                  chunk: int = 8, honor_temperature: bool = True, max_logprobs: Optional[int] = None, admit_min: int = 1,
-                 admit_max_wait: int = 4, overlap_admissions: bool = False):
+                 admit_max_wait: int = 4, overlap_admissions: bool = False, launch_ahead: bool = False):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
         self.honor_temperature = bool(honor_temperature)   # False: every request is served greedy
         # guided decoding needs the tokenizer's byte strings on the device; engines without set_vocab (test fakes)
@@ -358,6 +358,7 @@ class LocalServer:
         # continuous mode: ViT + prefill of an admission on a second (CU-masked: Engine(admission_cus=...)) stream while the
         # other slots keep decoding (SlotScheduler(overlap=True))
         self.overlap_admissions = bool(overlap_admissions)
+        self.launch_ahead = bool(launch_ahead)
         self._q: "queue.Queue" = queue.Queue()
         self._running = 0
         self._stop = False
@@ -543,7 +544,8 @@ class LocalServer:
         try:
             sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature,
                                 guided=self.guided, logprobs=self.max_logprobs, admit_min=self.admit_min,
-                                admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions)
+                                admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions,
+                                launch_ahead=self.launch_ahead)
         except Exception as e:  # cannot enter slot mode: every request gets a 500
             sch, boot_error = None, f"{type(e).__name__}: {e}"
         self._sch = sch
@@ -582,7 +584,8 @@ class LocalServer:
                 try:
                     sch = SlotScheduler(self.engine, self.max_tokens_cap, self.chunk, sampling=self.honor_temperature,
                                         guided=self.guided, logprobs=self.max_logprobs, admit_min=self.admit_min,
-                                        admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions)
+                                        admit_max_wait=self.admit_max_wait, overlap=self.overlap_admissions,
+                                launch_ahead=self.launch_ahead)
                 except Exception as e2:
                     sch, boot_error = None, f"{type(e2).__name__}: {e2}"
                 self._sch = sch

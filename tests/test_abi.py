@@ -32,7 +32,7 @@ def test_header_has_the_survey_operator_set():
     protos = header_prototypes()
     for name in ("kr_layernorm", "kr_rmsnorm", "kr_gemm_bf16", "kr_rope2d_vision", "kr_mrope", "kr_attn_varlen",
                  "kr_kv_append", "kr_attn_decode_gqa", "kr_embed_scatter", "kr_argmax", "kr_bcast_weights",
-                 "kr_linear_decode", "kr_attn_decode_fused", "kr_sample_greedy"):
+                 "kr_linear_decode", "kr_attn_decode_fused", "kr_attn_decode_slots", "kr_sample_greedy"):
         assert name in protos, name
 
 

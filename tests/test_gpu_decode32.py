@@ -44,9 +44,9 @@ def ints(rng, *shape, lo=-1, hi=2):
 
 def dec32(L, mode, xp, W, M, N, K, waves_ref, ksplit=1, out=None, out_f32=None, ldc=0, bias=None, res=None, ldr=0, w_scale=None,
           atomic=False, tiles=0, zero=None, zero_bytes=0, cs=None, cs_stride=0, plen=None, ctx=None, q=None, kc=None, vc=None,
-          heads=0, kv_heads=0, s_max=64):
+          heads=0, kv_heads=0, s_max=64, gs=False):
     a = Dec32(ptr(xp), ptr(W), ptr(w_scale), ptr(bias), ptr(res), ldr, ptr(out), ptr(out_f32), ldc, M, N, K, waves_ref, ksplit,
-              1 if atomic else 0, tiles, ptr(zero), zero_bytes, ptr(cs), cs_stride, ptr(plen), ptr(ctx), ptr(q), ptr(kc), ptr(vc),
+              1 if atomic else 0, tiles, 1 if gs else 0, 0, ptr(zero), zero_bytes, ptr(cs), cs_stride, ptr(plen), ptr(ctx), ptr(q), ptr(kc), ptr(vc),
               heads, kv_heads, s_max)
     L.kr_linear_decode32(mode, C.byref(a), 0)
 
@@ -130,6 +130,15 @@ def test_linear_decode32_gives_the_narrow_launch_bits(L, M, N, K, waves, ksplit,
             np.testing.assert_array_equal(acc.cpu().numpy(), r[0] + r[1])
             oc = other.cpu().numpy()
             assert not oc[:M * N].any() and (oc[M * N:] == 3.0).all(), "zeroing job: exactly the requested range"
+            # group split: each K range's atoms in two workgroups adding into the range's slab = the narrow launch's slab of
+            # that range (its fold is (first half of the waves) + (second half))
+            if ksplit == 2 and tiles == 0:
+                for tw in (0, 2, 4):                      # 0: the launch's own choice (4 at 8-atom partitions, else 2)
+                    if (N // 16) % (tw or (4 if waves == 8 else 2)):
+                        continue
+                    pair = torch.zeros(2, M, N, dtype=torch.float32, device=DEV)
+                    dec32(L, DEC_PLAIN, xp, Wd, M, N, K, waves, ksplit=2, out_f32=pair, ldc=N, atomic=True, gs=True, tiles=tw)
+                    np.testing.assert_array_equal(pair.cpu().numpy(), r)
 
 
 @pytest.mark.parametrize("M", [19, 32])
@@ -205,7 +214,7 @@ def test_resnorm32_then_qkv32_gives_the_resnorm_and_direct_qkv_bits(L, H, KVH, K
             hrows = host(h)
         else:
             hp = torch.full((32 * K,), 9.0, dtype=torch.bfloat16, device=DEV)
-            L.kr_decode_resnorm32(ptr(xd), K, ptr(pd), 1, B, ptr(xo), K, ptr(nd), 1e-6, ptr(hp), B, K, 0)
+            L.kr_decode_resnorm32(ptr(xd), K, ptr(pd), 1, B, ptr(xo), K, ptr(nd), 1e-6, ptr(hp), B, K, 0, 0)
             np.testing.assert_array_equal(unpack_rows32(host(hp), K)[:B], hrows)
             dec32(L, DEC_ROPE_KV, hp, Wd, B, N, K, 8, bias=bd, cs=cs_d, cs_stride=T, plen=pl_d, ctx=ctx_d, q=q_d, kc=kc_d, vc=vt_d, heads=H,
                   kv_heads=KVH, s_max=s_max, w_scale=sd)
@@ -268,3 +277,23 @@ def test_linear_decode32_rejects_bad_arguments(L):
         dec32(L, DEC_PLAIN, z, z, 32, 16, 64, 8, out=o, ldc=16, atomic=True)
     with pytest.raises(KarantaHipError, match="mode"):
         dec32(L, DEC_SILU8, z, z, 32, 16, 64, 8, out=o, ldc=16)
+
+
+@pytest.mark.parametrize("B,K", [(32, 1536), (21, 3584), (17, 256)])
+def test_resnorm32_sum_slabs_first_is_the_one_slab_sum(L, B, K):
+    """x + (slab 0 + slab 1) (the slabs of a group-split down_proj) = x + the one atomically accumulated slab of <= 16 rows."""
+    rng = np.random.default_rng(B + K)
+    x, nw = rnd(rng, B, K), rnd(rng, K)
+    s0, s1 = (rng.standard_normal((B, K)).astype(np.float32) for _ in range(2))
+    xd, nd = dev_bf16(x), dev_bf16(nw)
+    two = torch.from_numpy(np.stack([s0, s1])).to(DEV)
+    one = torch.from_numpy(s0 + s1).to(DEV)
+    outs = []
+    for part, n, first in ((two, 2, 1), (one, 1, 0)):
+        xo, hp = torch.zeros(B, K, dtype=torch.bfloat16, device=DEV), torch.zeros(32 * K, dtype=torch.bfloat16, device=DEV)
+        L.kr_decode_resnorm32(ptr(xd), K, ptr(part), n, B, ptr(xo), K, ptr(nd), 1e-6, ptr(hp), B, K, first, 0)
+        outs.append((host(xo), host(hp)))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    with pytest.raises(KarantaHipError):
+        L.kr_decode_resnorm32(ptr(xd), K, ptr(one), 1, B, ptr(xo), K, ptr(nd), 1e-6, ptr(hp), B, K, 1, 0)

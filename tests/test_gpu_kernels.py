@@ -633,10 +633,12 @@ def run_prep_attn(L, lens, H, KVH, hd, causal, seed, as_cache=False, s_max=256, 
     assert_close_bf16(host(o), ref, rel=2 ** -6, abs_=2e-2, what="attention out")
 
 
-@pytest.mark.parametrize("q_block", [128, 256])
-@pytest.mark.parametrize("lens", [[24], [64], [130, 5, 200], [129], [1, 63, 65], [257, 300]])
-def test_vit_attention_hd80(L, lens, q_block):
-    run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens), q_block=q_block)
+@pytest.mark.parametrize("q_block", [128, 256, "4x64"])
+@pytest.mark.parametrize("lens", [[24], [64], [130, 5, 200], [129], [1, 63, 65], [257, 300], [4900]])
+def test_vit_attention_hd80(L, lens, q_block, monkeypatch):
+    """"4x64": the 256-query workgroup as 4 waves x 64 queries (attn_varlen_q64_kernel, one wave per SIMD)."""
+    monkeypatch.setenv("KARANTA_ATTN_Q64_NOW", "1" if q_block == "4x64" else "0")
+    run_prep_attn(L, lens, H=4, KVH=4, hd=80, causal=False, seed=sum(lens), q_block=256 if q_block == "4x64" else q_block)
 
 
 @pytest.mark.parametrize("lens", [[4900], [4920, 1408]])
@@ -1871,6 +1873,16 @@ def test_attn_decode_partials_then_merge_launch(L, H, KVH, n_split, config5):
     for b, c in enumerate(ctxs):
         ref = np_attention(q[b][:, None], kc[b, :, :c + 1], vc[b, :, :c + 1], hd ** -0.5, False)
         assert_close_bf16(got[b:b + 1], ref, rel=2 ** -6, abs_=2e-2, what=f"partials + merge b={b} n_split={n_split}")
+    # the serving form: slots whose finished flag is set are skipped (their partials stay as they were), live slots get the same bits
+    fin = torch.tensor([b % 3 == 1 for b in range(B)], dtype=torch.int32, device=DEV)
+    ws2 = torch.full_like(ws, 5.0)
+    L.kr_attn_decode_slots(ptr(q_d), ptr(kc_d), ptr(vt_d), ptr(ctx_d), ptr(fin), ptr(ws2), B, H, KVH, hd, s_max, n_split, hd ** -0.5, 0)
+    a, b2 = ws.cpu().numpy().reshape(B, -1), ws2.cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        if b % 3 == 1:
+            assert (b2[b] == 5.0).all(), f"slot {b} is finished: untouched"
+        else:
+            np.testing.assert_array_equal(b2[b], a[b])
 
 
 @pytest.mark.parametrize("H,KVH", [(2, 1), (12, 2), (28, 4)])

@@ -253,3 +253,43 @@ def test_admission_batching_waits_for_several_free_slots_but_not_forever():
     sch2.run(reqs())
     assert all(len(e[1]) >= 2 or i == len([x for x in eng2.log if x[0] == "admit"]) - 1
                for i, e in enumerate([x for x in eng2.log if x[0] == "admit"]))
+
+
+class AheadEngine(FakeEngine):
+    """FakeEngine with the snapshot API: the scheduler queues one decode chunk ahead of the flags it reads."""
+
+    def begin_slots(self, max_new, sampling=False):
+        super().begin_slots(max_new, sampling)
+        self.snaps = 0
+
+    def snapshot_slots(self):
+        self.snaps += 1
+        return np.asarray(self.fin).copy(), np.asarray(self.gen).copy()
+
+    def read_snapshot(self, snap):
+        return snap
+
+    def poll_slots(self):
+        raise AssertionError("launch-ahead reads snapshots, it never drains the stream")
+
+
+def test_launch_ahead_gives_the_same_results_one_chunk_later():
+    reqs = lambda: [SlotRequest(Page([k, 0, 0]), mt, tag=f"r{k}") for k, mt in [(0, 10), (1, 9), (2, 5), (3, 30), (4, 30), (5, 32)]]
+    base = SlotScheduler(FakeEngine(2, SCRIPT), max_tokens_cap=32, chunk=4)
+    assert not base.launch_ahead and base.over == 4
+    want = base.run(reqs())
+    eng = AheadEngine(2, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=32, chunk=4, launch_ahead=True)
+    assert sch.launch_ahead and sch.over == 8 and eng.max_new == 32 + 8
+    got = sch.run(reqs())
+    for a, b in zip(got, want):
+        assert a.tag == b.tag and a.tokens.tolist() == b.tokens.tolist() and a.finish_reason == b.finish_reason and a.error is None
+    assert sch.idle and sch.running == 0 and eng.snaps >= 2
+    # a slot re-filled after a snapshot was taken is not harvested from that snapshot (it still shows the previous occupant's EOS)
+    eng = AheadEngine(1, SCRIPT)
+    sch = SlotScheduler(eng, max_tokens_cap=64, chunk=2, launch_ahead=True)
+    res = sch.run([SlotRequest(Page([2]), 5, tag="a"), SlotRequest(Page([4]), 20, tag="b"), SlotRequest(Page([5]), 50, tag="c")])
+    assert [r.tokens.tolist() for r in res] == [[99], [6] * 7 + [99], [9] * 50]
+    assert max(len(h) for h in eng.hist) <= 50 + 4             # at most 2 chunks past a limit
+    # off unless asked for
+    assert not SlotScheduler(AheadEngine(1, SCRIPT), max_tokens_cap=8, chunk=2).launch_ahead
