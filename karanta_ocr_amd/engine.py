@@ -411,6 +411,7 @@ class Engine:
         self.wide_mode = os.environ.get("KARANTA_WIDE", "1") == "1" and t.hidden_size % 512 == 0 and t.hidden_size <= 4096
         self.wide_blocks = int(os.environ.get("KARANTA_WIDE_BLOCKS", "256"))
         self.wide_waves = int(os.environ.get("KARANTA_WIDE_WAVES", "0"))  # 0: ceil(tiles / blocks), at most 8
+        self.wide_spread32 = os.environ.get("KARANTA_WIDE_SPREAD32", "1") == "1"   # > 16 rows: tiles dealt as at <= 16 rows (_wide_geometry)
         if self.B > 16 and not (self.wide_mode and self.narrow_mode and self.narrow_o and t.intermediate_size % 64 == 0):
             raise KarantaHipError("max_batch > 16 needs the wide / narrow decode kernels (hidden_size % 512 == 0) and hidden_size <= 2048 or == 3584")
         # Above 16 rows the decode linears hold two 16-row column tiles per weight fragment, with all 32 normalised x rows
@@ -578,6 +579,12 @@ class Engine:
         (4 rows per wave) stages all 32 rows — with 5 waves 12 rows went the slow way, behind the weight ring
         (gate/up at B = 32: 16.7 -> 14.7 us)."""
         tiles = N // 16
+        if M > 16 and not self.wide_waves and self.wide_spread32:
+            # r4: 8 waves stage the 32 rows, but the TILES are dealt as at <= 16 rows — to as many workgroups as there are compute
+            # units to pull them (2B gate/up: 1120 tiles = 224 workgroups whose waves 0..4 own one tile each and waves 5..7 only
+            # help with the prologue; 140 x 8 left 116 compute units without a weight stream)
+            own = min(8, -(-tiles // self.wide_blocks))
+            return min(self.wide_blocks, -(-tiles // own)), 8
         waves = self.wide_waves or (8 if M > 16 else min(8, -(-tiles // self.wide_blocks)))
         return min(self.wide_blocks, -(-tiles // waves)), waves
 
