@@ -338,3 +338,18 @@ def test_attn_plan_picks_the_workgroup_shape():
         P.make_attn_plan([300], [0], [0], False, q_block=64)
 
 
+
+
+def test_gpu_busy_tool_on_a_synthetic_trace(tmp_path):
+    """csrc/tools/gpu_busy.py (the corpus run's busy fraction, profiles/r04_corpus_gpu_busy.txt): union of intervals, gaps by class and
+    by the kernels on both sides."""
+    import os, subprocess, sys
+    csv = tmp_path / "trace.csv"
+    csv.write_text("Kernel_Name,Start_Timestamp,End_Timestamp\n"
+                   "void a<1>(int),0,1000\nvoid b(int),1500,2500\nvoid c(int),2400,3000\nvoid d(int),303000,304000\n")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "karanta_ocr_amd", "csrc", "tools", "gpu_busy.py")
+    out = subprocess.run([sys.executable, tool, str(csv)], capture_output=True, text=True, check=True).stdout
+    assert "kernels 4" in out and "= 1.2 %" in out                      # 3500 ns busy of 304000
+    assert "c  ->  d" in out and "n=    1  avg    300.0 us" in out       # the one long gap, attributed
+    out = subprocess.run([sys.executable, tool, str(csv), "--last-s", "0.0000015"], capture_output=True, text=True, check=True).stdout
+    assert "kernels 1" in out and "= 100.0 %" in out
