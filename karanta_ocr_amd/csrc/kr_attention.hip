@@ -386,7 +386,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
         // with __launch_bounds__ spills into the loop: 1.65 ms per ViT block against 1.42 on the same box.)
         // causal: a wave whose 32 queries all sit before this tile's first key has nothing to add (every score would be
         // masked: p = 0 exactly), it only takes part in the staging — waves 0 and 1 of a block skip its last tile
-        if (!CAUSAL || t * 64 <= q_pos0 + wave * 32 + 31) {
+        // a wave without a valid query (the ragged last query block of a segment: 4900 = 19 x 256 + 36 leaves six of eight waves
+        // empty) only takes part in the staging: the matrix pipe and the LDS ports go to the waves that have rows
+        // (8-wave workgroups only: the same test in the 4-wave instantiation measured 5 % slower on full blocks)
+        if ((!CAUSAL || t * 64 <= q_pos0 + wave * 32 + 31) && (NW == 4 || wave * 32 < n_q)) {
         bf16x8 kf[2][C::KS];
         if (HD == 128) {
             // k_lds_off(32 sub + lq, 2 ks + lh) = 8192 sub + [256 lq + ((lh ^ (lq & 15)) << 4)] ^ (ks << 5): ONE lane
