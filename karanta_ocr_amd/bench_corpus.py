@@ -193,6 +193,9 @@ def main(argv=None):
                     help="queue the next decode chunk before waiting for the previous chunk's flags (SlotScheduler(launch_ahead=True); "
                          "measured: no gain on this workload, profiles/r04_corpus_launch_ahead.txt)")
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU front end")
+    ap.add_argument("--upload-at-admission", action="store_true",
+                    help="r3 behaviour: the decoded page crosses PCIe at admission, on the scheduler thread (default: at parse time, in "
+                         "the request's thread, on a stream of its own)")
     ap.add_argument("--guided", action="store_true", help="every request carries the pipeline's guided_regex")
     ap.add_argument("--gpus", type=int, default=None,
                     help="the node: N servers through launch.py (real cli, one checkpoint read + RCCL broadcast), least-loaded routing, "
@@ -220,7 +223,8 @@ def main(argv=None):
     limits = rng.integers(args.t_min, args.t_max + 1, size=args.pages).tolist()
     urls = [IP.encode_png_data_url(IP.synthetic_page(100 + i, args.page, args.page)) for i in range(args.distinct)]
     tok = S.ByteTokenizer(cfg)
-    front = S.ChatFrontend(cfg, tok, max_pixels=1003520, device_images=not args.host_images)
+    front = S.ChatFrontend(cfg, tok, max_pixels=1003520, device_images=not args.host_images,
+                           upload_device=None if (args.host_images or args.upload_at_admission) else "cuda:0")
     probe = front.parse({"messages": [{"role": "user", "content": [{"type": "text", "text": PROMPT},
                                                                     {"type": "image_url", "image_url": {"url": urls[0]}}]}],
                          "max_tokens": 1})

@@ -182,7 +182,8 @@ def make_server(args, log=print):
                              else "none shipped with the checkpoint: hand-coded Qwen2-VL template"))
     front = ChatFrontend(cfg, HFTokenizer(os.path.join(args.model_dir, "tokenizer.json"), cfg), min_pixels=min_pixels,
                          max_pixels=max_pixels,
-                         max_model_len=args.max_model_len, device_images=not args.host_images, chat_template=template)
+                         max_model_len=args.max_model_len, device_images=not args.host_images, chat_template=template,
+                         upload_device=None if args.host_images else "cuda:0")
     return LocalServer(eng, front, served_model_name=args.served_model_name, log=log, continuous=not args.static_batching,
                        max_tokens_cap=min(args.max_tokens_cap, args.max_model_len), honor_temperature=not args.greedy,
                        max_logprobs=args.max_logprobs, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait)

@@ -141,8 +141,16 @@ class ChatFrontend:
 
     def __init__(self, cfg: ModelConfig, tokenizer, min_pixels: int = IP.MIN_PIXELS,
                  max_pixels: int = IP.MAX_PIXELS_CLASS_DEFAULT, max_model_len: int = 16384, device_images: bool = False,
-                 chat_template: Optional[str] = None):
+                 chat_template: Optional[str] = None, upload_device: Optional[str] = None):
         self.cfg, self.tok = cfg, tokenizer
+        # device_images + upload_device: the decoded page goes to HBM HERE, in the request's own thread and on a stream of its
+        # own, instead of at admission on the scheduler thread (a blocking 3 MB copy per page with the GPU waiting behind it)
+        self._upload_device, self._upload_stream = None, None
+        if upload_device is not None and device_images:
+            import torch
+            if torch.cuda.is_available():
+                self._upload_device = torch.device(upload_device)
+                self._upload_stream = torch.cuda.Stream(device=self._upload_device)
         # the checkpoint's own jinja template (load_chat_template); None: the hand-coded Qwen2-VL turns below
         self._template = None
         if chat_template:
@@ -181,6 +189,16 @@ class ChatFrontend:
         self.device_images = bool(device_images)
         self.max_model_len = max_model_len  # reference --max_model_len default (pipeline.py:1225-1230)
         self._guide_cache: Dict[str, Any] = {}   # regex -> guided.Guide (the pipeline sends one pattern for every page)
+
+    def _upload(self, u8: np.ndarray):
+        """HWC uint8 page -> a tensor resident in HBM (Engine.patches_from_images takes it as it is).  The copy blocks this thread
+        and the upload stream only; the request holds the tensor until it has been answered."""
+        import torch
+        with torch.cuda.stream(self._upload_stream):
+            u8 = np.ascontiguousarray(u8)
+            if not u8.flags.writeable:        # PIL-backed arrays are read-only views
+                u8 = u8.copy()
+            return torch.from_numpy(u8).to(self._upload_device)
 
     def _guide_for(self, req: Dict[str, Any]):
         """guided_regex (pipeline.py:304-307) / response_format (vllm_client.py:196) -> byte DFA, or None."""
@@ -289,7 +307,7 @@ class ChatFrontend:
                         except ValueError as e:
                             raise BadRequest(str(e)) from e
                         grid = (1, rh // self.cfg.vision.patch_size, rw // self.cfg.vision.patch_size)
-                        images.append(u8)
+                        images.append(self._upload(u8) if self._upload_device is not None else u8)
                     else:
                         pv, grid = IP.image_to_patches(img, self.min_pixels, self.max_pixels)
                         pvs.append(pv)
