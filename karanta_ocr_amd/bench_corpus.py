@@ -180,18 +180,18 @@ def main(argv=None):
     ap.add_argument("--slots", type=int, default=32)
     ap.add_argument("--t-min", type=int, default=64)
     ap.add_argument("--t-max", type=int, default=512)
-    ap.add_argument("--chunk", type=int, default=8, help="decode steps between two looks at the finished flags (r3 sweep: 6-8 best)")
+    ap.add_argument("--chunk", type=int, default=2,
+                    help="decode steps between two looks at the finished flags (r4: 2 with launch-ahead; the r3 loop wanted 6-8)")
     ap.add_argument("--page", type=int, default=1024)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans (encoded once, cycled)")
     ap.add_argument("--admit", type=int, default=8, help="pages one admission may prefill together")
     ap.add_argument("--admit-min", type=int, default=6, help="free slots (and waiting requests) an admission waits for while others decode")
-    ap.add_argument("--admit-max-wait", type=int, default=8, help="... but never longer than this many scheduler steps")
+    ap.add_argument("--admit-max-wait", type=int, default=48, help="... but never longer than this many scheduler steps (of --chunk decode steps)")
     ap.add_argument("--overlap-cus", type=int, default=None,
                     help="overlap admissions with decoding: ViT + prefill on a stream restricted to this many CUs "
                          "(kr_stream_create_cu_mask; 0 = an ordinary second stream; unset = admissions interrupt the decode graph)")
-    ap.add_argument("--launch-ahead", action="store_true",
-                    help="queue the next decode chunk before waiting for the previous chunk's flags (SlotScheduler(launch_ahead=True); "
-                         "measured: no gain on this workload, profiles/r04_corpus_launch_ahead.txt)")
+    ap.add_argument("--no-launch-ahead", action="store_true",
+                    help="the r3 loop: wait for a chunk's flags before queueing the next one (use with --chunk 8 --admit-max-wait 8)")
     ap.add_argument("--host-images", action="store_true", help="PIL resize on the host instead of the GPU front end")
     ap.add_argument("--upload-at-admission", action="store_true",
                     help="r3 behaviour: the decoded page crosses PCIe at admission, on the scheduler thread (default: at parse time, in "
@@ -236,7 +236,7 @@ def main(argv=None):
     eng.load_weights(random_weights(cfg, 0, as_bits=True))
     srv = S.LocalServer(eng, front, log=lambda *_: None, continuous=True, max_tokens_cap=args.t_max, chunk=args.chunk,
                         honor_temperature=False, admit_min=args.admit_min, admit_max_wait=args.admit_max_wait,
-                        overlap_admissions=args.overlap_cus is not None, launch_ahead=args.launch_ahead)
+                        overlap_admissions=args.overlap_cus is not None, launch_ahead=not args.no_launch_ahead)
     port = 8791
     S.register_local_server(port, srv)
     guided = GUIDED
@@ -283,7 +283,7 @@ def main(argv=None):
                     f"VLLMClient.generate -> LocalServer(continuous), {args.workers} worker threads, {B} decode slots, "
                     f"max_tokens U[{args.t_min},{args.t_max}] (mean {np.mean(limits):.0f}), prompt {P} tokens, "
                     f"admit_min {args.admit_min} (max wait {args.admit_max_wait} x {args.chunk} steps), "
-                    f"{'chunks queued one ahead, ' if args.launch_ahead and args.overlap_cus is None else ''}"
+                    f"{'chunks queued one ahead, ' if not args.no_launch_ahead and args.overlap_cus is None else ''}"
                     f"{'admissions interrupt the decode graph' if args.overlap_cus is None else 'admissions overlapped on ' + (str(args.overlap_cus) + ' CUs' if args.overlap_cus else 'an unmasked second stream')}, "
                     f"{'host PIL' if args.host_images else 'GPU'} image front end, {'guided_regex' if args.guided else 'greedy'}, "
                     f"random-init weights",

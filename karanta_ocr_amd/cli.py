@@ -63,7 +63,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--admit-min", type=int, default=1,
                     help="while sequences decode, wait for this many free slots + waiting requests before an admission "
                          "(6: +8 %% pages/s on a saturated server, profiles/r03_corpus_sweep.txt; 1: lowest latency)")
-    ap.add_argument("--admit-max-wait", type=int, default=8, help="... but at most this many scheduler steps of 8 decode steps")
+    ap.add_argument("--admit-max-wait", type=int, default=48, help="... but at most this many scheduler steps of 2 decode steps")
     ap.add_argument("--quantization", default=None, choices=("fp8",),
                     help="decoder Linears as fp8 codes + row scales (vLLM's flag; implied by a checkpoint with a quantization_config)")
     ap.add_argument("--max-logprobs", type=int, default=None,
@@ -166,7 +166,7 @@ def make_server(args, log=print):
     max_prompt_tokens, max_patches = admission_budget(args, cfg, max_pixels)
     log(f"admission budget: {max_prompt_tokens} prompt tokens / {max_patches} image patches per ViT + prefill pass, "
         f"{args.max_num_seqs} decode slots of {args.max_model_len} tokens")
-    # cache rows per slot: the model length + the steps a slot may run past its limit before the scheduler looks (2 chunks of 8
+    # cache rows per slot: the model length + the steps a slot may run past its limit before the scheduler looks (2 chunks of up to 8
     # with launch-ahead) + the parking row
     eng = Engine(cfg, device="cuda:0", max_batch=args.max_num_seqs, s_max=(args.max_model_len + 17 + 63) // 64 * 64,
                  max_patches=max_patches, max_prompt_tokens=max_prompt_tokens,

@@ -45,7 +45,7 @@ class SlotScheduler:
     def __init__(self, engine, max_tokens_cap: int, chunk: int = 8, eos_token_ids: Optional[Sequence[int]] = None,
                  max_prompt_tokens: Optional[int] = None, max_patches: Optional[int] = None, sampling: bool = False,
                  overlap: bool = False, guided: bool = False, logprobs: Optional[int] = None, admit_min: int = 1,
-                 admit_max_wait: int = 4, launch_ahead: bool = False):
+                 admit_max_wait: int = 4, launch_ahead: bool = True):
         if max_tokens_cap < 1 or chunk < 1:
             raise ValueError("max_tokens_cap and chunk must be >= 1")
         self.engine = engine
@@ -61,11 +61,11 @@ class SlotScheduler:
         # (Engine.admit_begin / admit_ready / admit_end); one admission in flight at a time
         self.overlap = bool(overlap) and all(hasattr(engine, m) for m in ("admit_begin", "admit_ready", "admit_end"))
         self._inflight = None                        # (handle, requests, slots)
-        # launch-ahead (opt-in; engines with snapshot_slots / read_snapshot): the NEXT decode chunk is queued before the host waits for
-        # the previous chunk's slot flags, so harvesting, the server loop and the next admission's host work run while the GPU decodes.
-        # A finished slot is seen one chunk later: a slot may run up to 2 * chunk - 1 steps past its limit.  Measured on the corpus
-        # run (profiles/r04_corpus_launch_ahead.txt): 28.3-28.5 pages/s against 28.6 — the GPU is ~95 % busy without it and the later
-        # harvest costs slot occupancy (0.86 -> 0.84) — so it is OFF by default; it pays where the host is slow relative to a chunk.
+        # launch-ahead (engines with snapshot_slots / read_snapshot): the NEXT decode chunk is queued before the host waits for the
+        # previous chunk's slot flags, so harvesting, the server loop and the next admission's host work run while the GPU decodes.
+        # A finished slot is seen one chunk later (a slot may run up to 2 * chunk - 1 steps past its limit), so it goes with SHORT
+        # chunks: measured on the corpus run (profiles/r04_corpus_launch_ahead.txt) chunk 8 loses 1 % to the r3 loop (slot occupancy
+        # 0.86 -> 0.84), chunks of 2 gain 2 % (29.6-29.9 against 29.15 pages/s) — the server's defaults.
         self.launch_ahead = (bool(launch_ahead) and not self.overlap
                              and all(hasattr(engine, m) for m in ("snapshot_slots", "read_snapshot")))
         self.over = (2 if self.launch_ahead else 1) * int(chunk)

@@ -354,12 +354,13 @@ class LocalServer:
     ``generate`` call and leaves together.  ``continuous=True``: the slot scheduler (scheduler.SlotScheduler) —
     a request leaves as soon as it hits EOS or its ``max_tokens`` and the next waiting request is prefilled into
     its slot while the others keep decoding; ``max_tokens_cap`` bounds any request's ``max_tokens`` and
-    ``chunk`` is the number of decode steps between two looks at the device's finished flags."""
+    ``chunk`` is the number of decode steps between two looks at the device's finished flags (with launch_ahead the next chunk is
+    queued before the look: scheduler.SlotScheduler)."""
 
     def __init__(self, engine, frontend: ChatFrontend, served_model_name: str = "karantaocr",
                  batch_wait_s: float = 0.005, log=print, continuous: bool = False, max_tokens_cap: int = 4096,
-                 chunk: int = 8, honor_temperature: bool = True, max_logprobs: Optional[int] = None, admit_min: int = 1,
-                 admit_max_wait: int = 4, overlap_admissions: bool = False, launch_ahead: bool = False):
+                 chunk: int = 2, honor_temperature: bool = True, max_logprobs: Optional[int] = None, admit_min: int = 1,
+                 admit_max_wait: int = 16, overlap_admissions: bool = False, launch_ahead: bool = True):
         self.engine, self.frontend, self.name = engine, frontend, served_model_name
         self.honor_temperature = bool(honor_temperature)   # False: every request is served greedy
         # guided decoding needs the tokenizer's byte strings on the device; engines without set_vocab (test fakes)
@@ -428,7 +429,8 @@ class LocalServer:
             return 400, {"error": {"message": f"logprobs: this server records at most {self.max_logprobs} top_logprobs "
                                               "(start it with --max-logprobs)", "type": "BadRequestError", "code": 400}}
         room = self.engine.seq_room() if hasattr(self.engine, "seq_room") else None
-        need = len(parsed.input_ids) + min(int(parsed.max_tokens), self.max_tokens_cap) + (self.chunk if self.continuous else 0)
+        over = self.chunk * (2 if self.launch_ahead and not self.overlap_admissions else 1)   # steps past its limit (scheduler.over)
+        need = len(parsed.input_ids) + min(int(parsed.max_tokens), self.max_tokens_cap) + (over if self.continuous else 0)
         if room is not None and need > room:
             # the request's OWN prompt + max_tokens against one sequence's cache rows: a client error for this request
             # only (the reference skips the attempt on 400, pipeline.py:321-332) — never an engine exception that

@@ -291,5 +291,6 @@ def test_launch_ahead_gives_the_same_results_one_chunk_later():
     res = sch.run([SlotRequest(Page([2]), 5, tag="a"), SlotRequest(Page([4]), 20, tag="b"), SlotRequest(Page([5]), 50, tag="c")])
     assert [r.tokens.tolist() for r in res] == [[99], [6] * 7 + [99], [9] * 50]
     assert max(len(h) for h in eng.hist) <= 50 + 4             # at most 2 chunks past a limit
-    # off unless asked for
-    assert not SlotScheduler(AheadEngine(1, SCRIPT), max_tokens_cap=8, chunk=2).launch_ahead
+    # the default where the engine can do it; opt-out
+    assert SlotScheduler(AheadEngine(1, SCRIPT), max_tokens_cap=8, chunk=2).launch_ahead
+    assert not SlotScheduler(AheadEngine(1, SCRIPT), max_tokens_cap=8, chunk=2, launch_ahead=False).launch_ahead
