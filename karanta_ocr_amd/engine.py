@@ -350,6 +350,7 @@ class Engine:
         self.v_perm = None  # Qwen2.5-VL: window-order gather indices live in the per-geometry cache
         self.v_m1 = z(N // 4 + 1, v.merge_dim)
         self._vit_cache = {}
+        self._vit_rot_cache = {}   # (t, h, w) -> (cos, sin) of one image, resident in HBM (_vit_tables)
         self.img_embeds = z(N // 4 + 1, t.hidden_size)
         # decoder prefill
         self.p_x = z(M, t.hidden_size)
@@ -625,8 +626,22 @@ class Engine:
         if hit is None:
             v, dev = self.cfg.vision, self.device
             plan = POS.vit_attn_plan(key)
-            cos, sin = POS.vision_rotary_tables(key, v.head_dim, v.spatial_merge_size)
             t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            # the rotary tables of an image depend on its own grid only: kept per grid, so that a batch of a new COMPOSITION (every
+            # admission of a corpus with mixed page sizes) costs a concatenation on the device, not ~0.7 ms of numpy per page with the
+            # GPU waiting (the work lists below are a few hundred integers)
+            per_img = []
+            for g in key:
+                hit_i = self._vit_rot_cache.get(g)
+                if hit_i is None:
+                    c_i, s_i = POS.vision_rotary_tables((g,), v.head_dim, v.spatial_merge_size)
+                    hit_i = (t_(c_i), t_(s_i))
+                    if len(self._vit_rot_cache) > 64:
+                        self._vit_rot_cache.clear()
+                    self._vit_rot_cache[g] = hit_i
+                per_img.append(hit_i)
+            cos = per_img[0][0] if len(per_img) == 1 else torch.cat([c for c, _ in per_img])
+            sin = per_img[0][1] if len(per_img) == 1 else torch.cat([s_ for _, s_ in per_img])
             dplan = lambda pl: (pl, t_(pl.blk_tok0), t_(pl.blk_ntok), t_(pl.blk_k_row0), t_(pl.blk_vt_blk), t_(pl.qblk),
                                 t_(pl.qblk_len))
             extra = None
@@ -636,9 +651,10 @@ class Engine:
                 unit = v.spatial_merge_size ** 2
                 order, win_lens = POS.vision_window_order(key, v.spatial_merge_size, v.window_size, v.patch_size)
                 perm = (order[:, None] * unit + np.arange(unit)[None, :]).reshape(-1)      # patch-level gather
-                cos, sin = cos[perm], sin[perm]
+                perm_long = t_(perm.astype(np.int64))
+                cos, sin = cos.index_select(0, perm_long), sin.index_select(0, perm_long)
                 extra = (t_(perm.astype(np.int32)), t_(np.argsort(order).astype(np.int32)), dplan(POS.segments_attn_plan(win_lens)))
-            hit = (plan, t_(cos), t_(sin), t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0),
+            hit = (plan, cos, sin, t_(plan.blk_tok0), t_(plan.blk_ntok), t_(plan.blk_k_row0),
                    t_(plan.blk_vt_blk), t_(plan.qblk), t_(plan.qblk_len), extra)
             if len(self._vit_cache) > 16:
                 self._vit_cache.clear()
