@@ -286,6 +286,9 @@ class Engine:
         self.n_split = decode_splits
         self._ignore_eos = self._freeze_finished = self._want_logits = self._sampling = False
         self._guided = False          # the decode graph masks logits by the slots' DFA states and advances them
+        # what the current mode ALLOWS (begin_slots(sampling=, guided=); generate(): what its pages need): _sampling / _guided say
+        # what the next decode step RUNS — in slot mode they follow the requests that are actually in the slots (set_step_features)
+        self._cap_sampling = self._cap_guided = False
         self._logprobs = None         # None or k: the decode graph records log-probabilities (kr_logprobs_topk)
         self._adm_stream = None                          # second stream of the overlapped admission (slot mode)
         # overlapped admissions run on a stream restricted to this many compute units (kr_stream_create_cu_mask), so the
@@ -891,9 +894,10 @@ class Engine:
             if g is None:
                 rows.append((0, 0, 0, None))
                 continue
-            if not self._guided:
+            if not self._cap_guided:
                 raise KarantaHipError("a page carries a guide but the engine is not in its guided configuration "
                                       "(generate() decides from its pages; begin_slots(guided=True) for slot mode)")
+            self._guided = self._sampling = True      # from this admission on the steps carry the masked sampling pass
             dg = self.compile_guide(g)
             rows.append((dg.trans.data_ptr(), dg.masks.data_ptr(), dg.start, dg))
         return rows
@@ -1000,9 +1004,11 @@ class Engine:
             self._h2d(self.p_sin, sin)
             temps = np.asarray([float(getattr(p, "temperature", 0.0) or 0.0) for p in pages], np.float32)
             seeds = np.asarray([int(getattr(p, "seed", 0) or 0) & 0xFFFFFFFF for p in pages], np.uint32).view(np.int32)
-            if temps.max(initial=0.0) > 0 and not self._sampling:
-                raise KarantaHipError("a page asks for temperature > 0 but the engine is in its greedy configuration "
-                                      "(generate() decides from its pages; begin_slots(sampling=True) for slot mode)")
+            if temps.max(initial=0.0) > 0:
+                if not self._cap_sampling:
+                    raise KarantaHipError("a page asks for temperature > 0 but the engine is in its greedy configuration "
+                                          "(generate() decides from its pages; begin_slots(sampling=True) for slot mode)")
+                self._sampling = True
             grows = self._guide_rows(pages)
             if whole_batch:
                 tb, sb = np.zeros(self.B, np.float32), np.zeros(self.B, np.int32)
@@ -1360,6 +1366,7 @@ class Engine:
         self._guided = any(getattr(p, "guide", None) is not None for p in pages)
         # a guided row is masked in the sampling pass, so that pass runs (rows with T = 0 stay a plain argmax)
         self._sampling = self._guided or any(float(getattr(p, "temperature", 0.0) or 0.0) > 0 for p in pages)
+        self._cap_sampling, self._cap_guided = self._sampling, self._guided
         ks = [int(p.logprobs) for p in pages if getattr(p, "logprobs", None) is not None]
         if ks and not 0 <= max(ks) <= 20:
             raise KarantaHipError("logprobs must be in 0..20")
@@ -1470,6 +1477,7 @@ class Engine:
         self._ignore_eos, self._freeze_finished, self._want_logits = False, True, False
         self._guided = bool(guided)
         self._sampling = bool(sampling) or self._guided
+        self._cap_sampling, self._cap_guided = self._sampling, self._guided
         self._logprobs = None if logprobs is None else int(logprobs)
         self._last_batch = self.B
         self._ensure_history(max_new_tokens)
@@ -1563,6 +1571,15 @@ class Engine:
                                    rec.get("guides"))
             self._first_tokens(rec["slots"])
         return rec["lens"]
+
+    def set_step_features(self, sampling: bool, guided: bool):
+        """Slot mode: which passes the NEXT decode steps carry, within what begin_slots() allowed.  The scheduler calls it with what
+        the requests in the slots need: a server that accepts guided / sampled requests runs the plain argmax graph (no f32 logits
+        written and re-read, no DFA advance) while none is decoding — rows with temperature 0 and no guide get the same token from
+        either graph.  An admission that brings a guide or a temperature switches the passes on by itself (prefill)."""
+        guided = bool(guided) and self._cap_guided
+        self._guided = guided
+        self._sampling = (bool(sampling) and self._cap_sampling) or guided
 
     def decode_steps(self, n: int):
         """n decode steps over all slots (asynchronous on the engine's stream).  While an admission is in flight on a CU-masked

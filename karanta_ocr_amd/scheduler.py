@@ -12,6 +12,7 @@ retire`, and any object with those six methods (the CPU tests use a fake) can st
 from __future__ import annotations
 
 import collections
+import os
 import time
 from dataclasses import dataclass
 from typing import Any, Deque, Dict, Iterable, List, Optional, Sequence
@@ -96,6 +97,10 @@ class SlotScheduler:
         if logprobs is not None:
             kw["logprobs"] = int(logprobs)
         engine.begin_slots(self.cap + self.over, **kw)
+        # engines that can switch the sampling / guided passes of the decode graph off while no request in a slot needs them
+        self._features = ((sampling or guided) and hasattr(engine, "set_step_features")
+                          and os.environ.get("KARANTA_STEP_FEATURES", "1") == "1")
+        self._features_now = None
 
     # ------------------------------------------------------------------ public
     def submit(self, req: SlotRequest) -> None:
@@ -164,6 +169,12 @@ class SlotScheduler:
         return seq, self.engine.snapshot_slots()
 
     def _decode_chunk(self):
+        if self._features:      # the passes the steps carry follow the requests that are in the slots right now
+            need_g = any(getattr(r.page, "guide", None) is not None for r in self.active.values())
+            need_s = need_g or any(float(getattr(r.page, "temperature", 0.0) or 0.0) > 0 for r in self.active.values())
+            if (need_s, need_g) != self._features_now:
+                self.engine.set_step_features(need_s, need_g)
+                self._features_now = (need_s, need_g)
         self.engine.decode_steps(self.chunk)
         self.steps += self.chunk
         self.slot_steps_busy += self.chunk * len(self.active)
